@@ -1,0 +1,62 @@
+"""Shared test helpers.  GPU tests are marked ``@pytest.mark.gpu``."""
+import json
+import os
+import sys
+
+import networkx as nx
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run via gpurun)')
+
+
+def load_golden(name):
+    with open(os.path.join(GOLDEN, name + '.json')) as f:
+        return json.load(f)
+
+
+def tree_from_edges(edges, nodes=None):
+    """Rebuild the nx.Graph in the fixture's edge insertion order (adjacency
+    order decides the reference's preorder, so it must be preserved)."""
+    T = nx.Graph()
+    if nodes is not None:
+        T.add_nodes_from(nodes)
+    for a, b, w in edges:
+        T.add_edge(int(a), int(b), weight=float(w))
+    return T
+
+
+def config_from_golden(fx):
+    """Fixture -> (T, root, nstates, Q_default, root_distn, list of per-site
+    node_to_allowed_states dicts)."""
+    T = tree_from_edges(fx['edges'])
+    root = fx['root']
+    n = fx['nstates']
+    Q_default = None
+    if 'Q_default' in fx:
+        Q_default = np.array(fx['Q_default'])
+    else:
+        for na, nb in nx.bfs_edges(T, root):
+            T[na][nb]['Q'] = np.array(fx['Q_edges'][str(nb)])
+    sites = []
+    for row in fx['leaf_states']:
+        d = dict((v, set(range(n))) for v in T)
+        for leaf, s in zip(fx['leaves'], row):
+            if fx['obs_kind'] == 'state':
+                d[leaf] = {int(s)}
+            else:
+                d[leaf] = set(fx['leaf_allowed'][int(s)])
+        sites.append(d)
+    return T, root, n, Q_default, np.array(fx['root_distn']), sites
+
+
+@pytest.fixture(scope='session')
+def golden():
+    return load_golden

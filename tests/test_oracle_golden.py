@@ -1,0 +1,181 @@
+"""
+Pins the oracle (oracle/oracle_numpy.py) to the reference: every golden vector
+in tests/golden/ was produced by the reference's own pure-Python code
+(tools/gen_golden.py), plus the literal known answers of its test-suite.
+CPU only.
+"""
+import itertools
+
+import networkx as nx
+import numpy as np
+import pytest
+
+from conftest import load_golden, tree_from_edges, config_from_golden
+from oracle import oracle_numpy as orc
+
+RTOL = 1e-12
+
+
+def test_rerooting_known_answer():
+    # reference tests/test_mjp.py:91-164; SURVEY known answer 0.002296828148732273
+    fx = load_golden('test_mjp_rerooting')
+    T = tree_from_edges(fx['edges'])
+    Q = np.array(fx['Q'])
+    distn = np.array(fx['root_distn'])
+    n = fx['nstates']
+    allowed = dict((v, set(range(n))) for v in T)
+    for k, s in fx['node_to_state'].items():
+        allowed[int(k)] = {s}
+    for r in fx['rootings']:
+        lk = orc.mjp_dense_get_likelihood(T, allowed, r['root'], n,
+                                          root_distn=distn, Q_default=Q)
+        assert lk == pytest.approx(r['likelihood'], rel=RTOL)
+        assert lk == pytest.approx(0.002296828148732273, rel=1e-12)
+        assert lk == pytest.approx(r['marginalised'], rel=1e-12)
+
+
+def test_sum_to_one():
+    # reference tests/test_mjp.py:52-89
+    fx = load_golden('sum_to_one')
+    T = tree_from_edges(fx['edges'])
+    Q = np.array(fx['Q'])
+    distn = np.array(fx['root_distn'])
+    total = 0.0
+    for assignment, want in zip(fx['assignments'], fx['likelihoods']):
+        allowed = dict((v, {s}) for v, s in enumerate(assignment))
+        lk = orc.mjp_dense_get_likelihood(T, allowed, 0, 3, root_distn=distn,
+                                          Q_default=Q)
+        assert lk == pytest.approx(want, rel=RTOL)
+        total += lk
+    assert total == pytest.approx(1.0, rel=1e-12)
+
+
+def test_kat_four_log_half():
+    # reference tests/test_mc.py:131-150: fully observed history
+    fx = load_golden('kat_history')
+    assert fx['history_log_likelihood'] == 4 * np.log(0.5)
+    T = tree_from_edges(fx['edges'])
+    P = np.array(fx['P'])
+    for a, b in T.edges():
+        T[a][b]['P'] = P
+    allowed = dict((int(k), {v}) for k, v in fx['node_to_state'].items())
+    lk = orc.mcy_dense_get_likelihood(T, 0, 3, node_to_allowed_states=allowed,
+                                      root_distn=np.array(fx['root_distn']))
+    assert np.log(lk) == pytest.approx(4 * np.log(0.5), rel=1e-15)
+
+
+def test_jukes_cantor_closed_form():
+    # reference _conditional_expectation.py:15-33
+    fx = load_golden('jukes_cantor')
+    for row in fx['rows']:
+        n, t = row['n'], row['t']
+        Q = np.full((n, n), 1.0 / (n - 1))
+        np.fill_diagonal(Q, 0)
+        Q -= np.diag(Q.sum(axis=1))
+        for expm in (orc.custom_expm, orc.expm_pade):
+            P = expm(Q, t)
+            assert P[0, 0] == pytest.approx(row['p_same'], rel=1e-12)
+            assert P[0, 1] == pytest.approx(row['p_diff'], rel=1e-12)
+
+
+def test_random_sparse_trees_type_y_and_z():
+    # set-up of reference tests/test_mc.py:52-102; expected values from the
+    # reference's unaccelerated pset/set/pmap and _mcz pmap
+    fx = load_golden('random_sparse')
+    assert any(c['zero'] for c in fx['cases'])
+    for c in fx['cases']:
+        n = c['nstates']
+        T = tree_from_edges(c['edges'], nodes=c['nodes'])
+        root = c['root']
+        for na, nb in nx.bfs_edges(T, root):
+            T[na][nb]['P'] = np.array(c['P'][str(nb)])
+        allowed = dict((int(k), set(v)) for k, v in c['allowed'].items())
+        pre, idx, ptr, esd = orc.get_esd_transitions(T, root, n)
+        mask = orc.define_state_mask(allowed, pre, n)
+        m1 = orc.mcy_esd_get_node_to_pset(idx, ptr, esd, mask.copy())
+        for i, v in enumerate(pre):
+            assert set(np.flatnonzero(m1[i])) == set(c['pset'][str(v)])
+        m2 = orc.esd_get_node_to_set(idx, ptr, esd, m1.copy())
+        for i, v in enumerate(pre):
+            assert set(np.flatnonzero(m2[i])) == set(c['set'][str(v)])
+        pmap = orc.mcy_esd_get_node_to_pmap(idx, ptr, esd, m2)
+        for i, v in enumerate(pre):
+            np.testing.assert_allclose(pmap[i], c['pmap'][str(v)],
+                                       rtol=RTOL, atol=0)
+        distn = np.array(c['root_distn'])
+        if c['zero']:
+            with pytest.raises(orc.StructuralZeroProb):
+                orc.mc0_get_likelihood(pmap[0], root_distn=distn)
+        else:
+            lk = orc.mc0_get_likelihood(pmap[0], root_distn=distn)
+            assert lk == pytest.approx(c['likelihood'], rel=RTOL)
+        # type-z (reference _mcz.py:140-163)
+        obs = np.array([c['obs_lik'][str(v)] for v in pre])
+        pz = orc.mcy_esd_get_node_to_pmap(idx, ptr, esd, m2, obs_lik=obs)
+        for i, v in enumerate(pre):
+            np.testing.assert_allclose(pz[i], c['pmap_z'][str(v)],
+                                       rtol=RTOL, atol=0)
+
+
+@pytest.mark.parametrize('name', ['c1', 'c2', 'c3', 'c5'])
+def test_config_fixtures(name):
+    fx = load_golden('config_' + name)
+    T, root, n, Q_default, distn, sites = config_from_golden(fx)
+    # single-site reference-shaped entry point
+    for allowed, want in zip(sites[:2], fx['likelihoods']):
+        lk = orc.mjp_dense_get_likelihood(T, allowed, root, n,
+                                          root_distn=distn,
+                                          Q_default=Q_default)
+        assert lk == pytest.approx(want, rel=1e-11)
+    # batched form
+    pre, idx, ptr, esd = orc.get_expm_augmented_transitions(
+        T, root, n, Q_default=Q_default)
+    for k, P in fx['P_scipy'].items():
+        np.testing.assert_allclose(esd[pre.index(int(k))], np.array(P),
+                                   rtol=1e-12, atol=1e-300)
+    obs_nodes = [pre.index(v) for v in fx['leaves']]
+    obs = np.zeros((len(sites), len(obs_nodes), n))
+    for i, allowed in enumerate(sites):
+        for k, v in enumerate(fx['leaves']):
+            obs[i, k, sorted(allowed[v])] = 1.0
+    ll, status = orc.batch_log_likelihoods(idx, ptr, esd, obs_nodes, obs,
+                                           root_distn=distn)
+    assert not status.any()
+    np.testing.assert_allclose(ll, fx['log_likelihoods'], rtol=1e-11)
+    if 'pmaps' in fx:
+        mask = orc.define_state_mask(sites[0], pre, n)
+        _, pmap = orc.esd_get_node_to_pmap(idx, ptr, esd, mask)
+        for i, v in enumerate(pre):
+            np.testing.assert_allclose(pmap[i], fx['pmaps'][0][str(v)],
+                                       rtol=1e-11, atol=0)
+
+
+def test_expm_pade_matches_scipy_fixture():
+    # reference tests/test_expm.py:20-82 matrix families + model matrices
+    fx = load_golden('expm')
+    worst = 0.0
+    for row in fx['rows']:
+        Q = np.array(row['Q'])
+        want = np.array(row['P'])
+        got = orc.expm_pade(Q, row['t'])
+        err = np.abs(got - want).max() / max(1.0, np.abs(want).max())
+        worst = max(worst, err)
+        np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-14)
+        np.testing.assert_allclose(orc.custom_expm(Q, row['t']), want,
+                                   rtol=1e-13, atol=1e-300)
+    assert worst < 1e-13
+
+
+def test_single_node_tree_and_errors():
+    # reference _mcy_dense.py:472-487, _mjp_dense.py:397-398
+    T = nx.Graph()
+    T.add_node(7)
+    Q = np.array([[-1.0, 1.0], [2.0, -2.0]])
+    assert orc.mjp_dense_get_likelihood(T, {7: {0}}, 7, 2, None, Q) == 1
+    lk = orc.mjp_dense_get_likelihood(T, {7: {0, 1}}, 7, 2,
+                                      np.array([0.25, 0.5]), Q)
+    assert lk == pytest.approx(0.75)
+    with pytest.raises(orc.StructuralZeroProb):
+        orc.mjp_dense_get_likelihood(T, {7: set()}, 7, 2, None, Q)
+    with pytest.raises(ValueError):
+        orc.mjp_dense_get_likelihood(T, {7: {0}}, 8, 2, None, Q)

@@ -1,0 +1,426 @@
+#!/usr/bin/env python
+"""
+Generate tests/golden/*.json by running the REFERENCE's own pure-Python code.
+
+Runs only in the build container (it reads /root/reference); the GPU box never
+needs it.  Nothing from the reference is copied: the outputs are data (inputs +
+expected outputs).  Import recipe: the two package
+``__init__`` files import the long-gone ``numpy.testing.Tester``, so empty
+package objects whose ``__path__`` points at the reference directories are
+registered instead, and an empty module named ``pyfelscore`` lets ``_mcy`` and
+``_mcz`` import (none of the functions used below calls into it: they are the
+reference's "unaccelerated" twins, ``_mcy.py:396-470,611-682``,
+``_mcz.py:94-166``, ``_mc0.py:89-138``).
+
+Reference functions exercised:
+  _mcx.get_likelihood / get_node_to_pmap      raoteh/sampler/_mcx.py:141-256
+  _mc0.get_likelihood                          raoteh/sampler/_mc0.py:202-252
+  _mc0.get_history_log_likelihood              raoteh/sampler/_mc0.py:141-199
+  _mc0.get_node_to_set_unaccelerated           raoteh/sampler/_mc0.py:89-138
+  _mcy.unaccelerated_get_node_to_pset/_pmap    raoteh/sampler/_mcy.py:396-470,611-682
+  _mcz.get_node_to_pmap                        raoteh/sampler/_mcz.py:94-166
+  _conditional_expectation.get_jukes_cantor_*  raoteh/sampler/_conditional_expectation.py:15-33
+expm per edge is ``scipy.linalg.expm(Q*t)`` exactly as ``_mjp_dense.py:24-25``.
+
+usage: python tools/gen_golden.py [--out tests/golden]
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import itertools
+import json
+import os
+import sys
+import time
+import types
+
+import networkx as nx
+import numpy as np
+import scipy
+import scipy.linalg
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+REF = '/root/reference'
+
+
+def import_reference():
+    for name, path in (('raoteh', REF + '/raoteh'),
+                       ('raoteh.sampler', REF + '/raoteh/sampler')):
+        m = types.ModuleType(name)
+        m.__path__ = [path]
+        sys.modules[name] = m
+    sys.modules.setdefault('pyfelscore', types.ModuleType('pyfelscore'))
+    mods = {}
+    for mod in ('_util', '_density', '_mc0', '_mcx', '_mcy', '_mcz',
+                '_conditional_expectation'):
+        mods[mod] = importlib.import_module('raoteh.sampler.' + mod)
+    return mods
+
+
+def dense_to_nx(P):
+    """Dense transition matrix -> the weighted nx.DiGraph the sparse reference
+    API uses; zero entries are absent edges (structural zeros)."""
+    G = nx.DiGraph()
+    n = P.shape[0]
+    G.add_nodes_from(range(n))
+    for i in range(n):
+        for j in range(n):
+            if P[i, j] != 0:
+                G.add_edge(i, j, weight=float(P[i, j]))
+    return G
+
+
+def tree_json(T):
+    return [[int(a), int(b), dict((k, v) for k, v in d.items()
+                                  if k == 'weight')]
+            for a, b, d in T.edges(data=True)]
+
+
+def edges_in_insertion_order(T):
+    return [[int(a), int(b), float(d.get('weight', 1.0))]
+            for a, b, d in T.edges(data=True)]
+
+
+def augmented(T, root, Q_default):
+    """nx tree whose BFS edges carry P = expm(Q*t) as nx.DiGraph (for the
+    reference's sparse API) and the same P dense (for the fixture)."""
+    T_aug = nx.Graph()
+    T_aug.add_nodes_from(T)
+    dense = {}
+    for na, nb in nx.bfs_edges(T, root):
+        edge = T[na][nb]
+        Q = edge.get('Q', Q_default)
+        P = scipy.linalg.expm(np.asarray(Q) * edge['weight'])
+        T_aug.add_edge(na, nb, weight=edge['weight'], P=dense_to_nx(P))
+        dense[nb] = P
+    return T_aug, dense
+
+
+def ref_type_y(mods, T_aug, root, node_to_allowed_states):
+    """Likelihood + pmaps for allowed-set observations through the reference's
+    unaccelerated functions."""
+    _mc0, _mcy = mods['_mc0'], mods['_mcy']
+    pset = _mcy.unaccelerated_get_node_to_pset(
+        T_aug, root, node_to_allowed_states=node_to_allowed_states)
+    nset = _mc0.get_node_to_set_unaccelerated(T_aug, root, pset)
+    pmap = _mcy.unaccelerated_get_node_to_pmap(
+        T_aug, root, node_to_allowed_states=node_to_allowed_states,
+        node_to_set=nset)
+    return pset, nset, pmap
+
+
+def pmap_json(pmap, nstates):
+    return dict((str(int(v)), [float(m.get(s, 0.0)) for s in range(nstates)])
+                for v, m in pmap.items())
+
+
+def set_json(d):
+    return dict((str(int(v)), sorted(int(s) for s in ss))
+                for v, ss in d.items())
+
+
+# ---------------------------------------------------------------------------
+# fixtures
+# ---------------------------------------------------------------------------
+
+def fixture_test_mjp(mods):
+    """tests/test_mjp.py:91-164 inputs; likelihood for every rooting and the
+    16-term marginalisation."""
+    _mcx, _mc0 = mods['_mcx'], mods['_mc0']
+    T = nx.Graph()
+    T.add_weighted_edges_from([(0, 1, 2.0), (0, 2, 3.0), (0, 3, 4.0),
+                               (1, 4, 5.0), (1, 5, 6.0)])
+    nstates = 4
+    distn = {0: 0.1, 1: 0.2, 2: 0.3, 3: 0.4}
+    Q = np.zeros((4, 4))
+    for a, b, w in [(0, 1, 1.0 * distn[1]), (1, 0, 1.0 * distn[0]),
+                    (1, 2, 2.0 * distn[2]), (2, 1, 2.0 * distn[1]),
+                    (2, 3, 1.0 * distn[3]), (3, 2, 1.0 * distn[2]),
+                    (3, 0, 2.0 * distn[0]), (0, 3, 2.0 * distn[3])]:
+        Q[a, b] = w
+    Q -= np.diag(Q.sum(axis=1))
+    node_to_state = {2: 0, 3: 1, 4: 2, 5: 3}
+    out = dict(edges=edges_in_insertion_order(T), nstates=nstates,
+               root_distn=[distn[s] for s in range(4)], Q=Q.tolist(),
+               node_to_state=dict((str(k), v) for k, v in node_to_state.items()),
+               rootings=[])
+    for root in range(6):
+        T_aug, _ = augmented(T, root, Q)
+        lk = _mcx.get_likelihood(T_aug, root, node_to_state=node_to_state,
+                                 root_distn=distn)
+        marg = 0.0
+        for s0 in range(4):
+            for s1 in range(4):
+                nm = dict(node_to_state)
+                nm[0] = s0
+                nm[1] = s1
+                try:
+                    marg += _mcx.get_likelihood(T_aug, root, node_to_state=nm,
+                                                root_distn=distn)
+                except mods['_util'].StructuralZeroProb:
+                    pass
+        out['rootings'].append(dict(root=root, likelihood=lk,
+                                    marginalised=marg))
+    return out
+
+
+def fixture_sum_to_one(mods):
+    """tests/test_mjp.py:52-89 with a fixed seed: star tree, 3 states, all 81
+    singleton assignments; the likelihoods sum to 1."""
+    _mcx = mods['_mcx']
+    rng = np.random.RandomState(20131004)
+    T = nx.Graph()
+    T.add_weighted_edges_from([(0, 1, 2.0), (0, 2, 3.0), (0, 3, 4.0)])
+    n = 3
+    w = rng.exponential(size=n)
+    distn = w / w.sum()
+    Q = rng.exponential(size=(n, n))
+    np.fill_diagonal(Q, 0)
+    Q -= np.diag(Q.sum(axis=1))
+    T_aug, _ = augmented(T, 0, Q)
+    liks = []
+    for assignment in itertools.product(range(n), repeat=4):
+        nts = dict(zip(range(4), assignment))
+        lk = _mcx.get_likelihood(
+            T_aug, 0, node_to_state=nts,
+            root_distn=dict(enumerate(distn.tolist())))
+        liks.append(lk)
+    return dict(edges=edges_in_insertion_order(T), nstates=n, root=0,
+                root_distn=distn.tolist(), Q=Q.tolist(),
+                assignments=[list(a) for a in
+                             itertools.product(range(n), repeat=4)],
+                likelihoods=liks, total=float(np.sum(liks)))
+
+
+def fixture_kat_history(mods):
+    """tests/test_mc.py:131-150: history log likelihood == 4*log(0.5)."""
+    _mc0 = mods['_mc0']
+    T = nx.Graph()
+    T.add_edge(0, 1)
+    T.add_edge(0, 2)
+    T.add_edge(0, 3)
+    P = np.array([[0.5, 0.25, 0.25], [0.25, 0.5, 0.25], [0.25, 0.25, 0.5]])
+    node_to_state = {0: 0, 1: 0, 2: 0, 3: 0}
+    root_distn = {0: 0.5, 1: 0.5, 2: 0, 3: 0}
+    ll = _mc0.get_history_log_likelihood(T, 0, node_to_state,
+                                         root_distn=root_distn,
+                                         P_default=dense_to_nx(P))
+    return dict(edges=[[0, 1, 1.0], [0, 2, 1.0], [0, 3, 1.0]], nstates=3,
+                P=P.tolist(), root=0, root_distn=[0.5, 0.5, 0.0],
+                node_to_state={'0': 0, '1': 0, '2': 0, '3': 0},
+                history_log_likelihood=ll,
+                literal='4*log(0.5)', literal_value=4 * np.log(0.5))
+
+
+def fixture_jukes_cantor(mods):
+    """_conditional_expectation.py:25-33: p_ij(t) closed form vs the rate
+    matrix of :15-23 (weights 1/(n-1))."""
+    ce = mods['_conditional_expectation']
+    rows = []
+    for n in (3, 4, 7):
+        for t in (0.01, 0.5, 2.0, 10.0):
+            rows.append(dict(
+                n=n, t=t,
+                p_same=ce.get_jukes_cantor_probability(0, 0, t, n),
+                p_diff=ce.get_jukes_cantor_probability(0, 1, t, n)))
+    return dict(rows=rows)
+
+
+def _random_sparse_P(rng, n):
+    """Random row-stochastic matrix with one structural zero per row
+    (the generator pattern of tests/test_mc.py:33-49)."""
+    P = np.zeros((n, n))
+    for i in range(n):
+        jmiss = rng.randint(n)
+        w = rng.exponential(size=n)
+        w[jmiss] = 0
+        P[i] = w / w.sum()
+    return P
+
+
+def fixture_random_sparse(mods, ncases=24):
+    """Random small trees with a random sparse P on every edge, sparse root
+    distribution, and one disallowed state per node (the set-up of
+    tests/test_mc.py:52-102, seed fixed): per-node pset / set / pmap and the
+    likelihood (or StructuralZeroProb) from the reference's unaccelerated
+    type-y path; plus a type-z variant with random observation likelihoods."""
+    _mc0, _mcz, _util = mods['_mc0'], mods['_mcz'], mods['_util']
+    rng = np.random.RandomState(1234)
+    cases = []
+    for case in range(ncases):
+        n = int(rng.randint(2, 6))
+        nnodes = int(rng.randint(2, 9))
+        # random recursive tree with shuffled, non-contiguous ids
+        ids = (rng.permutation(30)[:nnodes] + 3).tolist()
+        T = nx.Graph()
+        T.add_node(ids[0])
+        Ps = {}
+        for k in range(1, nnodes):
+            parent = ids[rng.randint(k)]
+            T.add_edge(parent, ids[k], weight=1.0)
+        root = ids[int(rng.randint(nnodes))]
+        T_aug = nx.Graph()
+        T_aug.add_nodes_from(T)
+        for na, nb in nx.bfs_edges(T, root):
+            P = _random_sparse_P(rng, n)
+            Ps[nb] = P
+            T_aug.add_edge(na, nb, P=dense_to_nx(P))
+        w = rng.exponential(size=n)
+        w[rng.randint(n)] = 0
+        distn = w / w.sum()
+        distn_dict = dict((i, float(p)) for i, p in enumerate(distn) if p)
+        allowed = dict((v, set(range(n))) for v in T)
+        for v in T:
+            allowed[v].discard(int(rng.randint(n)))
+        rec = dict(edges=[[int(a), int(b), 1.0] for a, b in T.edges()],
+                   nodes=[int(v) for v in T], root=int(root), nstates=n,
+                   root_distn=distn.tolist(),
+                   P=dict((str(int(k)), v.tolist()) for k, v in Ps.items()),
+                   allowed=set_json(allowed))
+        pset, nset, pmap = ref_type_y(mods, T_aug, root, allowed)
+        rec['pset'] = set_json(pset)
+        rec['set'] = set_json(nset)
+        rec['pmap'] = pmap_json(pmap, n)
+        try:
+            rec['likelihood'] = _mc0.get_likelihood(pmap[root],
+                                                    root_distn=distn_dict)
+            rec['zero'] = False
+        except _util.StructuralZeroProb:
+            rec['likelihood'] = 0.0
+            rec['zero'] = True
+        # type-z: random likelihood for every (node, state)
+        obs = dict((v, dict((s, float(rng.uniform(0.1, 1.0)))
+                            for s in range(n))) for v in T)
+        pmap_z = _mcz.get_node_to_pmap(T_aug, root,
+                                       node_to_state_to_likelihood=obs,
+                                       node_to_set=nset)
+        rec['obs_lik'] = dict((str(int(v)), [m[s] for s in range(n)])
+                              for v, m in obs.items())
+        rec['pmap_z'] = pmap_json(pmap_z, n)
+        cases.append(rec)
+    return dict(cases=cases)
+
+
+def fixture_config(mods, name, nsites, with_pmap=False):
+    """A BASELINE.json-shaped configuration evaluated by the reference path:
+    E x scipy.linalg.expm + _mcx.get_likelihood (type-x observations, C1-C3)
+    or the unaccelerated type-y path (C5)."""
+    from raoteh_amd import synth
+    _mcx, _mc0 = mods['_mcx'], mods['_mc0']
+    cfg = synth.make_config(name, nsites=nsites)
+    T, root, leaves, n = cfg['T'], cfg['root'], cfg['leaves'], cfg['nstates']
+    t0 = time.time()
+    T_aug, dense = augmented(T, root, cfg['Q_default'])
+    distn = cfg['root_distn']
+    distn_dict = dict((i, float(p)) for i, p in enumerate(distn) if p)
+    liks = []
+    pmaps = []
+    for site in range(nsites):
+        if cfg['obs_kind'] == 'state':
+            nts = dict((leaf, int(cfg['leaf_states'][site, k]))
+                       for k, leaf in enumerate(leaves))
+            pm = _mcx.get_node_to_pmap(T_aug, root, node_to_state=nts)
+        else:
+            allowed = synth.site_node_to_allowed_states(cfg, site)
+            _, _, pm = ref_type_y(mods, T_aug, root, allowed)
+        liks.append(_mc0.get_likelihood(pm[root], root_distn=distn_dict))
+        if with_pmap:
+            pmaps.append(pmap_json(pm, n))
+    seconds = time.time() - t0
+    rec = dict(config=name, nsites=nsites, nstates=n, root=int(root),
+               leaves=[int(v) for v in leaves],
+               edges=edges_in_insertion_order(T),
+               root_distn=np.asarray(distn).tolist(),
+               obs_kind=cfg['obs_kind'],
+               leaf_states=cfg['leaf_states'][:nsites].tolist(),
+               likelihoods=liks,
+               log_likelihoods=[float(np.log(x)) for x in liks],
+               reference_seconds=seconds)
+    if cfg['Q_default'] is not None:
+        rec['Q_default'] = np.asarray(cfg['Q_default']).tolist()
+    else:
+        rec['Q_edges'] = dict(
+            (str(int(nb)), np.asarray(T[na][nb]['Q']).tolist())
+            for na, nb in nx.bfs_edges(T, root))
+        rec['leaf_allowed'] = [list(map(int, a)) for a in cfg['leaf_allowed']]
+    # a few scipy expm outputs so expm parity is testable by itself
+    keep = list(dense)[:3] if n > 20 else list(dense)
+    rec['P_scipy'] = dict((str(int(k)), dense[k].tolist()) for k in keep)
+    if with_pmap:
+        rec['pmaps'] = pmaps
+    return rec
+
+
+def fixture_expm(mods):
+    """scipy.linalg.expm(Q*t) on the matrix families the reference tests
+    (tests/test_expm.py:44-82: 3-state tolerance forms a/b/c at
+    t = 2^-5..2^5) plus HKY/MG94/blinking matrices at small and large t."""
+    from raoteh_amd import synth
+    rng = np.random.RandomState(1234)
+    rows = []
+    for t in np.logspace(-5, 5, 10, base=2):
+        for form in 'abc':
+            if form == 'a':
+                a, w, r = rng.exponential(size=3)
+                R = [(0, 1, a), (1, 0, w), (1, 2, r)]
+            elif form == 'b':
+                a, r = rng.exponential(size=2)
+                R = [(0, 1, a), (1, 2, r)]
+            else:
+                a = rng.exponential()
+                R = [(0, 1, a), (1, 2, a)]
+            Q = np.zeros((3, 3))
+            for i, j, x in R:
+                Q[i, j] = x
+            Q -= np.diag(Q.sum(axis=1))
+            rows.append(dict(form=form, t=float(t), Q=Q.tolist(),
+                             P=scipy.linalg.expm(Q * t).tolist()))
+    Qh, _ = synth.hky85()
+    Qm, _ = synth.mg94()
+    c5 = synth.make_config('c5', nsites=1)
+    Qb = c5['T'][0][1]['Q']
+    for label, Q in (('hky85', Qh), ('blinking20', Qb), ('mg94', Qm)):
+        for t in (1e-4, 0.05, 0.3, 1.0, 4.0, 40.0):
+            if label == 'mg94' and t not in (0.05, 1.0, 40.0):
+                continue
+            rows.append(dict(form=label, t=t, Q=np.asarray(Q).tolist(),
+                             P=scipy.linalg.expm(np.asarray(Q) * t).tolist()))
+    return dict(rows=rows)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--out', default=os.path.join(os.path.dirname(HERE),
+                                                  'tests', 'golden'))
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    mods = import_reference()
+    meta = dict(generator='tools/gen_golden.py',
+                reference='/root/reference (argriffing/raoteh)',
+                python=sys.version.split()[0], numpy=np.__version__,
+                scipy=scipy.__version__, networkx=nx.__version__)
+    fixtures = dict(
+        test_mjp_rerooting=fixture_test_mjp(mods),
+        sum_to_one=fixture_sum_to_one(mods),
+        kat_history=fixture_kat_history(mods),
+        jukes_cantor=fixture_jukes_cantor(mods),
+        random_sparse=fixture_random_sparse(mods),
+        expm=fixture_expm(mods),
+        config_c1=fixture_config(mods, 'c1', 4, with_pmap=True),
+        config_c2=fixture_config(mods, 'c2', 6),
+        config_c3=fixture_config(mods, 'c3', 2),
+        config_c5=fixture_config(mods, 'c5', 4),
+    )
+    for name, fx in fixtures.items():
+        fx['_meta'] = meta
+        path = os.path.join(args.out, name + '.json')
+        with open(path, 'w') as f:
+            json.dump(fx, f)
+        print('%-22s %8.1f KB' % (name, os.path.getsize(path) / 1024.0))
+
+
+if __name__ == '__main__':
+    main()
