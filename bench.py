@@ -1,0 +1,344 @@
+#!/usr/bin/env python
+"""
+bench.py -- site log-likelihoods / second of the batched tree-pruning hot path.
+
+One *step* = one pass of the hot path over one resident batch of synthetic
+sites: per-edge expm(Q*t) for every edge of the tree (from rates resident on
+the device) -> fragment repack -> Felsenstein upward pass + root reduce + log
+-> batch sum (-> RCCL all-reduce of the three totals when N > 1).  Inputs are in
+HBM before the timed region starts.  Batches rotate through several HBM copies
+so the 256 MiB Infinity Cache cannot hold the working set.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5]
+
+N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N ...`
+(one rank per GPU; RANK / LOCAL_RANK / WORLD_SIZE from the environment).  The
+worker processes do not import torch: the control plane (barrier, max over
+ranks) is a few bytes over a local TCP socket, the data-path reduce is
+ncclAllReduce (RCCL) inside libraoteh_hip.so.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import socket
+import struct
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F64_MFMA_PEAK_TFLOPS = 78.6    # MI355X datasheet dense FP64 matrix
+
+WORKLOADS = {
+    'c2': dict(desc='4-state HKY85, 64-leaf balanced tree, 100000 sites/GPU, '
+                    'dense f64 leaf likelihood vectors', bound='hbm'),
+    'c3': dict(desc='61-state MG94 codon, 64-leaf balanced tree, 10000 sites/GPU, '
+                    'dense f64 leaf likelihood vectors', bound='mfma'),
+    'c5': dict(desc='20-state blinking compound process, 32-leaf tree, per-edge Q, '
+                    '50000 sites/GPU, dense f64 0/1 leaf masks', bound='hbm'),
+}
+
+
+# ---------------------------------------------------------------------------
+# tiny single-node control plane (no torch in the workers)
+# ---------------------------------------------------------------------------
+
+class Control(object):
+    """all-gather of small byte strings among the ranks of one node."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+        self.peers = []
+        self.sock = None
+        if world == 1:
+            return
+        token = '%s_%s' % (os.environ.get('MASTER_PORT', '0'), os.getppid())
+        path = '/tmp/raoteh_bench_rdzv_%s' % token
+        if rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind(('127.0.0.1', 0))
+            srv.listen(world)
+            with open(path + '.tmp', 'w') as f:
+                f.write(str(srv.getsockname()[1]))
+            os.rename(path + '.tmp', path)
+            conns = {}
+            while len(conns) < world - 1:
+                c, _ = srv.accept()
+                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                r = struct.unpack('i', self._recv(c, 4))[0]
+                conns[r] = c
+            self.peers = [conns[r] for r in range(1, world)]
+            srv.close()
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+        else:
+            deadline = time.time() + 300
+            while not os.path.exists(path):
+                if time.time() > deadline:
+                    raise RuntimeError('rendezvous file never appeared')
+                time.sleep(0.05)
+            port = int(open(path).read())
+            self.sock = socket.create_connection(('127.0.0.1', port))
+            self.sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            self.sock.sendall(struct.pack('i', rank))
+
+    @staticmethod
+    def _recv(c, n):
+        buf = b''
+        while len(buf) < n:
+            chunk = c.recv(n - len(buf))
+            if not chunk:
+                raise RuntimeError('peer closed the control connection')
+            buf += chunk
+        return buf
+
+    def allgather(self, payload):
+        """payload: bytes of equal length on every rank -> list per rank."""
+        if self.world == 1:
+            return [payload]
+        n = len(payload)
+        if self.rank == 0:
+            parts = [payload] + [self._recv(c, n) for c in self.peers]
+            blob = b''.join(parts)
+            for c in self.peers:
+                c.sendall(blob)
+        else:
+            self.sock.sendall(payload)
+            blob = self._recv(self.sock, n * self.world)
+        return [blob[i * n:(i + 1) * n] for i in range(self.world)]
+
+    def barrier(self):
+        self.allgather(b'\0')
+
+    def allreduce(self, values, op):
+        vals = np.asarray(values, dtype=np.float64)
+        parts = self.allgather(vals.tobytes())
+        arr = np.stack([np.frombuffer(p, dtype=np.float64) for p in parts])
+        return op(arr, axis=0)
+
+
+# ---------------------------------------------------------------------------
+# CPU baseline (the oracle; rank 0, N == 1 only)
+# ---------------------------------------------------------------------------
+
+def cpu_baseline(cfg, gpu_ll, budget_s):
+    """Reference-faithful port: for every site, E x scipy.linalg.expm + nx
+    marshalling + the three passes + root reduce, one thread -- exactly what
+    raoteh's _mjp_dense.get_likelihood does per call (_mjp_dense.py:362-407)."""
+    from oracle import oracle_numpy as orc
+    from raoteh_amd import synth
+    T, root, n = cfg['T'], cfg['root'], cfg['nstates']
+    t0 = time.perf_counter()
+    done = 0
+    worst = 0.0
+    while done < cfg['leaf_states'].shape[0]:
+        allowed = synth.site_node_to_allowed_states(cfg, done)
+        ll = orc.reference_faithful_site_loglik(
+            T, root, n, allowed, root_distn=cfg['root_distn'],
+            Q_default=cfg['Q_default'])
+        worst = max(worst, abs(ll - gpu_ll[done]) / abs(ll))
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    out = dict(value=done / dt, unit='sites/s', cores=1, kind='port',
+               sample='%d sites of the same workload, reference-faithful '
+                      '(per-site expm of every edge, numpy/scipy/networkx, '
+                      '1 thread), %.1f s' % (done, dt),
+               max_rel_err_gpu_vs_oracle=worst)
+    # amortised variant: expm once per edge, numpy-vectorised over sites
+    t0 = time.perf_counter()
+    pre, idx, ptr, esd = orc.get_expm_augmented_transitions(
+        T, root, n, Q_default=cfg['Q_default'])
+    m = min(cfg['leaf_states'].shape[0], 20000 if n <= 20 else 2000)
+    dense = synth.leaf_likelihoods(dict(cfg, leaf_states=cfg['leaf_states'][:m]))
+    ll, _ = orc.batch_log_likelihoods(idx, ptr, esd,
+                                      [pre.index(v) for v in cfg['leaves']],
+                                      dense, cfg['root_distn'])
+    dt = time.perf_counter() - t0
+    out['amortised_numpy_sites_per_s'] = m / dt
+    out['amortised_max_rel_err'] = float(np.max(
+        np.abs(ll - gpu_ll[:m]) / np.abs(ll)))
+    return out
+
+
+# ---------------------------------------------------------------------------
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
+    ap.add_argument('--sites', type=int, default=None,
+                    help='sites per GPU (default: the configuration size)')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-rotate', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('launch N > 1 with: python -m torch.distributed.run '
+                     '--nproc-per-node %d bench.py --gpus %d' % (args.gpus, args.gpus))
+        args.gpus = world
+
+    from raoteh_amd import synth, device, _lib     # fails loudly without the .so
+    ctl = Control(rank, world)
+    ctx = device.Context(local_rank)
+
+    wl = WORKLOADS[args.workload]
+    cfg = synth.make_config(args.workload, nsites=args.sites)
+    nsites = cfg['leaf_states'].shape[0]
+    T, root, n = cfg['T'], cfg['root'], cfg['nstates']
+    nleaves = len(cfg['leaves'])
+    nedges = T.number_of_edges()
+    if world > 1:
+        # every rank owns a different block of sites (weak scaling: the
+        # configuration's site count per GPU), same tree and rates
+        rng = np.random.RandomState(1000 + rank)
+        cfg['leaf_states'] = cfg['leaf_states'][rng.permutation(nsites)]
+
+    model = device.TreeModel(T, root, n, ctx=ctx)
+    model.set_rates(Q_default=cfg['Q_default'])
+    model.set_root_distn(cfg['root_distn'])
+    dense = synth.leaf_likelihoods(cfg)
+    batch0 = model.upload_sites(cfg['leaves'], dense, kind='dense')
+    del dense
+    batches = [batch0]
+    if not args.no_rotate:
+        while sum(b.device_bytes for b in batches) < 640 * 2 ** 20 and len(batches) < 8:
+            batches.append(batch0.clone())
+
+    # RCCL communicator for the data-path reduce
+    reduce_kind = 'none'
+    if world > 1:
+        reduce_kind = 'rccl'
+        ok = 1.0
+        try:
+            uid = device.Context.comm_unique_id() if rank == 0 else bytes(128)
+            uid = ctl.allgather(uid)[0]
+            ctx.comm_init(world, rank, uid)
+        except Exception as e:          # keep the job alive, say what happened
+            sys.stderr.write('rank %d: RCCL unavailable (%s)\n' % (rank, e))
+            ok = 0.0
+        if ctl.allreduce([ok], np.min)[0] < 1.0:
+            reduce_kind = 'host-socket-fallback'
+
+    def step(j):
+        b = batches[j % len(batches)]
+        model.recompute_transitions()
+        model.prune(b)
+        if reduce_kind == 'rccl':
+            model.allreduce(b)
+        return b
+
+    for j in range(args.warmup):
+        step(j)
+    ctx.sync()
+    ll0, st0 = model.fetch_log_likelihoods(batch0)
+    ctx.set_timing(True)
+    ctx.reset_timing()
+
+    ctl.barrier()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for j in range(args.steps):
+        last = step(j)
+    ctx.sync()
+    ctl.barrier()
+    t1 = time.perf_counter()
+    elapsed = float(ctl.allreduce([t1 - t0], np.max)[0])
+
+    totals = model.fetch_totals(last)
+    if reduce_kind == 'host-socket-fallback':
+        totals = ctl.allreduce(totals, np.sum)
+    if reduce_kind == 'none':
+        assert totals[2] == nsites
+    else:
+        assert totals[2] == nsites * world, totals
+    assert np.isfinite(totals[0]) and totals[1] == 0, totals
+
+    prune_ms, prune_cnt, prune_name = ctx.kernel_time(_lib.RT_K_PRUNE)
+    expm_ms, expm_cnt, expm_name = ctx.kernel_time(_lib.RT_K_EXPM)
+    red_ms, red_cnt, _ = ctx.kernel_time(_lib.RT_K_REDUCE)
+    ctx.set_timing(False)
+
+    if rank != 0:
+        return
+
+    alg_bytes = nsites * (8.0 * n * nleaves + 8.0)
+    alg_flops = nsites * (2.0 * n * n * nedges + n * nedges + 2.0 * n)
+    avg_prune_s = prune_ms / max(prune_cnt, 1) * 1e-3
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'traffic_%s.json' % args.workload)
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
+        except Exception:
+            traffic = None
+    if wl['bound'] == 'hbm':
+        achieved = alg_bytes / avg_prune_s / 1e9
+        roof = dict(bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
+                    frac=achieved / HBM_PEAK_GBS, traffic=traffic)
+    else:
+        achieved = alg_flops / avg_prune_s / 1e12
+        roof = dict(bound='mfma', achieved=achieved, peak=F64_MFMA_PEAK_TFLOPS,
+                    unit='TFLOP/s', frac=achieved / F64_MFMA_PEAK_TFLOPS,
+                    traffic=traffic)
+    roof.update(kernel=prune_name, avg_kernel_us=avg_prune_s * 1e6,
+                launches=prune_cnt, algorithmic_bytes_per_launch=alg_bytes,
+                algorithmic_flops_per_launch=alg_flops,
+                hbm_gbs=alg_bytes / avg_prune_s / 1e9)
+
+    out = {
+        'metric': 'site log-likelihoods/sec (batched tree pruning)',
+        'value': nsites * world * args.steps / elapsed,
+        'unit': 'sites/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': elapsed / args.steps * 1e3,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f64',
+        'data': 'synthetic',
+        'config': {'workload': '%s: %s' % (args.workload, wl['desc']),
+                   'sites_per_gpu': nsites, 'states': n, 'leaves': nleaves,
+                   'edges': nedges, 'batches_rotated': len(batches),
+                   'reduce': reduce_kind},
+        'roofline': roof,
+        'kernels_us': {'expm': expm_ms / max(expm_cnt, 1) * 1e3,
+                       'prune': avg_prune_s * 1e6,
+                       'reduce': red_ms / max(red_cnt, 1) * 1e3,
+                       'expm_kernel': expm_name},
+        'total_log_likelihood': float(totals[0]),
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(cfg, ll0, args.cpu_seconds)
+        out['cpu_baseline']['host_cpu_count'] = os.cpu_count()
+        out['speedup_vs_reference_faithful_cpu'] = (out['value'] /
+                                                    out['cpu_baseline']['value'])
+    else:
+        out['cpu_baseline'] = None
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

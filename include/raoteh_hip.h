@@ -1,0 +1,216 @@
+/*
+ * raoteh_hip.h -- C ABI of libraoteh_hip.so (gfx950 / MI355X).
+ *
+ * The drop-in boundary for the tree-CTMC likelihood hot path of
+ * argriffing/raoteh.  Plain pointers and sizes only; the caller owns every
+ * host buffer; the library never keeps a host pointer after a call returns;
+ * device memory is owned by the opaque handles.  No exception crosses the
+ * ABI: every function returns 0 (RT_OK) or a negative RT_ERR_* code and
+ * rt_last_error() returns a human-readable message for the calling thread.
+ *
+ * "Reference" citations are file:line under the reference repository root
+ * (argriffing/raoteh).  The reference's only native boundary on this path is
+ * the third-party Cython module `pyfelscore` (absent from the reference
+ * tree, version unpinned, README.md:8-9); section 1 below replaces exactly
+ * the pyfelscore entry points the path calls plus the scipy expm call.
+ * Section 2 is the batched, device-resident form of the same path.
+ *
+ * All floating point data is IEEE binary64; all index data int64 (as the
+ * reference passes, _density.py:138-139, _mcy_dense.py:49); row-major,
+ * C-contiguous.
+ */
+#ifndef RAOTEH_HIP_H
+#define RAOTEH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK                0
+#define RT_ERR_INVALID      -1   /* bad argument (shape, null, range)        */
+#define RT_ERR_HIP          -2   /* a HIP runtime call failed                */
+#define RT_ERR_UNSUPPORTED  -3   /* valid input outside implemented limits   */
+#define RT_ERR_NOMEM        -4   /* host or device allocation failed         */
+#define RT_ERR_RCCL         -5   /* RCCL missing or a collective failed      */
+#define RT_ERR_SINGULAR     -6   /* expm: Pade denominator singular          */
+
+#define RT_MAX_STATES       64   /* n <= 64 for the pruning kernels          */
+#define RT_MAX_EXPM_STATES  62   /* n <= 62 for the LDS-resident expm        */
+
+/* per-site status written by rt_prune (reference: StructuralZeroProb raised
+ * by _mc0_dense.py:190-203 when the root likelihood is zero)                */
+#define RT_SITE_OK           0
+#define RT_SITE_ZERO_PROB    1
+#define RT_SITE_NEGATIVE     4   /* bit: a negative root pmap entry was
+                                    clamped (reference warns + clamps,
+                                    _mc0_dense.py:184-189)                   */
+
+/* observation encodings for rt_sites_create                                 */
+#define RT_OBS_DENSE         0   /* f64 [nsites][nobs][n] likelihood vectors
+                                    (type z, _mcz.py:159-160; 0/1 masks and
+                                    one-hot vectors are special cases)       */
+#define RT_OBS_STATE         1   /* uint8 [nsites][nobs] observed state,
+                                    255 = unobserved (type x, _mcx.py:12-23) */
+#define RT_OBS_MASK          2   /* uint64 [nsites][nobs] bit s = state s
+                                    allowed (type y, _mcy.py:12-16)          */
+
+/* kernel ids for rt_ctx_kernel_time                                         */
+#define RT_K_EXPM            0
+#define RT_K_PRUNE           1
+#define RT_K_REDUCE          2
+#define RT_K_COUNT           3
+
+typedef struct rt_ctx   rt_ctx;     /* one per GPU / process                 */
+typedef struct rt_model rt_model;   /* tree + transition matrices on device  */
+typedef struct rt_sites rt_sites;   /* one resident batch of site data       */
+
+/* ---- 0. library / context ------------------------------------------------ */
+
+int         rt_version(void);                 /* 100*major + minor            */
+const char *rt_last_error(void);              /* thread-local, never NULL     */
+int         rt_device_count(int *count);
+int         rt_ctx_create(int device, rt_ctx **ctx);
+int         rt_ctx_destroy(rt_ctx *ctx);
+int         rt_ctx_sync(rt_ctx *ctx);         /* wait for the ctx stream      */
+/* Optional per-kernel HIP-event timing (events are recorded on the stream
+ * the kernels are launched on).  rt_ctx_kernel_time drains finished events
+ * and returns the accumulated device time and launch count since the last
+ * reset; `name` receives a static string with the kernel variant used.      */
+int         rt_ctx_set_timing(rt_ctx *ctx, int enabled);
+int         rt_ctx_reset_timing(rt_ctx *ctx);
+int         rt_ctx_kernel_time(rt_ctx *ctx, int kernel, double *total_ms,
+                               int64_t *launches, const char **name);
+
+/* ---- 1. reference-shaped entry points (host pointers in and out) --------- */
+
+/* P[b] = expm(Q[q_index[b]] * t[b]) for b in [0,count).  Replaces
+ * scipy.linalg.expm(Q * weight) at _mjp_dense.py:24-25 (called once per edge
+ * at _mjp_dense.py:352-358) and pyfelscore.get_tolerance_rate_matrix(t,Q,P)
+ * (_tmjp_dense.py:239, tests/test_expm.py:38).  q_index may be NULL
+ * (then matrix b uses Q[b] if nq == count, or Q[0] if nq == 1).
+ * info (optional, int32[count][2]) receives the Pade degree and the number
+ * of squarings used.  n <= RT_MAX_EXPM_STATES.                              */
+int rt_expm(rt_ctx *ctx, int64_t n, int64_t count,
+            const double *Q, int64_t nq, const int64_t *q_index,
+            const double *t, double *P, int32_t *info);
+
+/* The three pyfelscore passes of _mcy_dense.py:261-291, batched over
+ * `nsites` independent sites that share the tree and the transitions:
+ *   tree_csr_indices int64[nnodes-1], tree_csr_indptr int64[nnodes+1]:
+ *       children CSR in DFS-preorder index space (_density.py:104-140)
+ *   esd_transitions  f64[nnodes][n][n], slot = CHILD preorder index, root
+ *       slot ignored (_density.py:143-180)
+ *   state_mask       int64[nsites][nnodes][n], 0/1
+ *   subtree_probability f64[nsites][nnodes][n], every entry written.
+ * nsites == 1 is the exact single-call shape of the reference.              */
+
+/* pyfelscore.mcy_esd_get_node_to_pset (call sites _mcy_dense.py:168,270,
+ * _mcx_dense.py:145, _mcy.py:219,309,508): backward boolean pass, in place. */
+int rt_mcy_esd_get_node_to_pset(rt_ctx *ctx, int64_t nnodes, int64_t n,
+            int64_t nsites, const int64_t *tree_csr_indices,
+            const int64_t *tree_csr_indptr, const double *esd_transitions,
+            int64_t *state_mask);
+
+/* pyfelscore.esd_get_node_to_set (_mcy_dense.py:175,277, _mcx_dense.py:152,
+ * _mcy.py:226,515): forward boolean pass, in place.                         */
+int rt_esd_get_node_to_set(rt_ctx *ctx, int64_t nnodes, int64_t n,
+            int64_t nsites, const int64_t *tree_csr_indices,
+            const int64_t *tree_csr_indptr, const double *esd_transitions,
+            int64_t *state_mask);
+
+/* pyfelscore.mcy_esd_get_node_to_pmap (_mcy_dense.py:184,286,
+ * _mcx_dense.py:161, _mcy.py:533): Felsenstein upward pass
+ *   L[v,s] = mask[v,s] * obs_lik[v,s] * prod_c sum_s' P_c[s,s'] L[c,s'].
+ * obs_likelihood (optional, f64[nsites][nnodes][n]) is the type-z factor of
+ * _mcz.py:159-160; pass NULL for the plain type-x/y pass.                   */
+int rt_mcy_esd_get_node_to_pmap(rt_ctx *ctx, int64_t nnodes, int64_t n,
+            int64_t nsites, const int64_t *tree_csr_indices,
+            const int64_t *tree_csr_indptr, const double *esd_transitions,
+            const int64_t *state_mask, const double *obs_likelihood,
+            double *subtree_probability);
+
+/* ---- 2. batched, device-resident hot path --------------------------------
+ * _mjp_dense.get_likelihood (_mjp_dense.py:362-407) for many sites:
+ *   rt_model_create        tree (same CSR as above) -> device, schedule built
+ *   rt_model_set_rates     per-edge expm(Q*t) on the device, P stays resident
+ *                          (get_expm_augmented_tree, _mjp_dense.py:328-359)
+ *   rt_sites_create        per-site observations -> kernel-native HBM layout
+ *   rt_prune               upward pass + root reduce + log + batch sum
+ *                          (_mcy_dense.py:286 + _mc0_dense.py:147-212)
+ * rt_model_set_rates, rt_prune and rt_allreduce_totals are asynchronous on the
+ * context's stream; the rt_*_get_* functions synchronise.                    */
+
+int rt_model_create(rt_ctx *ctx, int64_t nnodes, int64_t n,
+            const int64_t *tree_csr_indices, const int64_t *tree_csr_indptr,
+            rt_model **model);
+int rt_model_destroy(rt_model *model);
+
+/* Q f64[nq][n][n]; node_q int64[nnodes] = which Q the edge above node v uses
+ * (entry 0, the root, is ignored; NULL = all edges use Q[0]); t f64[nnodes]
+ * branch length of the edge above node v (t[0] ignored).                    */
+int rt_model_set_rates(rt_model *model, const double *Q, int64_t nq,
+            const int64_t *node_q, const double *t);
+/* Re-run the per-edge expm from the Q / node_q / t already resident on the
+ * device (what an optimiser or MCMC loop does after changing rates in place;
+ * also one benchmark step).                                                 */
+int rt_model_recompute_transitions(rt_model *model);
+/* Set / read back esd_transitions f64[nnodes][n][n] directly.               */
+int rt_model_set_transitions(rt_model *model, const double *esd_transitions);
+int rt_model_get_transitions(rt_model *model, double *esd_transitions);
+/* Pade degree / squarings per node from the last rt_model_set_rates.        */
+int rt_model_get_expm_info(rt_model *model, int32_t *info /*[nnodes][2]*/);
+/* root_distn f64[n] or NULL (= weights of one, NOT uniform:
+ * _mjp_dense.py:389-393).                                                   */
+int rt_model_set_root_distn(rt_model *model, const double *root_distn);
+
+/* Number of accumulator slots the post-order schedule needs (the fast
+ * kernels hold 8 in registers; deeper trees use the generic kernel).        */
+int rt_model_schedule_depth(const rt_model *model);
+/* Copy the schedule out: int32[nops][4] = {node, obs, pop, dst} (see
+ * csrc/common.h rt_op).  ops may be NULL to query nops only.                */
+int rt_model_get_schedule(const rt_model *model, int32_t *ops, int64_t capacity,
+            int64_t *nops);
+/* The same schedule computed on the host only (no device needed; tests).    */
+int rt_build_schedule(int64_t nnodes, const int64_t *tree_csr_indices,
+            const int64_t *tree_csr_indptr, int32_t *ops /*[nnodes][4]*/,
+            int32_t *depth);
+/* Process-wide options: "force_generic" (0/1) routes every later
+ * rt_sites_create to the generic fallback kernel.                           */
+int rt_set_option(const char *key, int64_t value);
+
+/* obs_nodes int64[nobs]: preorder indices of the nodes that carry per-site
+ * data (all other nodes are unrestricted).  data layout per `kind` above.   */
+int rt_sites_create(rt_model *model, int64_t nsites, int kind, int64_t nobs,
+            const int64_t *obs_nodes, const void *data, rt_sites **sites);
+/* A second batch with the same values at different HBM addresses (used by
+ * the benchmark to rotate batches so the 256 MiB Infinity Cache cannot hold
+ * the working set).                                                         */
+int rt_sites_clone(rt_sites *sites, rt_sites **clone);
+int rt_sites_destroy(rt_sites *sites);
+int64_t rt_sites_device_bytes(const rt_sites *sites);
+
+int rt_prune(rt_model *model, rt_sites *sites);
+/* loglik f64[nsites] (-inf where status has RT_SITE_ZERO_PROB),
+ * status int32[nsites]; either may be NULL.                                 */
+int rt_sites_get_logliks(rt_sites *sites, double *loglik, int32_t *status);
+/* totals[0] = sum of log-likelihoods over sites with non-zero likelihood,
+ * totals[1] = number of zero-probability sites, totals[2] = number of sites */
+int rt_sites_get_totals(rt_sites *sites, double totals[3]);
+
+/* ---- 3. multi-GPU: one process per GPU, RCCL over xGMI ------------------- */
+
+/* rank 0 calls rt_comm_unique_id and ships the 128 bytes to the other ranks
+ * by any host channel; then every rank calls rt_comm_init.                  */
+int rt_comm_unique_id(unsigned char id[128]);
+int rt_comm_init(rt_ctx *ctx, int nranks, int rank, const unsigned char id[128]);
+int rt_comm_destroy(rt_ctx *ctx);
+/* ncclAllReduce(sum, f64, 3) of the totals of `sites`, in place on the
+ * device, on the context stream.                                            */
+int rt_allreduce_totals(rt_ctx *ctx, rt_sites *sites);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAOTEH_HIP_H */

@@ -1,0 +1,696 @@
+// C ABI of libraoteh_hip.so: contexts, models (tree + transition matrices),
+// site batches, and the host-pointer reference-shaped entry points.
+// See include/raoteh_hip.h for the contract of every function.
+#include "common.h"
+
+#include <algorithm>
+#include <cmath>
+
+// ---- errors ----------------------------------------------------------------------
+
+static thread_local char g_err[512] = "";
+
+void rt_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *rt_last_error(void) { return g_err; }
+extern "C" int rt_version(void) { return 100; }
+
+extern "C" int rt_device_count(int *count)
+{
+    RT_REQUIRE(count, "null count");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *count = 0;
+        rt_set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+        return RT_ERR_HIP;
+    }
+    *count = c;
+    return RT_OK;
+}
+
+// ---- context ------------------------------------------------------------------------
+
+extern "C" int rt_ctx_create(int device, rt_ctx **out)
+{
+    RT_REQUIRE(out, "null out pointer");
+    *out = nullptr;
+    int count = 0;
+    RT_HIP(hipGetDeviceCount(&count));
+    RT_REQUIRE(device >= 0 && device < count, "device %d not in [0,%d)", device, count);
+    RT_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    RT_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        rt_set_error("device %d is %s; this library is built for gfx950 (MI355X) only",
+                     device, prop.gcnArchName);
+        return RT_ERR_UNSUPPORTED;
+    }
+    rt_ctx *ctx = new (std::nothrow) rt_ctx();
+    if (!ctx) return RT_ERR_NOMEM;
+    ctx->device = device;
+    ctx->num_cus = prop.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        rt_set_error("hipStreamCreate: %s", hipGetErrorString(e));
+        return RT_ERR_HIP;
+    }
+    *out = ctx;
+    return RT_OK;
+}
+
+extern "C" int rt_ctx_sync(rt_ctx *ctx)
+{
+    RT_REQUIRE(ctx, "null context");
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+static void drain_slot(rt_timing_slot &s, bool wait)
+{
+    size_t keep = 0;
+    for (size_t i = 0; i < s.pending.size(); ++i) {
+        auto &pr = s.pending[i];
+        hipError_t q = wait ? hipEventSynchronize(pr.second) : hipEventQuery(pr.second);
+        if (q == hipSuccess) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                s.total_ms += ms;
+                s.launches += 1;
+            }
+            s.pool.push_back(pr.first);
+            s.pool.push_back(pr.second);
+        } else {
+            s.pending[keep++] = pr;
+        }
+    }
+    s.pending.resize(keep);
+}
+
+extern "C" int rt_ctx_destroy(rt_ctx *ctx)
+{
+    if (!ctx) return RT_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    rt_comm_destroy(ctx);
+    for (auto &s : ctx->slots) {
+        drain_slot(s, true);
+        for (auto ev : s.pool) hipEventDestroy(ev);
+    }
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RT_OK;
+}
+
+extern "C" int rt_ctx_set_timing(rt_ctx *ctx, int enabled)
+{
+    RT_REQUIRE(ctx, "null context");
+    ctx->timing = enabled != 0;
+    return RT_OK;
+}
+
+extern "C" int rt_ctx_reset_timing(rt_ctx *ctx)
+{
+    RT_REQUIRE(ctx, "null context");
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto &s : ctx->slots) {
+        drain_slot(s, true);
+        s.total_ms = 0.0;
+        s.launches = 0;
+    }
+    return RT_OK;
+}
+
+extern "C" int rt_ctx_kernel_time(rt_ctx *ctx, int kernel, double *total_ms,
+                                  int64_t *launches, const char **name)
+{
+    RT_REQUIRE(ctx, "null context");
+    RT_REQUIRE(kernel >= 0 && kernel < RT_K_COUNT, "bad kernel id %d", kernel);
+    rt_timing_slot &s = ctx->slots[kernel];
+    drain_slot(s, true);
+    if (total_ms) *total_ms = s.total_ms;
+    if (launches) *launches = s.launches;
+    if (name) *name = s.name;
+    return RT_OK;
+}
+
+void rt_time_begin(rt_ctx *ctx, int kernel, const char *name, hipEvent_t *start)
+{
+    *start = nullptr;
+    rt_timing_slot &s = ctx->slots[kernel];
+    if (name && name[0]) s.name = name;
+    if (!ctx->timing) return;
+    hipEvent_t ev = nullptr;
+    if (!s.pool.empty()) { ev = s.pool.back(); s.pool.pop_back(); }
+    else if (hipEventCreate(&ev) != hipSuccess) return;
+    hipEventRecord(ev, ctx->stream);
+    *start = ev;
+}
+
+void rt_time_end(rt_ctx *ctx, int kernel, hipEvent_t start)
+{
+    if (!start) return;
+    rt_timing_slot &s = ctx->slots[kernel];
+    hipEvent_t ev = nullptr;
+    if (!s.pool.empty()) { ev = s.pool.back(); s.pool.pop_back(); }
+    else if (hipEventCreate(&ev) != hipSuccess) { s.pool.push_back(start); return; }
+    hipEventRecord(ev, ctx->stream);
+    s.pending.emplace_back(start, ev);
+    if (s.pending.size() > 4096) drain_slot(s, false);
+}
+
+// ---- expm, host pointers ----------------------------------------------------------------
+
+extern "C" int rt_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *Q,
+                       int64_t nq, const int64_t *q_index, const double *t, double *P,
+                       int32_t *info)
+{
+    RT_REQUIRE(ctx, "null context");
+    RT_REQUIRE(n >= 1 && count >= 0 && nq >= 1, "bad sizes");
+    RT_REQUIRE(Q && t && P, "null array");
+    if (n > RT_MAX_EXPM_STATES) {
+        rt_set_error("expm: n=%lld > %d", (long long)n, RT_MAX_EXPM_STATES);
+        return RT_ERR_UNSUPPORTED;
+    }
+    RT_REQUIRE(q_index || nq == 1 || nq == count,
+               "q_index is NULL but nq=%lld is neither 1 nor count", (long long)nq);
+    if (count == 0) return RT_OK;
+    std::vector<int32_t> qi((size_t)count);
+    for (int64_t b = 0; b < count; ++b) {
+        const int64_t v = q_index ? q_index[b] : (nq == 1 ? 0 : b);
+        RT_REQUIRE(v >= 0 && v < nq, "q_index[%lld]=%lld out of range", (long long)b,
+                   (long long)v);
+        qi[(size_t)b] = (int32_t)v;
+    }
+    RT_HIP(hipSetDevice(ctx->device));
+    double *dQ = nullptr, *dt = nullptr, *dP = nullptr;
+    int32_t *dqi = nullptr, *dinfo = nullptr;
+    const size_t nn = (size_t)n * n;
+    int rc = RT_OK;
+    hipError_t e = hipMalloc((void **)&dQ, nq * nn * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&dt, count * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&dP, count * nn * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&dqi, count * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&dinfo, count * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(dQ, Q, nq * nn * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dt, t, count * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dqi, qi.data(), count * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) rc = rt_launch_expm(ctx, n, count, dQ, dqi, dt, dP, dinfo);
+    if (e == hipSuccess && rc == RT_OK)
+        e = hipMemcpyAsync(P, dP, count * nn * 8, hipMemcpyDeviceToHost, ctx->stream);
+    std::vector<int32_t> hinfo((size_t)count * 2, 0);
+    if (e == hipSuccess && rc == RT_OK)
+        e = hipMemcpyAsync(hinfo.data(), dinfo, count * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && rc == RT_OK) e = hipStreamSynchronize(ctx->stream);
+    hipFree(dQ); hipFree(dt); hipFree(dP); hipFree(dqi); hipFree(dinfo);
+    if (rc != RT_OK) return rc;
+    if (e != hipSuccess) {
+        rt_set_error("rt_expm: %s", hipGetErrorString(e));
+        return RT_ERR_HIP;
+    }
+    if (info) memcpy(info, hinfo.data(), (size_t)count * 8);
+    for (int64_t b = 0; b < count; ++b)
+        if (hinfo[2 * b] < 0) {
+            rt_set_error("expm: singular Pade denominator for matrix %lld", (long long)b);
+            return RT_ERR_SINGULAR;
+        }
+    return RT_OK;
+}
+
+// ---- model -----------------------------------------------------------------------------------
+
+// Post-order schedule with a Sethi-Ullman child order (the child whose subtree
+// needs the most accumulator slots goes first), so the register stack of the
+// fast kernels stays at <= floor(log2(#leaves)) + 1 slots for any tree shape.
+static void build_schedule(rt_model *m)
+{
+    const int64_t N = m->nnodes;
+    std::vector<std::vector<int32_t>> kids((size_t)N);
+    m->parent.assign((size_t)N, -1);
+    for (int64_t v = 0; v < N; ++v)
+        for (int64_t e = m->indptr[v]; e < m->indptr[v + 1]; ++e) {
+            kids[(size_t)v].push_back((int32_t)m->indices[e]);
+            m->parent[(size_t)m->indices[e]] = (int32_t)v;
+        }
+    std::vector<int> need((size_t)N, 0);
+    for (int64_t v = N - 1; v >= 0; --v) {
+        auto &k = kids[(size_t)v];
+        if (k.empty()) continue;
+        std::stable_sort(k.begin(), k.end(),
+                         [&](int32_t a, int32_t b) { return need[a] > need[b]; });
+        int nd = std::max(1, need[k[0]]);
+        for (size_t i = 1; i < k.size(); ++i) nd = std::max(nd, 1 + need[k[i]]);
+        need[(size_t)v] = nd;
+    }
+    m->ops.clear();
+    m->ops.reserve((size_t)N);
+    std::vector<int32_t> acc_slot((size_t)N, -1);
+    std::vector<std::pair<int32_t, size_t>> stack;   // (node, next child)
+    stack.emplace_back(0, 0);
+    int sp = 0, maxsp = 0;
+    while (!stack.empty()) {
+        const int32_t v = stack.back().first;
+        const size_t ci = stack.back().second;
+        auto &k = kids[(size_t)v];
+        if (ci < k.size()) {
+            stack.back().second = ci + 1;
+            stack.emplace_back(k[ci], 0);
+            continue;
+        }
+        stack.pop_back();
+        rt_op op;
+        op.node = v;
+        op.obs = -1;
+        op.pop = k.empty() ? -1 : acc_slot[(size_t)v];
+        if (!k.empty()) sp -= 1;
+        if (stack.empty()) {
+            op.dst = -1;                       // root
+        } else {
+            const int32_t p = stack.back().first;
+            if (acc_slot[(size_t)p] < 0) {
+                acc_slot[(size_t)p] = sp;
+                op.dst = sp | 256;
+                sp += 1;
+                maxsp = std::max(maxsp, sp);
+            } else {
+                op.dst = acc_slot[(size_t)p];
+            }
+        }
+        m->ops.push_back(op);
+    }
+    m->max_depth = maxsp;
+}
+
+extern "C" int rt_build_schedule(int64_t nnodes, const int64_t *idx, const int64_t *ptr,
+                                 int32_t *ops, int32_t *depth)
+{
+    RT_REQUIRE(nnodes >= 1 && ptr && (idx || nnodes == 1) && ops, "bad arguments");
+    RT_REQUIRE(ptr[0] == 0 && ptr[nnodes] == nnodes - 1,
+               "tree_csr_indptr does not describe a tree");
+    for (int64_t v = 0; v < nnodes; ++v)
+        for (int64_t e = ptr[v]; e < ptr[v + 1]; ++e)
+            RT_REQUIRE(idx[e] > v && idx[e] < nnodes, "children not in preorder");
+    rt_model m;
+    m.nnodes = nnodes;
+    if (nnodes > 1) m.indices.assign(idx, idx + (nnodes - 1));
+    m.indptr.assign(ptr, ptr + nnodes + 1);
+    build_schedule(&m);
+    memcpy(ops, m.ops.data(), m.ops.size() * sizeof(rt_op));
+    if (depth) *depth = m.max_depth;
+    return RT_OK;
+}
+
+static int64_t pfrag_doubles(const rt_model *m)
+{
+    const int64_t nops = (int64_t)m->ops.size();
+    if (m->n <= 4) return nops * m->n * m->n;
+    const int64_t nt = (m->n + 15) / 16, kp = ((m->n + 3) / 4 + 1) / 2;
+    return nops * nt * kp * 128;
+}
+
+extern "C" int rt_model_destroy(rt_model *m)
+{
+    if (!m) return RT_OK;
+    hipSetDevice(m->ctx->device);
+    hipStreamSynchronize(m->ctx->stream);
+    hipFree(m->d_indices); hipFree(m->d_indptr); hipFree(m->d_ops); hipFree(m->d_P);
+    hipFree(m->d_Pfrag); hipFree(m->d_root); hipFree(m->d_Q); hipFree(m->d_qidx);
+    hipFree(m->d_t); hipFree(m->d_info);
+    delete m;
+    return RT_OK;
+}
+
+extern "C" int rt_model_create(rt_ctx *ctx, int64_t nnodes, int64_t n,
+                               const int64_t *idx, const int64_t *ptr, rt_model **out)
+{
+    RT_REQUIRE(ctx && out, "null pointer");
+    *out = nullptr;
+    RT_REQUIRE(nnodes >= 1 && n >= 1, "bad sizes");
+    RT_REQUIRE(n <= RT_MAX_STATES, "n=%lld > %d", (long long)n, RT_MAX_STATES);
+    RT_REQUIRE(nnodes < (1ll << 30), "tree too large");
+    RT_REQUIRE(ptr && (idx || nnodes == 1), "null array");
+    RT_REQUIRE(ptr[0] == 0 && ptr[nnodes] == nnodes - 1,
+               "tree_csr_indptr does not describe a tree");
+    std::vector<char> seen((size_t)nnodes, 0);
+    for (int64_t v = 0; v < nnodes; ++v) {
+        RT_REQUIRE(ptr[v + 1] >= ptr[v], "tree_csr_indptr not monotone");
+        for (int64_t e = ptr[v]; e < ptr[v + 1]; ++e) {
+            RT_REQUIRE(idx[e] > v && idx[e] < nnodes,
+                       "child index %lld of node %lld is not in preorder",
+                       (long long)idx[e], (long long)v);
+            RT_REQUIRE(!seen[(size_t)idx[e]], "node %lld has two parents",
+                       (long long)idx[e]);
+            seen[(size_t)idx[e]] = 1;
+        }
+    }
+    RT_HIP(hipSetDevice(ctx->device));
+    rt_model *m = new (std::nothrow) rt_model();
+    if (!m) return RT_ERR_NOMEM;
+    m->ctx = ctx;
+    m->nnodes = nnodes;
+    m->n = n;
+    if (nnodes > 1) m->indices.assign(idx, idx + (nnodes - 1));
+    m->indptr.assign(ptr, ptr + nnodes + 1);
+    build_schedule(m);
+    const size_t nn = (size_t)n * n;
+    hipError_t e = hipMalloc((void **)&m->d_indices, std::max<size_t>(8, (nnodes - 1) * 8));
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_indptr, (nnodes + 1) * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_ops, m->ops.size() * sizeof(rt_op));
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_P, nnodes * nn * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_Pfrag, pfrag_doubles(m) * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_root, n * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_qidx, nnodes * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_t, nnodes * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_info, nnodes * 8);
+    if (e == hipSuccess && nnodes > 1)
+        e = hipMemcpy(m->d_indices, idx, (nnodes - 1) * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(m->d_indptr, ptr, (nnodes + 1) * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(m->d_ops, m->ops.data(), m->ops.size() * sizeof(rt_op),
+                      hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(m->d_P, 0, nnodes * nn * 8);
+    if (e == hipSuccess) e = hipMemset(m->d_info, 0, nnodes * 8);
+    std::vector<double> ones((size_t)n, 1.0);
+    if (e == hipSuccess) e = hipMemcpy(m->d_root, ones.data(), n * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        rt_set_error("rt_model_create: %s", hipGetErrorString(e));
+        rt_model_destroy(m);
+        return e == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_HIP;
+    }
+    *out = m;
+    return RT_OK;
+}
+
+static int model_run_expm(rt_model *m)
+{
+    RT_TRY(rt_launch_expm(m->ctx, m->n, m->nnodes, m->d_Q, m->d_qidx, m->d_t, m->d_P,
+                          m->d_info));
+    m->have_P = true;
+    m->frag_dirty = true;
+    return rt_launch_pfrag(m);
+}
+
+extern "C" int rt_model_set_rates(rt_model *m, const double *Q, int64_t nq,
+                                  const int64_t *node_q, const double *t)
+{
+    RT_REQUIRE(m && Q && t, "null pointer");
+    RT_REQUIRE(nq >= 1, "nq must be >= 1");
+    if (m->n > RT_MAX_EXPM_STATES) {
+        rt_set_error("expm: n=%lld > %d", (long long)m->n, RT_MAX_EXPM_STATES);
+        return RT_ERR_UNSUPPORTED;
+    }
+    RT_HIP(hipSetDevice(m->ctx->device));
+    const size_t nn = (size_t)m->n * m->n;
+    std::vector<int32_t> qi((size_t)m->nnodes);
+    std::vector<double> tt((size_t)m->nnodes);
+    qi[0] = -1;
+    tt[0] = 0.0;
+    for (int64_t v = 1; v < m->nnodes; ++v) {
+        const int64_t q = node_q ? node_q[v] : 0;
+        RT_REQUIRE(q >= 0 && q < nq, "node_q[%lld]=%lld out of range", (long long)v,
+                   (long long)q);
+        RT_REQUIRE(std::isfinite(t[v]), "branch length of node %lld is not finite",
+                   (long long)v);
+        qi[(size_t)v] = (int32_t)q;
+        tt[(size_t)v] = t[v];
+    }
+    if (nq > m->q_capacity) {
+        hipFree(m->d_Q);
+        m->d_Q = nullptr;
+        m->q_capacity = 0;
+        RT_HIP(hipMalloc((void **)&m->d_Q, nq * nn * 8));
+        m->q_capacity = nq;
+    }
+    hipStream_t st = m->ctx->stream;
+    // pageable sources: hipMemcpy (synchronous) so the vectors above may go away
+    RT_HIP(hipStreamSynchronize(st));
+    RT_HIP(hipMemcpy(m->d_Q, Q, nq * nn * 8, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(m->d_qidx, qi.data(), m->nnodes * 4, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(m->d_t, tt.data(), m->nnodes * 8, hipMemcpyHostToDevice));
+    return model_run_expm(m);
+}
+
+extern "C" int rt_model_recompute_transitions(rt_model *m)
+{
+    RT_REQUIRE(m, "null model");
+    RT_REQUIRE(m->d_Q, "rt_model_set_rates has not been called");
+    RT_HIP(hipSetDevice(m->ctx->device));
+    return model_run_expm(m);
+}
+
+extern "C" int rt_model_set_transitions(rt_model *m, const double *esd)
+{
+    RT_REQUIRE(m && esd, "null pointer");
+    RT_HIP(hipSetDevice(m->ctx->device));
+    RT_HIP(hipStreamSynchronize(m->ctx->stream));
+    RT_HIP(hipMemcpy(m->d_P, esd, (size_t)m->nnodes * m->n * m->n * 8,
+                     hipMemcpyHostToDevice));
+    m->have_P = true;
+    m->frag_dirty = true;
+    return rt_launch_pfrag(m);
+}
+
+extern "C" int rt_model_get_transitions(rt_model *m, double *esd)
+{
+    RT_REQUIRE(m && esd, "null pointer");
+    RT_REQUIRE(m->have_P, "the model has no transition matrices yet");
+    RT_HIP(hipSetDevice(m->ctx->device));
+    RT_HIP(hipStreamSynchronize(m->ctx->stream));
+    RT_HIP(hipMemcpy(esd, m->d_P, (size_t)m->nnodes * m->n * m->n * 8,
+                     hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" int rt_model_get_expm_info(rt_model *m, int32_t *info)
+{
+    RT_REQUIRE(m && info, "null pointer");
+    RT_HIP(hipSetDevice(m->ctx->device));
+    RT_HIP(hipStreamSynchronize(m->ctx->stream));
+    RT_HIP(hipMemcpy(info, m->d_info, (size_t)m->nnodes * 8, hipMemcpyDeviceToHost));
+    for (int64_t v = 1; v < m->nnodes; ++v)
+        if (info[2 * v] < 0) {
+            rt_set_error("expm: singular Pade denominator on the edge above node %lld",
+                         (long long)v);
+            return RT_ERR_SINGULAR;
+        }
+    return RT_OK;
+}
+
+extern "C" int rt_model_set_root_distn(rt_model *m, const double *root_distn)
+{
+    RT_REQUIRE(m, "null model");
+    RT_HIP(hipSetDevice(m->ctx->device));
+    std::vector<double> w((size_t)m->n, 1.0);
+    if (root_distn) w.assign(root_distn, root_distn + m->n);
+    RT_HIP(hipStreamSynchronize(m->ctx->stream));
+    RT_HIP(hipMemcpy(m->d_root, w.data(), m->n * 8, hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+extern "C" int rt_model_schedule_depth(const rt_model *m)
+{
+    return m ? m->max_depth : -1;
+}
+
+// ---- sites ------------------------------------------------------------------------------------
+
+static const int RT_FAST_MAX_DEPTH = 16;   // LDS accumulator stack of the fast kernels
+static int g_force_generic = 0;
+
+extern "C" int rt_set_option(const char *key, int64_t value)
+{
+    RT_REQUIRE(key, "null key");
+    if (strcmp(key, "force_generic") == 0) { g_force_generic = value != 0; return RT_OK; }
+    rt_set_error("unknown option %s", key);
+    return RT_ERR_INVALID;
+}
+
+extern "C" int rt_sites_destroy(rt_sites *s)
+{
+    if (!s) return RT_OK;
+    hipSetDevice(s->model->ctx->device);
+    hipStreamSynchronize(s->model->ctx->stream);
+    hipFree(s->d_ops); hipFree(s->d_obs); hipFree(s->d_loglik); hipFree(s->d_status);
+    hipFree(s->d_partial); hipFree(s->d_totals); hipFree(s->d_scratch);
+    delete s;
+    return RT_OK;
+}
+
+static int sites_alloc(rt_sites *s, bool generic)
+{
+    rt_model *m = s->model;
+    const int64_t n = m->n;
+    const int64_t K = s->nobs;
+    int64_t padded;
+    if (s->layout == RT_LAYOUT_LANE) {
+        s->nblocks = std::max<int64_t>(1, (s->nsites + 63) / 64);
+        const int64_t np = (n + 1) & ~1ll;
+        s->obs_bytes = s->nblocks * K * 64 * np * 8;
+        padded = s->nblocks * 64;
+        s->npartials = s->nblocks;
+    } else {
+        s->nblocks = std::max<int64_t>(1, (s->nsites + 15) / 16);
+        const int64_t kp = ((n + 3) / 4 + 1) / 2;
+        s->obs_bytes = s->nblocks * K * kp * 128 * 8;
+        padded = s->nblocks * 16;
+        const int64_t nt = (n + 15) / 16;
+        const int64_t waves = nt == 3 ? 3 : 4;
+        const int64_t tiles = waves / nt;
+        s->npartials = (s->nblocks + tiles - 1) / tiles * waves;
+    }
+    hipError_t e = hipMalloc((void **)&s->d_ops, s->ops.size() * sizeof(rt_op));
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_obs, std::max<int64_t>(s->obs_bytes, 1024));
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_loglik, padded * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_status, padded * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_partial, s->npartials * 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_totals, 3 * 8);
+    if (e == hipSuccess) e = hipMemset(s->d_totals, 0, 3 * 8);
+    if (e == hipSuccess && generic) {
+        s->scratch_bytes = std::max<int64_t>(1, m->max_depth) * n * padded * 8;
+        e = hipMalloc((void **)&s->d_scratch, s->scratch_bytes);
+    }
+    if (e == hipSuccess)
+        e = hipMemcpy(s->d_ops, s->ops.data(), s->ops.size() * sizeof(rt_op),
+                      hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        rt_set_error("rt_sites: %s", hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_HIP;
+    }
+    return RT_OK;
+}
+
+extern "C" int rt_sites_create(rt_model *m, int64_t nsites, int kind, int64_t nobs,
+                               const int64_t *obs_nodes, const void *data,
+                               rt_sites **out)
+{
+    RT_REQUIRE(m && out, "null pointer");
+    *out = nullptr;
+    RT_REQUIRE(nsites >= 1, "nsites must be >= 1");
+    RT_REQUIRE(kind == RT_OBS_DENSE || kind == RT_OBS_STATE || kind == RT_OBS_MASK,
+               "unknown observation kind %d", kind);
+    RT_REQUIRE(nobs >= 0 && nobs <= m->nnodes, "bad nobs");
+    RT_REQUIRE(nobs == 0 || (obs_nodes && data), "null observation arrays");
+    RT_REQUIRE(kind != RT_OBS_STATE || m->n <= 255, "uint8 states need n <= 255");
+    RT_HIP(hipSetDevice(m->ctx->device));
+    rt_sites *s = new (std::nothrow) rt_sites();
+    if (!s) return RT_ERR_NOMEM;
+    s->model = m;
+    s->nsites = nsites;
+    s->nobs = nobs;
+    s->node_obs.assign((size_t)m->nnodes, -1);
+    for (int64_t j = 0; j < nobs; ++j) {
+        const int64_t v = obs_nodes[j];
+        if (v < 0 || v >= m->nnodes || s->node_obs[(size_t)v] >= 0) {
+            rt_set_error("obs_nodes[%lld]=%lld out of range or repeated", (long long)j,
+                         (long long)v);
+            delete s;
+            return RT_ERR_INVALID;
+        }
+        s->node_obs[(size_t)v] = (int32_t)j;
+    }
+    // observation stream = observed nodes in schedule order
+    s->ops = m->ops;
+    std::vector<int64_t> src_of_k;
+    for (auto &op : s->ops) {
+        const int32_t j = s->node_obs[(size_t)op.node];
+        if (j >= 0) {
+            op.obs = (int32_t)src_of_k.size();
+            src_of_k.push_back(j);
+        }
+    }
+    const bool generic = g_force_generic || m->max_depth > RT_FAST_MAX_DEPTH;
+    s->layout = (generic || m->n <= 4) ? RT_LAYOUT_LANE : RT_LAYOUT_MFMA;
+    int rc = sites_alloc(s, generic);
+    if (rc == RT_OK) rc = rt_sites_pack(s, kind, src_of_k.data(), data);
+    if (rc != RT_OK) {
+        rt_sites_destroy(s);
+        return rc;
+    }
+    *out = s;
+    return RT_OK;
+}
+
+extern "C" int rt_sites_clone(rt_sites *src, rt_sites **out)
+{
+    RT_REQUIRE(src && out, "null pointer");
+    *out = nullptr;
+    RT_HIP(hipSetDevice(src->model->ctx->device));
+    rt_sites *s = new (std::nothrow) rt_sites();
+    if (!s) return RT_ERR_NOMEM;
+    s->model = src->model;
+    s->nsites = src->nsites;
+    s->nobs = src->nobs;
+    s->layout = src->layout;
+    s->node_obs = src->node_obs;
+    s->ops = src->ops;
+    int rc = sites_alloc(s, src->d_scratch != nullptr);
+    if (rc == RT_OK && s->obs_bytes > 0) {
+        hipStreamSynchronize(src->model->ctx->stream);
+        hipError_t e = hipMemcpy(s->d_obs, src->d_obs, s->obs_bytes, hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) {
+            rt_set_error("rt_sites_clone: %s", hipGetErrorString(e));
+            rc = RT_ERR_HIP;
+        }
+    }
+    if (rc != RT_OK) {
+        rt_sites_destroy(s);
+        return rc;
+    }
+    *out = s;
+    return RT_OK;
+}
+
+extern "C" int64_t rt_sites_device_bytes(const rt_sites *s)
+{
+    return s ? s->obs_bytes : 0;
+}
+
+extern "C" int rt_prune(rt_model *m, rt_sites *s)
+{
+    RT_REQUIRE(m && s, "null pointer");
+    RT_REQUIRE(s->model == m, "the site batch belongs to another model");
+    RT_REQUIRE(m->have_P, "the model has no transition matrices yet");
+    RT_HIP(hipSetDevice(m->ctx->device));
+    return rt_launch_prune(m, s);
+}
+
+extern "C" int rt_sites_get_logliks(rt_sites *s, double *loglik, int32_t *status)
+{
+    RT_REQUIRE(s, "null pointer");
+    RT_HIP(hipSetDevice(s->model->ctx->device));
+    RT_HIP(hipStreamSynchronize(s->model->ctx->stream));
+    if (loglik)
+        RT_HIP(hipMemcpy(loglik, s->d_loglik, s->nsites * 8, hipMemcpyDeviceToHost));
+    if (status)
+        RT_HIP(hipMemcpy(status, s->d_status, s->nsites * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" int rt_sites_get_totals(rt_sites *s, double totals[3])
+{
+    RT_REQUIRE(s && totals, "null pointer");
+    RT_HIP(hipSetDevice(s->model->ctx->device));
+    RT_HIP(hipStreamSynchronize(s->model->ctx->stream));
+    RT_HIP(hipMemcpy(totals, s->d_totals, 3 * 8, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+// Debug / test hook: copy the post-order schedule out (rt_op as int32[4]).
+extern "C" int rt_model_get_schedule(const rt_model *m, int32_t *ops, int64_t capacity,
+                                     int64_t *nops)
+{
+    RT_REQUIRE(m && nops, "null pointer");
+    *nops = (int64_t)m->ops.size();
+    if (ops) {
+        RT_REQUIRE(capacity >= *nops, "capacity too small");
+        memcpy(ops, m->ops.data(), m->ops.size() * sizeof(rt_op));
+    }
+    return RT_OK;
+}

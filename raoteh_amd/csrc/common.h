@@ -1,0 +1,138 @@
+// Internal declarations shared by the HIP translation units of
+// libraoteh_hip.so.  gfx950 only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/raoteh_hip.h"
+
+// ---- error plumbing ---------------------------------------------------------
+
+void rt_set_error(const char *fmt, ...);
+
+#define RT_HIP(call)                                                          \
+    do {                                                                      \
+        hipError_t e_ = (call);                                               \
+        if (e_ != hipSuccess) {                                               \
+            rt_set_error("%s failed: %s (%s:%d)", #call,                      \
+                         hipGetErrorString(e_), __FILE__, __LINE__);          \
+            return RT_ERR_HIP;                                                \
+        }                                                                     \
+    } while (0)
+
+#define RT_REQUIRE(cond, ...)                                                 \
+    do {                                                                      \
+        if (!(cond)) {                                                        \
+            rt_set_error(__VA_ARGS__);                                        \
+            return RT_ERR_INVALID;                                            \
+        }                                                                     \
+    } while (0)
+
+#define RT_TRY(call)                                                          \
+    do {                                                                      \
+        int rc_ = (call);                                                     \
+        if (rc_ != RT_OK) return rc_;                                         \
+    } while (0)
+
+// ---- handles ------------------------------------------------------------------
+
+struct rt_timing_slot {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::vector<hipEvent_t> pool;
+    double total_ms = 0.0;
+    int64_t launches = 0;
+    const char *name = "";
+};
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 0;
+    bool timing = false;
+    rt_timing_slot slots[RT_K_COUNT];
+    void *comm = nullptr;          // ncclComm_t
+    void *rccl = nullptr;          // dlopen handle
+};
+
+// One schedule step of the fast pruning kernels: a node of the tree visited in
+// post-order.  For a non-root node v the step forms L_v (pop its accumulator if
+// internal, multiply its observation in), t = P_v * L_v and folds t into its
+// parent's accumulator slot; the final step (dst = -1) is the root reduction.
+struct rt_op {
+    int32_t node;      // preorder index of v (also the P slot of edge parent->v)
+    int32_t obs;       // position of v in the observation stream, or -1
+    int32_t pop;       // accumulator slot of v (internal node), or -1 (leaf)
+    int32_t dst;       // parent's accumulator slot | (first child ? 256 : 0); -1 root
+};
+
+struct rt_model {
+    rt_ctx *ctx = nullptr;
+    int64_t nnodes = 0;
+    int64_t n = 0;
+    std::vector<int64_t> indices, indptr;   // host copy of the CSR
+    std::vector<int32_t> parent;            // preorder parent index, -1 root
+    std::vector<rt_op> ops;                 // post-order schedule
+    int max_depth = 0;                      // accumulator slots needed
+    // device
+    int64_t *d_indices = nullptr, *d_indptr = nullptr;
+    rt_op *d_ops = nullptr;
+    double *d_P = nullptr;          // [nnodes][n][n] esd_transitions
+    double *d_Pfrag = nullptr;      // MFMA A-fragment order (n > 4)
+    double *d_root = nullptr;       // [n] root weights (ones if unset)
+    double *d_Q = nullptr;          // rate matrices of the last set_rates
+    int64_t q_capacity = 0;
+    int32_t *d_qidx = nullptr;      // [nnodes]
+    double *d_t = nullptr;          // [nnodes]
+    int32_t *d_info = nullptr;      // [nnodes][2]
+    bool have_P = false;
+    bool frag_dirty = true;
+};
+
+// Device layouts of a site batch:
+//  RT_LAYOUT_LANE  (n <= 4)  [block of 64 sites][obs slot][lane][np] f64,
+//                  np = n rounded up to even: one lane owns one site
+//  RT_LAYOUT_MFMA  (n  > 4)  [block of 16 sites][obs slot][k-step pair][lane][2]
+//                  f64 in v_mfma_f64_16x16x4 B-operand order
+enum { RT_LAYOUT_LANE = 0, RT_LAYOUT_MFMA = 1 };
+
+struct rt_sites {
+    rt_model *model = nullptr;
+    int64_t nsites = 0;
+    int64_t nobs = 0;
+    int layout = RT_LAYOUT_LANE;
+    int64_t nblocks = 0;            // site blocks (64 or 16 sites each)
+    int64_t obs_bytes = 0;
+    std::vector<int32_t> node_obs;  // per node: stream position or -1
+    std::vector<rt_op> ops;         // model ops with .obs filled in
+    rt_op *d_ops = nullptr;
+    double *d_obs = nullptr;
+    double *d_loglik = nullptr;     // [nblocks * sites per block]
+    int32_t *d_status = nullptr;
+    double *d_partial = nullptr;    // [npartials][2] (sum, nzero)
+    int64_t npartials = 0;
+    double *d_totals = nullptr;     // [3]
+    double *d_scratch = nullptr;    // generic kernel message stack
+    int64_t scratch_bytes = 0;
+};
+
+// ---- internal entry points ---------------------------------------------------------
+
+void rt_time_begin(rt_ctx *ctx, int kernel, const char *name, hipEvent_t *start);
+void rt_time_end(rt_ctx *ctx, int kernel, hipEvent_t start);
+
+int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
+                   const int32_t *d_qidx, const double *d_t, double *d_P,
+                   int32_t *d_info);
+int rt_launch_pfrag(rt_model *m);
+int rt_launch_prune(rt_model *m, rt_sites *s);
+int rt_sites_pack(rt_sites *s, int kind, const int64_t *obs_order,
+                  const void *data);
+
+static inline int64_t rt_round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }

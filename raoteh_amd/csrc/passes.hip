@@ -1,0 +1,226 @@
+// The three pyfelscore passes on the reference's own array formats, batched
+// over sites (one workgroup of 64 lanes per site, lane = state).
+//
+//   mcy_esd_get_node_to_pset   backward boolean pass   (_mcy_dense.py:270)
+//   esd_get_node_to_set        forward boolean pass    (_mcy_dense.py:277)
+//   mcy_esd_get_node_to_pmap   Felsenstein upward pass (_mcy_dense.py:286)
+//
+// Arrays: tree CSR int64 (children, DFS-preorder index space, so every child
+// index is larger than its parent's), esd_transitions f64[N][n][n] keyed by the
+// child index, state_mask int64[nsites][N][n], pmap f64[nsites][N][n].
+// These kernels serve the drop-in API (per-node pmaps for every site); the
+// log-likelihood hot path is prune.hip.
+#include "common.h"
+
+namespace {
+
+__global__ void __launch_bounds__(64)
+pset_kernel(int nnodes, int n, const long *__restrict__ idx,
+            const long *__restrict__ ptr, const double *__restrict__ esd,
+            long *__restrict__ mask)
+{
+    const int s = threadIdx.x;
+    long *mk = mask + (size_t)blockIdx.x * nnodes * n;
+    for (int v = nnodes - 1; v >= 0; --v) {
+        if (s < n) {
+            long keep = mk[(size_t)v * n + s] != 0;
+            for (long e = ptr[v]; e < ptr[v + 1]; ++e) {
+                const long c = idx[e];
+                const double *Pc = esd + ((size_t)c * n + s) * n;
+                const long *mc = mk + (size_t)c * n;
+                long any = 0;
+                for (int sp = 0; sp < n; ++sp)
+                    any |= (Pc[sp] > 0.0) && (mc[sp] != 0);
+                keep &= any;
+            }
+            mk[(size_t)v * n + s] = keep;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(64)
+set_kernel(int nnodes, int n, const long *__restrict__ idx,
+           const long *__restrict__ ptr, const double *__restrict__ esd,
+           long *__restrict__ mask)
+{
+    const int sp = threadIdx.x;     // child state
+    long *mk = mask + (size_t)blockIdx.x * nnodes * n;
+    for (int v = 0; v < nnodes; ++v) {
+        for (long e = ptr[v]; e < ptr[v + 1]; ++e) {
+            const long c = idx[e];
+            if (sp < n) {
+                const double *Pc = esd + (size_t)c * n * n;
+                const long *mv = mk + (size_t)v * n;
+                long any = 0;
+                for (int s = 0; s < n; ++s)
+                    any |= (mv[s] != 0) && (Pc[(size_t)s * n + sp] > 0.0);
+                mk[(size_t)c * n + sp] = (mk[(size_t)c * n + sp] != 0) & any;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(64)
+pmap_kernel(int nnodes, int n, const long *__restrict__ idx,
+            const long *__restrict__ ptr, const double *__restrict__ esd,
+            const long *__restrict__ mask, const double *__restrict__ obs,
+            double *__restrict__ out)
+{
+    const int s = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * nnodes * n;
+    const long *mk = mask + base;
+    double *o = out + base;
+    for (int v = nnodes - 1; v >= 0; --v) {
+        if (s < n) {
+            double acc = 1.0;
+            for (long e = ptr[v]; e < ptr[v + 1]; ++e) {
+                const long c = idx[e];
+                const double *Pc = esd + ((size_t)c * n + s) * n;
+                const double *Lc = o + (size_t)c * n;
+                double sum = 0.0;
+                for (int sp = 0; sp < n; ++sp) sum = fma(Pc[sp], Lc[sp], sum);
+                acc *= sum;
+            }
+            if (obs) acc *= obs[base + (size_t)v * n + s];
+            o[(size_t)v * n + s] = mk[(size_t)v * n + s] != 0 ? acc : 0.0;
+        }
+        __syncthreads();
+    }
+}
+
+struct dev_tree {
+    long *idx = nullptr, *ptr = nullptr;
+    double *esd = nullptr;
+    ~dev_tree() { hipFree(idx); hipFree(ptr); hipFree(esd); }
+};
+
+int check_tree(int64_t nnodes, int64_t n, int64_t nsites, const int64_t *idx,
+               const int64_t *ptr, const double *esd)
+{
+    RT_REQUIRE(nnodes >= 1 && n >= 1 && nsites >= 0, "bad sizes");
+    RT_REQUIRE(n <= RT_MAX_STATES, "n=%lld > %d", (long long)n, RT_MAX_STATES);
+    RT_REQUIRE(ptr && esd && (idx || nnodes == 1), "null array");
+    RT_REQUIRE(ptr[0] == 0 && ptr[nnodes] == nnodes - 1,
+               "tree_csr_indptr does not describe a tree");
+    for (int64_t v = 0; v < nnodes; ++v) {
+        RT_REQUIRE(ptr[v + 1] >= ptr[v], "tree_csr_indptr not monotone");
+        for (int64_t e = ptr[v]; e < ptr[v + 1]; ++e)
+            RT_REQUIRE(idx[e] > v && idx[e] < nnodes,
+                       "child index %lld of node %lld is not in preorder",
+                       (long long)idx[e], (long long)v);
+    }
+    return RT_OK;
+}
+
+int upload_tree(rt_ctx *ctx, dev_tree &d, int64_t nnodes, int64_t n,
+                const int64_t *idx, const int64_t *ptr, const double *esd)
+{
+    const size_t ni = (size_t)(nnodes > 1 ? nnodes - 1 : 1);
+    RT_HIP(hipMalloc((void **)&d.idx, ni * 8));
+    RT_HIP(hipMalloc((void **)&d.ptr, (size_t)(nnodes + 1) * 8));
+    RT_HIP(hipMalloc((void **)&d.esd, (size_t)nnodes * n * n * 8));
+    if (nnodes > 1)
+        RT_HIP(hipMemcpyAsync(d.idx, idx, (size_t)(nnodes - 1) * 8,
+                              hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(hipMemcpyAsync(d.ptr, ptr, (size_t)(nnodes + 1) * 8, hipMemcpyHostToDevice,
+                          ctx->stream));
+    RT_HIP(hipMemcpyAsync(d.esd, esd, (size_t)nnodes * n * n * 8,
+                          hipMemcpyHostToDevice, ctx->stream));
+    return RT_OK;
+}
+
+int mask_pass(rt_ctx *ctx, bool forward, int64_t nnodes, int64_t n, int64_t nsites,
+              const int64_t *idx, const int64_t *ptr, const double *esd,
+              int64_t *state_mask)
+{
+    RT_REQUIRE(ctx, "null context");
+    RT_TRY(check_tree(nnodes, n, nsites, idx, ptr, esd));
+    RT_REQUIRE(state_mask || nsites == 0, "null state_mask");
+    if (nsites == 0) return RT_OK;
+    RT_HIP(hipSetDevice(ctx->device));
+    dev_tree d;
+    RT_TRY(upload_tree(ctx, d, nnodes, n, idx, ptr, esd));
+    const size_t bytes = (size_t)nsites * nnodes * n * 8;
+    long *dm = nullptr;
+    RT_HIP(hipMalloc((void **)&dm, bytes));
+    hipError_t e = hipMemcpyAsync(dm, state_mask, bytes, hipMemcpyHostToDevice,
+                                  ctx->stream);
+    if (e == hipSuccess) {
+        if (forward)
+            hipLaunchKernelGGL(set_kernel, dim3((unsigned)nsites), dim3(64), 0,
+                               ctx->stream, (int)nnodes, (int)n, d.idx, d.ptr, d.esd, dm);
+        else
+            hipLaunchKernelGGL(pset_kernel, dim3((unsigned)nsites), dim3(64), 0,
+                               ctx->stream, (int)nnodes, (int)n, d.idx, d.ptr, d.esd, dm);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(state_mask, dm, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(dm);
+    if (e != hipSuccess) {
+        rt_set_error("mask pass failed: %s", hipGetErrorString(e));
+        return RT_ERR_HIP;
+    }
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" int rt_mcy_esd_get_node_to_pset(rt_ctx *ctx, int64_t nnodes, int64_t n,
+        int64_t nsites, const int64_t *idx, const int64_t *ptr, const double *esd,
+        int64_t *state_mask)
+{
+    return mask_pass(ctx, false, nnodes, n, nsites, idx, ptr, esd, state_mask);
+}
+
+extern "C" int rt_esd_get_node_to_set(rt_ctx *ctx, int64_t nnodes, int64_t n,
+        int64_t nsites, const int64_t *idx, const int64_t *ptr, const double *esd,
+        int64_t *state_mask)
+{
+    return mask_pass(ctx, true, nnodes, n, nsites, idx, ptr, esd, state_mask);
+}
+
+extern "C" int rt_mcy_esd_get_node_to_pmap(rt_ctx *ctx, int64_t nnodes, int64_t n,
+        int64_t nsites, const int64_t *idx, const int64_t *ptr, const double *esd,
+        const int64_t *state_mask, const double *obs_likelihood,
+        double *subtree_probability)
+{
+    RT_REQUIRE(ctx, "null context");
+    RT_TRY(check_tree(nnodes, n, nsites, idx, ptr, esd));
+    RT_REQUIRE((state_mask && subtree_probability) || nsites == 0, "null array");
+    if (nsites == 0) return RT_OK;
+    RT_HIP(hipSetDevice(ctx->device));
+    dev_tree d;
+    RT_TRY(upload_tree(ctx, d, nnodes, n, idx, ptr, esd));
+    const size_t bytes = (size_t)nsites * nnodes * n * 8;
+    long *dm = nullptr;
+    double *dobs = nullptr, *dout = nullptr;
+    hipError_t e = hipMalloc((void **)&dm, bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&dout, bytes);
+    if (e == hipSuccess && obs_likelihood) e = hipMalloc((void **)&dobs, bytes);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(dm, state_mask, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && obs_likelihood)
+        e = hipMemcpyAsync(dobs, obs_likelihood, bytes, hipMemcpyHostToDevice,
+                           ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(pmap_kernel, dim3((unsigned)nsites), dim3(64), 0, ctx->stream,
+                           (int)nnodes, (int)n, d.idx, d.ptr, d.esd, dm, dobs, dout);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(subtree_probability, dout, bytes, hipMemcpyDeviceToHost,
+                           ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(dm);
+    hipFree(dout);
+    hipFree(dobs);
+    if (e != hipSuccess) {
+        rt_set_error("pmap pass failed: %s", hipGetErrorString(e));
+        return RT_ERR_HIP;
+    }
+    return RT_OK;
+}

@@ -1,0 +1,781 @@
+// Felsenstein upward pass (leaf -> root), batched over independent sites.
+//
+// Replaces pyfelscore.mcy_esd_get_node_to_pmap + _mc0_dense.get_likelihood of
+// the reference (raoteh/sampler/_mcy_dense.py:286, _mc0_dense.py:147-212) for
+// the log-likelihood hot path:
+//
+//   L[v,s] = obs[v,s] * prod_{c child of v} sum_{s'} P_c[s,s'] * L[c,s']
+//   lik    = sum_s w[s] * max(L[root,s], 0);  loglik = log(lik)
+//
+// Three kernel families, all f64, all driven by the same post-order schedule
+// (rt_op, common.h):
+//
+//   prune_lane_kernel   n <= 4   one lane = one site.  Leaf vectors stream
+//                       HBM -> LDS through an LDS-DMA ring (global_load_lds,
+//                       1 KiB per wave-instruction, R slots in flight per wave),
+//                       P_e comes through the scalar cache as FMA operands,
+//                       pending accumulators live in a register stack.
+//                       HBM-bound (config 2).
+//   prune_mfma_kernel   4 < n <= 64   one wave = 16 sites, one workgroup = 64
+//                       sites.  t = P_e * L as v_mfma_f64_16x16x4_f64 tiles:
+//                       the D tile of one edge IS the B operand of the next
+//                       edge (same lane/register map), so messages never leave
+//                       registers.  P_e is staged once per workgroup in LDS
+//                       (LDS-DMA, double buffered), leaf vectors are loaded in
+//                       B-operand order straight from HBM one step ahead.
+//   prune_generic_kernel  any n <= 64, any stack depth: one lane = one site,
+//                       accumulators in a global scratch stack.  Fallback only.
+#include "common.h"
+
+#include <algorithm>
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+#define RT_CONST_AS __attribute__((address_space(4)))
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef int int4_t __attribute__((ext_vector_type(4)));
+
+// schedule entries are wave-uniform: read them through the scalar cache
+__device__ __forceinline__ rt_op load_op(const RT_CONST_AS int4_t *ops, int i)
+{
+    const int4_t o = ops[i];
+    rt_op op;
+    op.node = o.x;
+    op.obs = o.y;
+    op.pop = o.z;
+    op.dst = o.w;
+    return op;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ void finish_site(double lik, bool negative,
+                                            bool valid, double *loglik,
+                                            int *status, long site,
+                                            double &sum, double &nzero)
+{
+    const bool ok = lik > 0.0;
+    if (valid) {
+        loglik[site] = ok ? log(lik) : -INFINITY;
+        status[site] = (ok ? RT_SITE_OK : RT_SITE_ZERO_PROB) |
+                       (negative ? RT_SITE_NEGATIVE : 0);
+        sum = ok ? log(lik) : 0.0;
+        nzero = ok ? 0.0 : 1.0;
+    } else {
+        sum = 0.0;
+        nzero = 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// How the fast kernels walk the tree
+// ---------------------------------------------------------------------------
+//
+// One flat loop over the post-order schedule (rt_op).  Pending accumulators
+// live in an LDS stack indexed by the slot numbers the host assigned
+// (build_schedule, api.hip): with its Sethi-Ullman child order the stack needs
+// at most floor(log2(#leaves)) + 1 slots for ANY tree shape.  The LDS stack is
+// laid out [slot][component][lane], so every access is a conflict-free
+// ds_read_b64 / ds_write_b64 and no register array is ever indexed at run time.
+// Every branch on the schedule is wave-uniform (scalar).
+
+#define RT_OP_IS_INTERNAL(op) ((op).pop >= 0)
+#define RT_OP_IS_ROOT(op) ((op).dst < 0)
+#define RT_OP_IS_FIRST(op) (((op).dst >> 8) != 0)
+
+// ---------------------------------------------------------------------------
+// n <= 4: one wave per workgroup, lane per site, LDS-DMA ring, scalar-cache P
+// ---------------------------------------------------------------------------
+
+template <int N, int R>
+__global__ void __launch_bounds__(64)
+prune_lane_kernel(const double *__restrict__ Pord,   // [nops][N][N]
+                  const rt_op *__restrict__ ops, int nops,
+                  const double *__restrict__ obs, int K,
+                  const double *__restrict__ root_w,
+                  double *__restrict__ loglik, int *__restrict__ status,
+                  double *__restrict__ partial, long nsites)
+{
+    constexpr int NP = (N + 1) & ~1;          // states per site in HBM (even)
+    constexpr int SLOT = 64 * NP * 8;         // bytes of one obs slot
+    constexpr int IPS = SLOT / 1024;          // LDS-DMA instructions per slot
+    constexpr int NN = N * N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int lane = threadIdx.x;
+    const long gw = blockIdx.x;               // site block of this wave
+    unsigned char *ring = smem;
+    double *stack = (double *)(smem + R * SLOT) + lane;   // [slot][N][64]
+    const unsigned char *g =
+        (const unsigned char *)obs + (size_t)gw * K * SLOT + lane * 16;
+    const RT_CONST_AS int4_t *ops_c = (const RT_CONST_AS int4_t *)ops;
+    const RT_CONST_AS double *P_c = (const RT_CONST_AS double *)Pord;
+    const RT_CONST_AS double *w_c = (const RT_CONST_AS double *)root_w;
+
+    // prologue: fill the ring
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        if (k < K) {
+#pragma unroll
+            for (int j = 0; j < IPS; ++j)
+                __builtin_amdgcn_global_load_lds(
+                    (glb_void *)(g + (size_t)k * SLOT + j * 1024),
+                    (lds_void *)(ring + k * SLOT + j * 1024), 16, 0, 0);
+        }
+    }
+
+    double lik = 0.0;
+    bool negative = false;
+    rt_op op = load_op(ops_c, 0);
+
+    for (int i = 0; i < nops; ++i) {
+        // this step's transition matrix: scalar loads, consumed as FMA operands
+        double p[NN];
+#pragma unroll
+        for (int j = 0; j < NN; ++j) p[j] = P_c[(long)i * NN + j];
+        const int inext = (i + 1 < nops) ? i + 1 : i;
+        const rt_op opn = load_op(ops_c, inext);
+
+        double x[N];
+        if (RT_OP_IS_INTERNAL(op)) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) x[j] = stack[(op.pop * N + j) * 64];
+        } else {
+#pragma unroll
+            for (int j = 0; j < N; ++j) x[j] = 1.0;
+        }
+        if (op.obs >= 0) {
+            const int k = op.obs;
+            if (k + R <= K)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 1) * IPS) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int rs = k % R;
+            const double *o = (const double *)(ring + rs * SLOT) + lane * NP;
+            double ov[NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) ov[j] = o[j];
+#pragma unroll
+            for (int j = 0; j < N; ++j) x[j] *= ov[j];
+            if (k + R < K) {
+#pragma unroll
+                for (int j = 0; j < IPS; ++j)
+                    __builtin_amdgcn_global_load_lds(
+                        (glb_void *)(g + (size_t)(k + R) * SLOT + j * 1024),
+                        (lds_void *)(ring + rs * SLOT + j * 1024), 16, 0, 0);
+            }
+        }
+        if (RT_OP_IS_ROOT(op)) {
+            // root reduction (_mc0_dense.py:184-209)
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                negative |= x[j] < 0.0;
+                s += w_c[j] * fmax(x[j], 0.0);
+            }
+            lik = s;
+        } else {
+            double t[N];
+#pragma unroll
+            for (int r = 0; r < N; ++r) {
+                double s = p[r * N] * x[0];
+#pragma unroll
+                for (int j = 1; j < N; ++j) s = fma(p[r * N + j], x[j], s);
+                t[r] = s;
+            }
+            double *d = stack + (op.dst & 255) * N * 64;
+            if (RT_OP_IS_FIRST(op)) {
+#pragma unroll
+                for (int r = 0; r < N; ++r) d[r * 64] = t[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < N; ++r) d[r * 64] *= t[r];
+            }
+        }
+        op = opn;
+    }
+
+    const long site = gw * 64 + lane;
+    double sum, nzero;
+    finish_site(lik, negative, site < nsites, loglik, status, site, sum, nzero);
+    sum = wave_sum(sum);
+    nzero = wave_sum(nzero);
+    if (lane == 0) {
+        partial[gw * 2] = sum;
+        partial[gw * 2 + 1] = nzero;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 4 < n <= 64: v_mfma_f64_16x16x4_f64
+// ---------------------------------------------------------------------------
+//
+// Register maps (guide: f64 MFMA 16x16x4): A lane l holds A[l&15][l>>4], B lane
+// l holds B[l>>4][l&15], D lane l reg r holds D[(l>>4) + 4r][l&15].
+//
+// A tile of 16 sites is owned by NT waves (NT = ceil(n/16) row tiles); wave m
+// computes rows 16m..16m+15 of t = P_e * x: KS = ceil(n/4) MFMAs with
+// A = its own 16 x 4 slices of P_e (loaded from HBM/L2 straight into registers,
+// one step ahead, in fragment order) and B = x (k-step kk = states 4kk..4kk+3
+// of the 16 sites).  The D registers of wave m are states 16m + 4r + (l>>4),
+// i.e. exactly rows 4m..4m+3 of the B operand of the next edge, so the waves of
+// a tile publish their four rows of x to an LDS exchange buffer (double
+// buffered, one workgroup barrier per step) and keep only their own rows of
+// the pending accumulators (LDS stack, 2 KB per slot per wave).  A workgroup is
+// 4 waves (3 when NT = 3) = 4/NT site tiles; nothing but x crosses waves.
+
+template <int NT, int KS>
+__global__ void __launch_bounds__((NT == 3 ? 3 : 4) * 64)
+prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
+                  const rt_op *__restrict__ ops, int nops,
+                  const double *__restrict__ obs, int K,  // [blk16][K][KP][64][2]
+                  const double *__restrict__ root_w, int n, int depth,
+                  double *__restrict__ loglik, int *__restrict__ status,
+                  double *__restrict__ partial, long nsites, long nblocks16)
+{
+    constexpr int WAVES = (NT == 3) ? 3 : 4;
+    constexpr int TILES = WAVES / NT;
+    constexpr int KP = (KS + 1) / 2;           // k-step pairs
+    constexpr int XB = NT * 4 * 64;            // doubles of one x exchange buffer
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = wave / NT;
+    const int m = wave - tile * NT;
+    const long gt = (long)blockIdx.x * TILES + tile;      // global site tile
+    const bool live = gt < nblocks16;
+    const long blk = live ? gt : nblocks16 - 1;           // keep barriers uniform
+
+    double *xbuf = (double *)smem;                         // [2][TILES][XB]
+    double *red = xbuf + 2 * TILES * XB;                   // [TILES][NT][16]
+    double *stack = red + TILES * NT * 16 +
+                    (size_t)wave * depth * 256 + lane;     // [slot][4][64]
+
+    const RT_CONST_AS int4_t *ops_c = (const RT_CONST_AS int4_t *)ops;
+    // A fragments of this wave: [op][m][q][lane][2]
+    const double *ag = Pfrag + ((size_t)m * KP * 64 + lane) * 2;
+    constexpr size_t ASTRIDE = (size_t)NT * KP * 128;
+    // observation pairs holding this wave's own rows 4m..4m+3: q = 2m, 2m+1
+    const double *og = obs + (size_t)blk * K * (KP * 128) + lane * 2;
+
+    double an[2 * KP];            // A fragments of the NEXT step
+    double on[4];                 // own rows of the next step's observation
+#pragma unroll
+    for (int j = 0; j < 4; ++j) on[j] = 1.0;
+
+    rt_op op = load_op(ops_c, 0);
+#pragma unroll
+    for (int q = 0; q < KP; ++q) {
+        const double2 v = *(const double2 *)(ag + q * 128);
+        an[2 * q] = v.x;
+        an[2 * q + 1] = v.y;
+    }
+    if (op.obs >= 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = 2 * m + h;
+            double2 v = {0.0, 0.0};
+            if (q < KP) v = *(const double2 *)(og + ((size_t)op.obs * KP + q) * 128);
+            on[2 * h] = v.x;
+            on[2 * h + 1] = v.y;
+        }
+    }
+
+    double lik = 0.0;
+    bool negative = false;
+
+    for (int i = 0; i < nops; ++i) {
+        // own rows of L_v = (accumulator of v) * (observation at v)
+        double x[4];
+        if (RT_OP_IS_INTERNAL(op)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = stack[(op.pop * 4 + r) * 64];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = 1.0;
+        }
+        if (op.obs >= 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] *= on[r];
+        }
+        if (RT_OP_IS_ROOT(op)) {
+            double s = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * m + 4 * r + (lane >> 4);
+                const double w = row < n ? root_w[row] : 0.0;
+                negative |= (row < n) && (x[r] < 0.0);
+                s += w * fmax(x[r], 0.0);
+            }
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            if (lane < 16) red[(tile * NT + m) * 16 + lane] = s;
+            __syncthreads();
+            if (m == 0 && lane < 16) {
+                double tot = 0.0;
+#pragma unroll
+                for (int mm = 0; mm < NT; ++mm) tot += red[(tile * NT + mm) * 16 + lane];
+                lik = tot;
+            }
+            break;
+        }
+        double *xb = xbuf + ((i & 1) * TILES + tile) * XB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xb[((4 * m + r) * 64) + lane] = x[r];
+
+        double a[2 * KP];
+#pragma unroll
+        for (int j = 0; j < 2 * KP; ++j) a[j] = an[j];
+
+        __syncthreads();      // x of every wave of the tile is in LDS
+
+        // start everything the next step needs
+        const int inext = (i + 1 < nops) ? i + 1 : i;
+        const rt_op opn = load_op(ops_c, inext);
+        if (!RT_OP_IS_ROOT(opn)) {
+#pragma unroll
+            for (int q = 0; q < KP; ++q) {
+                const double2 v = *(const double2 *)(ag + (size_t)inext * ASTRIDE + q * 128);
+                an[2 * q] = v.x;
+                an[2 * q + 1] = v.y;
+            }
+        }
+        if (opn.obs >= 0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int q = 2 * m + h;
+                double2 v = {0.0, 0.0};
+                if (q < KP) v = *(const double2 *)(og + ((size_t)opn.obs * KP + q) * 128);
+                on[2 * h] = v.x;
+                on[2 * h + 1] = v.y;
+            }
+        }
+
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const double b = xb[kk * 64 + lane];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], b, acc, 0, 0, 0);
+        }
+
+        double *d = stack + (op.dst & 255) * 256;
+        if (RT_OP_IS_FIRST(op)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d[r * 64] = acc[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d[r * 64] *= acc[r];
+        }
+        op = opn;
+    }
+
+    // lanes 0..15 of wave m == 0 own the 16 sites of the tile
+    const long site = blk * 16 + (lane & 15);
+    const bool valid = live && m == 0 && lane < 16 && site < nsites;
+    double sum, nzero;
+    finish_site(lik, negative, valid, loglik, status, site, sum, nzero);
+    sum = wave_sum(sum);
+    nzero = wave_sum(nzero);
+    if (lane == 0) {
+        const long gwv = (long)blockIdx.x * WAVES + wave;
+        partial[gwv * 2] = sum;
+        partial[gwv * 2 + 1] = nzero;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// generic fallback: lane per site, accumulator stack in global scratch
+// ---------------------------------------------------------------------------
+
+template <int NMAX>
+__global__ void __launch_bounds__(64)
+prune_generic_kernel(const double *__restrict__ P,   // [nnodes][n][n]
+                     const rt_op *__restrict__ ops, int nops,
+                     const double *__restrict__ obs, int K, int n, int np,
+                     const double *__restrict__ root_w,
+                     double *__restrict__ loglik, int *__restrict__ status,
+                     double *__restrict__ partial, double *__restrict__ scratch,
+                     long nsp, long nsites)
+{
+    const int lane = threadIdx.x;
+    const long blk = blockIdx.x;
+    const long site = blk * 64 + lane;
+    double lik = 0.0;
+    bool negative = false;
+    for (int i = 0; i < nops; ++i) {
+        const rt_op op = ops[i];
+        double x[NMAX];
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) {
+            x[j] = 1.0;
+            if (j < n) {
+                if (op.pop >= 0) x[j] = scratch[((long)op.pop * n + j) * nsp + site];
+                if (op.obs >= 0)
+                    x[j] *= obs[(((size_t)blk * K + op.obs) * 64 + lane) * np + j];
+            }
+        }
+        if (op.dst < 0) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < NMAX; ++j) {
+                if (j < n) {
+                    negative |= x[j] < 0.0;
+                    s += root_w[j] * fmax(x[j], 0.0);
+                }
+            }
+            lik = s;
+        } else {
+            const int dslot = op.dst & 255;
+            const bool first = (op.dst >> 8) != 0;
+            const double *Pe = P + (long)op.node * n * n;
+            for (int r = 0; r < n; ++r) {
+                double s = 0.0;
+#pragma unroll
+                for (int j = 0; j < NMAX; ++j)
+                    if (j < n) s = fma(Pe[r * n + j], x[j], s);
+                double *d = scratch + ((long)dslot * n + r) * nsp + site;
+                *d = first ? s : *d * s;
+            }
+        }
+    }
+    double sum, nzero;
+    finish_site(lik, negative, site < nsites, loglik, status, site, sum, nzero);
+    sum = wave_sum(sum);
+    nzero = wave_sum(nzero);
+    if (lane == 0) {
+        partial[blk * 2] = sum;
+        partial[blk * 2 + 1] = nzero;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// fixed-order reduction of the per-wave partial sums -> totals[3]
+// ---------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256)
+reduce_partials_kernel(const double *__restrict__ partial, long npartials,
+                       double *__restrict__ totals, double nsites)
+{
+    __shared__ double ssum[256];
+    __shared__ double szero[256];
+    double s = 0.0, z = 0.0;
+    for (long i = threadIdx.x; i < npartials; i += 256) {
+        s += partial[2 * i];
+        z += partial[2 * i + 1];
+    }
+    ssum[threadIdx.x] = s;
+    szero[threadIdx.x] = z;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            ssum[threadIdx.x] += ssum[threadIdx.x + w];
+            szero[threadIdx.x] += szero[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        totals[0] = ssum[0];
+        totals[1] = szero[0];
+        totals[2] = nsites;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// P repack: esd_transitions [node][n][n] -> kernel-native, step-ordered
+// ---------------------------------------------------------------------------
+
+// lane family: Pord[i][r][c] = P[node_i][r][c]
+__global__ void pack_p_lane_kernel(const double *__restrict__ P,
+                                   const rt_op *__restrict__ ops, int nops, int n,
+                                   double *__restrict__ Pord)
+{
+    const int i = blockIdx.x;
+    const rt_op op = ops[i];
+    for (int e = threadIdx.x; e < n * n; e += blockDim.x)
+        Pord[(long)i * n * n + e] = op.dst < 0 ? 0.0 : P[(long)op.node * n * n + e];
+}
+
+// mfma family: Pfrag[i][m][q][lane][e] = P[node_i][16m + (lane&15)][4(2q+e) + (lane>>4)]
+__global__ void pack_p_mfma_kernel(const double *__restrict__ P,
+                                   const rt_op *__restrict__ ops, int nops, int n,
+                                   int NT, int KP, double *__restrict__ Pfrag)
+{
+    const int i = blockIdx.x;
+    const rt_op op = ops[i];
+    const int total = NT * KP * 128;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int e2 = e & 1;
+        const int lane = (e >> 1) & 63;
+        const int q = (e >> 7) % KP;
+        const int m = (e >> 7) / KP;
+        const int row = 16 * m + (lane & 15);
+        const int col = 4 * (2 * q + e2) + (lane >> 4);
+        double v = 0.0;
+        if (op.dst >= 0 && row < n && col < n)
+            v = P[(long)op.node * n * n + row * n + col];
+        Pfrag[(long)i * total + e] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// site packing: user data -> kernel-native HBM layout
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ double obs_value(int kind, const void *data, long site,
+                                            long nobs, long j, int n, int s)
+{
+    if (kind == RT_OBS_DENSE)
+        return ((const double *)data)[((size_t)site * nobs + j) * n + s];
+    if (kind == RT_OBS_STATE) {
+        const unsigned char st = ((const unsigned char *)data)[(size_t)site * nobs + j];
+        return (st == 255 || st == s) ? 1.0 : 0.0;
+    }
+    const unsigned long long m = ((const unsigned long long *)data)[(size_t)site * nobs + j];
+    return ((m >> s) & 1ull) ? 1.0 : 0.0;
+}
+
+// [blk64][k][lane][np]
+__global__ void pack_sites_lane_kernel(int kind, const void *__restrict__ data,
+                                       const int *__restrict__ src_of_k, long nsites,
+                                       long nobs, int K, int n, int np,
+                                       double *__restrict__ out, size_t total)
+{
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (size_t)gridDim.x * blockDim.x) {
+        const int s = e % np;
+        const size_t r = e / np;
+        const int lane = r & 63;
+        const size_t r2 = r >> 6;
+        const int k = r2 % K;
+        const long blk = r2 / K;
+        const long site = blk * 64 + lane;
+        double v;
+        if (s >= n) v = 0.0;
+        else if (site >= nsites) v = 1.0;
+        else v = obs_value(kind, data, site, nobs, src_of_k[k], n, s);
+        out[e] = v;
+    }
+}
+
+// [blk16][k][kkpair][lane][2]: element e2 of pair q is k-step 2q+e2, state
+// 4(2q+e2) + (lane>>4), site blk*16 + (lane&15)
+__global__ void pack_sites_mfma_kernel(int kind, const void *__restrict__ data,
+                                       const int *__restrict__ src_of_k, long nsites,
+                                       long nobs, int K, int n, int KP,
+                                       double *__restrict__ out, size_t total)
+{
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (size_t)gridDim.x * blockDim.x) {
+        const int e2 = e & 1;
+        const int lane = (e >> 1) & 63;
+        const size_t r = e >> 7;
+        const int q = r % KP;
+        const size_t r2 = r / KP;
+        const int k = r2 % K;
+        const long blk = r2 / K;
+        const int s = 4 * (2 * q + e2) + (lane >> 4);
+        const long site = blk * 16 + (lane & 15);
+        double v;
+        if (s >= n) v = 0.0;
+        else if (site >= nsites) v = 1.0;
+        else v = obs_value(kind, data, site, nobs, src_of_k[k], n, s);
+        out[e] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+
+static int ks_of(int64_t n) { return (int)((n + 3) / 4); }
+static int nt_of(int64_t n) { return (int)((n + 15) / 16); }
+
+int rt_launch_pfrag(rt_model *m)
+{
+    if (!m->frag_dirty) return RT_OK;
+    const int nops = (int)m->ops.size();
+    const int n = (int)m->n;
+    hipStream_t st = m->ctx->stream;
+    if (n <= 4) {
+        hipLaunchKernelGGL(pack_p_lane_kernel, dim3(nops), dim3(64), 0, st, m->d_P,
+                           m->d_ops, nops, n, m->d_Pfrag);
+    } else {
+        hipLaunchKernelGGL(pack_p_mfma_kernel, dim3(nops), dim3(256), 0, st, m->d_P,
+                           m->d_ops, nops, n, nt_of(n), (ks_of(n) + 1) / 2, m->d_Pfrag);
+    }
+    RT_HIP(hipGetLastError());
+    m->frag_dirty = false;
+    return RT_OK;
+}
+
+int rt_sites_pack(rt_sites *s, int kind, const int64_t *src_of_k, const void *data)
+{
+    rt_model *m = s->model;
+    hipStream_t st = m->ctx->stream;
+    const int n = (int)m->n;
+    const int K = (int)s->nobs;
+    size_t in_bytes;
+    if (kind == RT_OBS_DENSE) in_bytes = (size_t)s->nsites * K * n * 8;
+    else if (kind == RT_OBS_STATE) in_bytes = (size_t)s->nsites * K;
+    else in_bytes = (size_t)s->nsites * K * 8;
+    void *d_in = nullptr;
+    int *d_src = nullptr;
+    std::vector<int> src(K);
+    for (int k = 0; k < K; ++k) src[k] = (int)src_of_k[k];
+    if (K > 0) {
+        RT_HIP(hipMalloc(&d_in, in_bytes));
+        RT_HIP(hipMalloc((void **)&d_src, sizeof(int) * K));
+        RT_HIP(hipMemcpyAsync(d_in, data, in_bytes, hipMemcpyHostToDevice, st));
+        RT_HIP(hipMemcpyAsync(d_src, src.data(), sizeof(int) * K,
+                              hipMemcpyHostToDevice, st));
+        const size_t total = (size_t)s->obs_bytes / 8;
+        size_t blocks = (total + 255) / 256;
+        if (blocks > 65536) blocks = 65536;
+        if (s->layout == RT_LAYOUT_LANE) {
+            const int np = (n + 1) & ~1;
+            hipLaunchKernelGGL(pack_sites_lane_kernel, dim3((unsigned)blocks), dim3(256),
+                               0, st, kind, d_in, d_src, (long)s->nsites, (long)K, K, n,
+                               np, s->d_obs, total);
+        } else {
+            const int KP = (ks_of(n) + 1) / 2;
+            hipLaunchKernelGGL(pack_sites_mfma_kernel, dim3((unsigned)blocks), dim3(256),
+                               0, st, kind, d_in, d_src, (long)s->nsites, (long)K, K, n,
+                               KP, s->d_obs, total);
+        }
+        RT_HIP(hipGetLastError());
+        RT_HIP(hipStreamSynchronize(st));
+        RT_HIP(hipFree(d_in));
+        RT_HIP(hipFree(d_src));
+    }
+    return RT_OK;
+}
+
+template <int N>
+static int launch_lane(rt_model *m, rt_sites *s, const char **name)
+{
+    constexpr int NP = (N + 1) & ~1;
+    constexpr int SLOT = 64 * NP * 8;
+    static const char *names[5] = {"", "prune_lane<1>", "prune_lane<2>", "prune_lane<3>",
+                                   "prune_lane<4>"};
+    *name = names[N];
+    const int depth = std::max(1, m->max_depth);
+    const int stack_bytes = depth * N * 512;
+    const unsigned grid = (unsigned)s->nblocks;
+    // ring depth: 8 slots in flight when at least 6 waves still fit on a CU,
+    // otherwise 4
+    const bool deep = (8 * SLOT + stack_bytes) * 6 <= 160 * 1024;
+    const int lds = (deep ? 8 : 4) * SLOT + stack_bytes;
+    auto kern = deep ? prune_lane_kernel<N, 8> : prune_lane_kernel<N, 4>;
+    RT_HIP(hipFuncSetAttribute((const void *)kern,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, m->ctx->stream, m->d_Pfrag,
+                       s->d_ops, (int)s->ops.size(), s->d_obs, (int)s->nobs, m->d_root,
+                       s->d_loglik, s->d_status, s->d_partial, (long)s->nsites);
+    return RT_OK;
+}
+
+template <int NT, int KS>
+static int launch_mfma_inst(rt_model *m, rt_sites *s)
+{
+    constexpr int WAVES = (NT == 3) ? 3 : 4;
+    constexpr int TILES = WAVES / NT;
+    const int depth = std::max(1, m->max_depth);
+    const int lds = (2 * TILES * NT * 4 * 64 + TILES * NT * 16) * 8 + WAVES * depth * 2048;
+    const unsigned grid = (unsigned)((s->nblocks + TILES - 1) / TILES);
+    auto kern = prune_mfma_kernel<NT, KS>;
+    RT_HIP(hipFuncSetAttribute((const void *)kern,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, m->ctx->stream,
+                       m->d_Pfrag, s->d_ops, (int)s->ops.size(), s->d_obs,
+                       (int)s->nobs, m->d_root, (int)m->n, depth, s->d_loglik,
+                       s->d_status, s->d_partial, (long)s->nsites, (long)s->nblocks);
+    return RT_OK;
+}
+
+static int launch_mfma(rt_model *m, rt_sites *s, const char **name)
+{
+    static char buf[17][32];
+    const int ks = ks_of(m->n);
+    snprintf(buf[ks], sizeof(buf[ks]), "prune_mfma<%d,%d>", nt_of(m->n), ks);
+    *name = buf[ks];
+    switch (ks) {
+    case 2: return launch_mfma_inst<1, 2>(m, s);
+    case 3: return launch_mfma_inst<1, 3>(m, s);
+    case 4: return launch_mfma_inst<1, 4>(m, s);
+    case 5: return launch_mfma_inst<2, 5>(m, s);
+    case 6: return launch_mfma_inst<2, 6>(m, s);
+    case 7: return launch_mfma_inst<2, 7>(m, s);
+    case 8: return launch_mfma_inst<2, 8>(m, s);
+    case 9: return launch_mfma_inst<3, 9>(m, s);
+    case 10: return launch_mfma_inst<3, 10>(m, s);
+    case 11: return launch_mfma_inst<3, 11>(m, s);
+    case 12: return launch_mfma_inst<3, 12>(m, s);
+    case 13: return launch_mfma_inst<4, 13>(m, s);
+    case 14: return launch_mfma_inst<4, 14>(m, s);
+    case 15: return launch_mfma_inst<4, 15>(m, s);
+    case 16: return launch_mfma_inst<4, 16>(m, s);
+    default: break;
+    }
+    rt_set_error("no MFMA pruning kernel for n=%lld", (long long)m->n);
+    return RT_ERR_UNSUPPORTED;
+}
+
+static int launch_generic(rt_model *m, rt_sites *s, const char **name)
+{
+    const int n = (int)m->n;
+    const int np = (n + 1) & ~1;
+    const long nsp = s->nblocks * 64;
+    const unsigned grid = (unsigned)s->nblocks;
+    hipStream_t st = m->ctx->stream;
+#define RT_GEN(NMAX)                                                               \
+    hipLaunchKernelGGL(prune_generic_kernel<NMAX>, dim3(grid), dim3(64), 0, st,    \
+                       m->d_P, s->d_ops, (int)s->ops.size(), s->d_obs,             \
+                       (int)s->nobs, n, np, m->d_root, s->d_loglik, s->d_status,   \
+                       s->d_partial, s->d_scratch, nsp, (long)s->nsites)
+    if (n <= 8) { *name = "prune_generic<8>"; RT_GEN(8); }
+    else if (n <= 16) { *name = "prune_generic<16>"; RT_GEN(16); }
+    else if (n <= 32) { *name = "prune_generic<32>"; RT_GEN(32); }
+    else { *name = "prune_generic<64>"; RT_GEN(64); }
+#undef RT_GEN
+    return RT_OK;
+}
+
+int rt_launch_prune(rt_model *m, rt_sites *s)
+{
+    rt_ctx *ctx = m->ctx;
+    const char *name = "";
+    hipEvent_t ev = nullptr;
+    // which family this batch was packed for
+    const bool generic = s->d_scratch != nullptr;
+    if (!generic) RT_TRY(rt_launch_pfrag(m));
+    rt_time_begin(ctx, RT_K_PRUNE, "", &ev);
+    int rc;
+    if (generic) rc = launch_generic(m, s, &name);
+    else if (s->layout == RT_LAYOUT_LANE) {
+        switch ((int)m->n) {
+        case 1: rc = launch_lane<1>(m, s, &name); break;
+        case 2: rc = launch_lane<2>(m, s, &name); break;
+        case 3: rc = launch_lane<3>(m, s, &name); break;
+        default: rc = launch_lane<4>(m, s, &name); break;
+        }
+    } else rc = launch_mfma(m, s, &name);
+    if (rc != RT_OK) return rc;
+    RT_HIP(hipGetLastError());
+    ctx->slots[RT_K_PRUNE].name = name;
+    rt_time_end(ctx, RT_K_PRUNE, ev);
+
+    rt_time_begin(ctx, RT_K_REDUCE, "reduce_partials", &ev);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, ctx->stream,
+                       s->d_partial, (long)s->npartials, s->d_totals,
+                       (double)s->nsites);
+    RT_HIP(hipGetLastError());
+    rt_time_end(ctx, RT_K_REDUCE, ev);
+    return RT_OK;
+}

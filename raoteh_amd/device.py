@@ -1,0 +1,343 @@
+"""
+Device-resident objects of the batched hot path (thin wrappers over the C ABI):
+
+    ctx   = get_context()                      one per process / GPU
+    model = TreeModel(T, root, nstates)        tree + schedule on the device
+    model.set_rates(Q_default=Q)               per-edge expm(Q*t) on the device
+    batch = model.upload_sites(obs_nodes, data, kind='dense')
+    loglik, status = model.log_likelihoods(batch)
+    total, nzero = model.total_log_likelihood(batch)
+
+Reference path being replaced: raoteh/sampler/_mjp_dense.py:362-407 called once
+per site (examples/p53/p53.py:88-100).
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import byref, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p
+
+import numpy as np
+
+from . import _lib
+from ._tree import TreeArrays, check_square_dense
+
+__all__ = ['Context', 'get_context', 'TreeModel', 'SiteBatch', 'device_count']
+
+_KINDS = {'dense': _lib.RT_OBS_DENSE, 'state': _lib.RT_OBS_STATE,
+          'mask': _lib.RT_OBS_MASK}
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _ptr(a, ctype):
+    return a.ctypes.data_as(ctypes.POINTER(ctype))
+
+
+def device_count():
+    n = c_int(0)
+    _lib.check(_lib.lib().rt_device_count(byref(n)))
+    return n.value
+
+
+class Context(object):
+    """One HIP stream on one GPU.  Fails loudly without the library or a GPU."""
+
+    def __init__(self, device=0):
+        self._h = c_void_p()
+        _lib.check(_lib.lib().rt_ctx_create(int(device), byref(self._h)))
+        self.device = int(device)
+
+    def close(self):
+        if self._h:
+            _lib.lib().rt_ctx_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _lib.check(_lib.lib().rt_ctx_sync(self._h))
+
+    def set_timing(self, enabled):
+        _lib.check(_lib.lib().rt_ctx_set_timing(self._h, int(bool(enabled))))
+
+    def reset_timing(self):
+        _lib.check(_lib.lib().rt_ctx_reset_timing(self._h))
+
+    def kernel_time(self, kernel):
+        """(total_ms, launches, kernel name) accumulated since the last reset."""
+        ms = c_double(0.0)
+        cnt = c_int64(0)
+        name = c_char_p()
+        _lib.check(_lib.lib().rt_ctx_kernel_time(self._h, int(kernel), byref(ms),
+                                                 byref(cnt), byref(name)))
+        return ms.value, cnt.value, (name.value or b'').decode()
+
+    # ---- reference-shaped, host-pointer entry points ----------------------
+
+    def expm(self, Q, t, q_index=None, return_info=False):
+        """P[b] = expm(Q[q_index[b]] * t[b]); Q is [n,n] or [nq,n,n]."""
+        Q = _f64(Q)
+        if Q.ndim == 2:
+            Q = Q[None]
+        if Q.ndim != 3 or Q.shape[1] != Q.shape[2]:
+            raise ValueError('expected the array to be square')
+        t = np.atleast_1d(_f64(t))
+        n, nq, count = Q.shape[1], Q.shape[0], t.shape[0]
+        P = np.empty((count, n, n), dtype=np.float64)
+        info = np.zeros((count, 2), dtype=np.int32)
+        qi = None if q_index is None else _i64(q_index)
+        _lib.check(_lib.lib().rt_expm(
+            self._h, n, count, _ptr(Q, c_double), nq,
+            None if qi is None else _ptr(qi, c_int64), _ptr(t, c_double),
+            _ptr(P, c_double), _ptr(info, c_int32)))
+        return (P, info) if return_info else P
+
+    def _pass_args(self, indices, indptr, esd, arr):
+        indices, indptr, esd = _i64(indices), _i64(indptr), _f64(esd)
+        nnodes, n = esd.shape[0], esd.shape[1]
+        if arr.ndim == 2:
+            nsites = 1
+        elif arr.ndim == 3:
+            nsites = arr.shape[0]
+        else:
+            raise ValueError('expected [nnodes,n] or [nsites,nnodes,n]')
+        if arr.shape[-2:] != (nnodes, n):
+            raise ValueError('array shape %s does not match (%d, %d)' % (
+                arr.shape, nnodes, n))
+        return indices, indptr, esd, nnodes, n, nsites
+
+    def node_to_pset(self, indices, indptr, esd, state_mask):
+        """In place on state_mask (int64, C-contiguous)."""
+        self._mask_pass('rt_mcy_esd_get_node_to_pset', indices, indptr, esd,
+                        state_mask)
+
+    def node_to_set(self, indices, indptr, esd, state_mask):
+        self._mask_pass('rt_esd_get_node_to_set', indices, indptr, esd,
+                        state_mask)
+
+    def _mask_pass(self, fn, indices, indptr, esd, state_mask):
+        if (state_mask.dtype != np.int64 or
+                not state_mask.flags['C_CONTIGUOUS']):
+            raise ValueError('state_mask must be a C-contiguous int64 array')
+        indices, indptr, esd, nnodes, n, nsites = self._pass_args(
+            indices, indptr, esd, state_mask)
+        _lib.check(getattr(_lib.lib(), fn)(
+            self._h, nnodes, n, nsites, _ptr(indices, c_int64),
+            _ptr(indptr, c_int64), _ptr(esd, c_double),
+            _ptr(state_mask, c_int64)))
+
+    def node_to_pmap(self, indices, indptr, esd, state_mask, out,
+                     obs_likelihood=None):
+        if out.dtype != np.float64 or not out.flags['C_CONTIGUOUS']:
+            raise ValueError('subtree_probability must be C-contiguous f64')
+        state_mask = _i64(state_mask)
+        indices, indptr, esd, nnodes, n, nsites = self._pass_args(
+            indices, indptr, esd, state_mask)
+        if out.shape != state_mask.shape:
+            raise ValueError('shape mismatch')
+        obs = None if obs_likelihood is None else _f64(obs_likelihood)
+        if obs is not None and obs.shape != state_mask.shape:
+            raise ValueError('shape mismatch')
+        _lib.check(_lib.lib().rt_mcy_esd_get_node_to_pmap(
+            self._h, nnodes, n, nsites, _ptr(indices, c_int64),
+            _ptr(indptr, c_int64), _ptr(esd, c_double),
+            _ptr(state_mask, c_int64),
+            None if obs is None else _ptr(obs, c_double), _ptr(out, c_double)))
+
+    # ---- multi-GPU ---------------------------------------------------------
+
+    @staticmethod
+    def comm_unique_id():
+        buf = (ctypes.c_ubyte * 128)()
+        _lib.check(_lib.lib().rt_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, nranks, rank, uid):
+        buf = (ctypes.c_ubyte * 128).from_buffer_copy(uid)
+        _lib.check(_lib.lib().rt_comm_init(self._h, int(nranks), int(rank), buf))
+
+
+_contexts = {}
+
+
+def get_context(device=0):
+    ctx = _contexts.get(device)
+    if ctx is None:
+        ctx = _contexts[device] = Context(device)
+    return ctx
+
+
+class SiteBatch(object):
+    def __init__(self, model, handle, nsites):
+        self.model = model
+        self._h = handle
+        self.nsites = nsites
+
+    def clone(self):
+        h = c_void_p()
+        _lib.check(_lib.lib().rt_sites_clone(self._h, byref(h)))
+        return SiteBatch(self.model, h, self.nsites)
+
+    @property
+    def device_bytes(self):
+        return _lib.lib().rt_sites_device_bytes(self._h)
+
+    def close(self):
+        if self._h:
+            _lib.lib().rt_sites_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class TreeModel(object):
+    """Tree + per-edge transition matrices resident on one GPU."""
+
+    def __init__(self, T, root, nstates, ctx=None):
+        self.ctx = ctx if ctx is not None else get_context()
+        self.tree = T if isinstance(T, TreeArrays) else TreeArrays(T, root)
+        self.nstates = int(nstates)
+        self._h = c_void_p()
+        ta = self.tree
+        _lib.check(_lib.lib().rt_model_create(
+            self.ctx._h, ta.nnodes, self.nstates, _ptr(ta.indices, c_int64),
+            _ptr(ta.indptr, c_int64), byref(self._h)))
+
+    def close(self):
+        if self._h:
+            _lib.lib().rt_model_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def schedule_depth(self):
+        return _lib.lib().rt_model_schedule_depth(self._h)
+
+    def set_rates(self, Q_default=None, Q=None, node_q=None, t=None):
+        """expm(Q*t) for every edge on the device.  Either pass nothing but
+        Q_default (edge 'Q' attributes override it, _mjp_dense.py:355) or the
+        explicit arrays Q [nq,n,n], node_q [nnodes], t [nnodes]."""
+        if Q is None:
+            Q, node_q = self.tree.rate_matrices(self.nstates, Q_default)
+        else:
+            Q = _f64(Q)
+            if Q.ndim == 2:
+                Q = Q[None]
+            if Q.shape[1:] != (self.nstates, self.nstates):
+                raise ValueError('expected the array to be square')
+        if t is None:
+            t = self.tree.branch_lengths()
+        t = _f64(t)
+        nq = _i64(node_q) if node_q is not None else None
+        if t.shape != (self.tree.nnodes,):
+            raise ValueError('t must have one entry per node')
+        _lib.check(_lib.lib().rt_model_set_rates(
+            self._h, _ptr(Q, c_double), Q.shape[0],
+            None if nq is None else _ptr(nq, c_int64), _ptr(t, c_double)))
+
+    def recompute_transitions(self):
+        _lib.check(_lib.lib().rt_model_recompute_transitions(self._h))
+
+    def set_transitions(self, esd):
+        esd = _f64(esd)
+        if esd.shape != (self.tree.nnodes, self.nstates, self.nstates):
+            raise ValueError('esd_transitions has the wrong shape')
+        _lib.check(_lib.lib().rt_model_set_transitions(self._h,
+                                                       _ptr(esd, c_double)))
+
+    def get_transitions(self):
+        esd = np.empty((self.tree.nnodes, self.nstates, self.nstates))
+        _lib.check(_lib.lib().rt_model_get_transitions(self._h,
+                                                       _ptr(esd, c_double)))
+        return esd
+
+    def expm_info(self):
+        info = np.zeros((self.tree.nnodes, 2), dtype=np.int32)
+        _lib.check(_lib.lib().rt_model_get_expm_info(self._h,
+                                                     _ptr(info, c_int32)))
+        return info
+
+    def set_root_distn(self, root_distn=None):
+        if root_distn is None:
+            _lib.check(_lib.lib().rt_model_set_root_distn(self._h, None))
+            return
+        w = _f64(root_distn)
+        if w.shape != (self.nstates,):
+            raise ValueError('root shape mismatch: %s %s' % (
+                (self.nstates,), w.shape))
+        _lib.check(_lib.lib().rt_model_set_root_distn(self._h,
+                                                      _ptr(w, c_double)))
+
+    def upload_sites(self, obs_nodes, data, kind='dense'):
+        """obs_nodes: tree nodes (nx ids) carrying per-site data, in the order
+        of the data's second axis.  data: dense f64[nsites,nobs,n] | state
+        uint8[nsites,nobs] (255 = unobserved) | mask uint64[nsites,nobs]."""
+        code = _KINDS[kind]
+        idx = _i64([self.tree.node_to_index[v] for v in obs_nodes])
+        if kind == 'dense':
+            data = _f64(data)
+            ok = data.ndim == 3 and data.shape[2] == self.nstates
+        elif kind == 'state':
+            data = np.ascontiguousarray(data, dtype=np.uint8)
+            ok = data.ndim == 2
+        else:
+            data = np.ascontiguousarray(data, dtype=np.uint64)
+            ok = data.ndim == 2
+        if not ok or data.shape[1] != len(idx):
+            raise ValueError('observation array has the wrong shape')
+        nsites = data.shape[0]
+        h = c_void_p()
+        _lib.check(_lib.lib().rt_sites_create(
+            self._h, nsites, code, len(idx), _ptr(idx, c_int64),
+            data.ctypes.data_as(c_void_p), byref(h)))
+        return SiteBatch(self, h, nsites)
+
+    def prune(self, batch):
+        """Asynchronous: upward pass + root reduce + batch sum on the device."""
+        _lib.check(_lib.lib().rt_prune(self._h, batch._h))
+
+    def allreduce(self, batch):
+        _lib.check(_lib.lib().rt_allreduce_totals(self.ctx._h, batch._h))
+
+    def fetch_log_likelihoods(self, batch):
+        ll = np.empty(batch.nsites, dtype=np.float64)
+        st = np.empty(batch.nsites, dtype=np.int32)
+        _lib.check(_lib.lib().rt_sites_get_logliks(
+            batch._h, _ptr(ll, c_double), _ptr(st, c_int32)))
+        return ll, st
+
+    def fetch_totals(self, batch):
+        tot = np.zeros(3, dtype=np.float64)
+        _lib.check(_lib.lib().rt_sites_get_totals(batch._h, _ptr(tot, c_double)))
+        return tot
+
+    def log_likelihoods(self, batch):
+        self.prune(batch)
+        return self.fetch_log_likelihoods(batch)
+
+    def total_log_likelihood(self, batch):
+        """(sum of log-likelihoods, number of zero-probability sites); the sum
+        is -inf when any site has zero probability."""
+        self.prune(batch)
+        tot = self.fetch_totals(batch)
+        nzero = int(tot[1])
+        return (-np.inf if nzero else float(tot[0])), nzero

@@ -1,0 +1,532 @@
+"""
+GPU parity tests (run on an MI355X through gpurun): every check goes through the
+C ABI of libraoteh_hip.so and compares with the oracle (oracle/oracle_numpy.py,
+pinned to the reference by tests/test_oracle_golden.py) or directly with the
+golden vectors generated from the reference.
+
+Tolerance: the north star asks for 1e-10 relative on log-likelihood; the tests
+use RTOL_LL = 1e-10 for log-likelihoods and 1e-11..1e-12 where the arithmetic
+is a plain re-ordering of the same f64 sums.  Masks / statuses are bit-exact.
+"""
+import itertools
+import warnings
+
+import networkx as nx
+import numpy as np
+import pytest
+
+from conftest import load_golden, tree_from_edges, config_from_golden
+from oracle import oracle_numpy as orc
+
+pytestmark = pytest.mark.gpu
+
+RTOL_LL = 1e-10
+
+
+@pytest.fixture(scope='module')
+def ra():
+    import raoteh_amd
+    from raoteh_amd import (_mjp_dense, _mcy_dense, _mcx_dense, _mcz, device,
+                            _lib, synth, pyfelscore_compat)
+    class NS(object):
+        pass
+    ns = NS()
+    ns.pkg = raoteh_amd
+    ns.mjp, ns.mcy, ns.mcx, ns.mcz = _mjp_dense, _mcy_dense, _mcx_dense, _mcz
+    ns.device, ns.lib, ns.synth, ns.pyf = device, _lib, synth, pyfelscore_compat
+    ns.ctx = device.get_context()
+    return ns
+
+
+# ---------------------------------------------------------------------------
+# expm
+# ---------------------------------------------------------------------------
+
+def test_expm_matches_scipy_fixture(ra):
+    # reference tests/test_expm.py:20-82 families + model matrices, expected
+    # values = scipy.linalg.expm as called at _mjp_dense.py:24-25
+    fx = load_golden('expm')
+    by_n = {}
+    for row in fx['rows']:
+        by_n.setdefault(len(row['Q']), []).append(row)
+    for n, rows in by_n.items():
+        Q = np.array([r['Q'] for r in rows])
+        t = np.array([r['t'] for r in rows])
+        P, info = ra.ctx.expm(Q, t, return_info=True)
+        for k, r in enumerate(rows):
+            want = np.array(r['P'])
+            # scipy's own documented accuracy is relative to the matrix norm
+            np.testing.assert_allclose(P[k], want, rtol=1e-10,
+                                       atol=1e-14 * max(1.0, np.abs(want).max()),
+                                       err_msg='%s t=%g' % (r['form'], r['t']))
+            assert np.abs(P[k].sum(axis=1) - 1).max() < 1e-12
+            m, s = orc.pade_order_and_squarings(
+                np.abs(np.array(r['Q']) * r['t']).sum(axis=0).max())
+            assert tuple(info[k]) == (m, s)
+
+
+def test_expm_against_own_algorithm_restated(ra):
+    rng = np.random.RandomState(7)
+    for n in (1, 2, 5, 17, 32, 47, 62):
+        Q = rng.exponential(size=(6, n, n))
+        for q in Q:
+            np.fill_diagonal(q, 0)
+            q -= np.diag(q.sum(axis=1))
+        t = np.array([1e-3, 0.02, 0.3, 1.0, 3.0, 11.0])
+        P = ra.ctx.expm(Q, t)
+        for k in range(6):
+            want = orc.expm_pade(Q[k], t[k])
+            np.testing.assert_allclose(P[k], want, rtol=1e-9, atol=1e-13)
+            np.testing.assert_allclose(P[k], orc.custom_expm(Q[k], t[k]),
+                                       rtol=1e-8, atol=1e-13)
+
+
+def test_expm_shared_q_and_errors(ra):
+    Q, _ = ra.synth.hky85()
+    t = np.linspace(0.01, 2.0, 50)
+    P = ra.ctx.expm(Q, t)                     # one Q, many t
+    for k in (0, 17, 49):
+        np.testing.assert_allclose(P[k], orc.custom_expm(Q, t[k]), rtol=1e-11,
+                                   atol=1e-15)
+    np.testing.assert_allclose(ra.mjp.custom_expm(Q, 0.3),
+                               orc.custom_expm(Q, 0.3), rtol=1e-11, atol=1e-15)
+    with pytest.raises(ValueError):
+        ra.mjp.custom_expm(np.zeros((3, 4)), 1.0)
+    with pytest.raises(ValueError):
+        ra.mjp.custom_expm(None, 1.0)
+    with pytest.raises(Exception):
+        ra.ctx.expm(np.zeros((63, 63)), [1.0])     # > RT_MAX_EXPM_STATES
+    out = np.empty((3, 3))
+    Q3 = np.array([[-1., 1, 0], [2, -5, 3], [0, 0, 0]])
+    ra.pyf.get_tolerance_rate_matrix(0.7, Q3, out)
+    np.testing.assert_allclose(out, orc.custom_expm(Q3, 0.7), rtol=1e-11,
+                               atol=1e-16)
+
+
+# ---------------------------------------------------------------------------
+# the three reference-format passes
+# ---------------------------------------------------------------------------
+
+def test_passes_match_reference_golden(ra):
+    fx = load_golden('random_sparse')
+    for c in fx['cases']:
+        n = c['nstates']
+        T = tree_from_edges(c['edges'], nodes=c['nodes'])
+        root = c['root']
+        for na, nb in nx.bfs_edges(T, root):
+            T[na][nb]['P'] = np.array(c['P'][str(nb)])
+        allowed = dict((int(k), set(v)) for k, v in c['allowed'].items())
+        pre, idx, ptr, esd = orc.get_esd_transitions(T, root, n)
+        mask = orc.define_state_mask(allowed, pre, n)
+        ra.pyf.mcy_esd_get_node_to_pset(idx, ptr, esd, mask)
+        for i, v in enumerate(pre):
+            assert set(np.flatnonzero(mask[i])) == set(c['pset'][str(v)])
+        ra.pyf.esd_get_node_to_set(idx, ptr, esd, mask)
+        for i, v in enumerate(pre):
+            assert set(np.flatnonzero(mask[i])) == set(c['set'][str(v)])
+        pmap = np.empty((len(pre), n))
+        ra.pyf.mcy_esd_get_node_to_pmap(idx, ptr, esd, mask, pmap)
+        for i, v in enumerate(pre):
+            np.testing.assert_allclose(pmap[i], c['pmap'][str(v)], rtol=1e-13,
+                                       atol=0)
+        # module-level mirrors
+        pm = ra.mcy.get_node_to_pmap(T, root, n, node_to_allowed_states=allowed)
+        for v in pre:
+            np.testing.assert_allclose(pm[v], c['pmap'][str(v)], rtol=1e-13)
+        distn = np.array(c['root_distn'])
+        if c['zero']:
+            with pytest.raises(ra.pkg.StructuralZeroProb):
+                ra.mcy.get_likelihood(T, root, n, node_to_allowed_states=allowed,
+                                      root_distn=distn)
+        else:
+            lk = ra.mcy.get_likelihood(T, root, n,
+                                       node_to_allowed_states=allowed,
+                                       root_distn=distn)
+            assert lk == pytest.approx(c['likelihood'], rel=1e-13)
+        # type z (_mcz.py:140-163)
+        obs = dict((int(k), dict(enumerate(v))) for k, v in c['obs_lik'].items())
+        nset = dict((int(k), set(v)) for k, v in c['set'].items())
+        pz = ra.mcz.get_node_to_pmap(T, root, n, node_to_state_to_likelihood=obs,
+                                     node_to_set=nset)
+        for v in pre:
+            np.testing.assert_allclose(pz[v], c['pmap_z'][str(v)], rtol=1e-13)
+
+
+def test_passes_batched_over_sites(ra):
+    rng = np.random.RandomState(3)
+    T, root, leaves = ra.synth.random_tree(23, seed=5)
+    n = 6
+    for na, nb in nx.bfs_edges(T, root):
+        P = rng.exponential(size=(n, n)) * (rng.uniform(size=(n, n)) > 0.3)
+        P[np.arange(n), np.arange(n)] += 0.1
+        T[na][nb]['P'] = P / P.sum(axis=1, keepdims=True)
+    pre, idx, ptr, esd = orc.get_esd_transitions(T, root, n)
+    nsites = 37
+    masks = (rng.uniform(size=(nsites, len(pre), n)) > 0.25).astype(np.int64)
+    want = masks.copy()
+    wantp = np.empty(masks.shape)
+    for s in range(nsites):
+        orc.mcy_esd_get_node_to_pset(idx, ptr, esd, want[s])
+        orc.esd_get_node_to_set(idx, ptr, esd, want[s])
+        orc.mcy_esd_get_node_to_pmap(idx, ptr, esd, want[s], out=wantp[s])
+    got = masks.copy()
+    ra.ctx.node_to_pset(idx, ptr, esd, got)
+    ra.ctx.node_to_set(idx, ptr, esd, got)
+    np.testing.assert_array_equal(got, want)
+    gotp = np.empty(masks.shape)
+    ra.ctx.node_to_pmap(idx, ptr, esd, got, gotp)
+    np.testing.assert_allclose(gotp, wantp, rtol=1e-13, atol=0)
+
+
+# ---------------------------------------------------------------------------
+# reference-shaped single-site API
+# ---------------------------------------------------------------------------
+
+def test_rerooting_known_answer(ra):
+    fx = load_golden('test_mjp_rerooting')        # tests/test_mjp.py:91-164
+    T = tree_from_edges(fx['edges'])
+    Q = np.array(fx['Q'])
+    distn = np.array(fx['root_distn'])
+    n = fx['nstates']
+    allowed = dict((v, set(range(n))) for v in T)
+    for k, s in fx['node_to_state'].items():
+        allowed[int(k)] = {s}
+    for r in fx['rootings']:
+        lk = ra.mjp.get_likelihood(T, allowed, r['root'], n, root_distn=distn,
+                                   Q_default=Q)
+        assert lk == pytest.approx(r['likelihood'], rel=1e-11)
+        assert lk == pytest.approx(0.002296828148732273, rel=1e-11)
+    # type-x mirror on the augmented tree
+    T_aug = ra.mjp.get_expm_augmented_tree(T, 0, Q_default=Q)
+    nts = dict((int(k), s) for k, s in fx['node_to_state'].items())
+    lk = ra.mcx.get_likelihood(T_aug, 0, n, node_to_state=nts, root_distn=distn)
+    assert lk == pytest.approx(0.002296828148732273, rel=1e-11)
+
+
+def test_sum_to_one(ra):
+    fx = load_golden('sum_to_one')                # tests/test_mjp.py:52-89
+    T = tree_from_edges(fx['edges'])
+    Q = np.array(fx['Q'])
+    distn = np.array(fx['root_distn'])
+    total = 0.0
+    for assignment, want in zip(fx['assignments'], fx['likelihoods']):
+        allowed = dict((v, {s}) for v, s in enumerate(assignment))
+        lk = ra.mjp.get_likelihood(T, allowed, 0, 3, root_distn=distn,
+                                   Q_default=Q)
+        assert lk == pytest.approx(want, rel=1e-10)
+        total += lk
+    assert total == pytest.approx(1.0, rel=1e-11)
+    # the same 81 assignments as one batch through the fast path
+    obs_nodes = [0, 1, 2, 3]
+    states = np.array(fx['assignments'], dtype=np.uint8)
+    ll, st = ra.mjp.get_log_likelihoods(T, 0, 3, obs_nodes, states, kind='state',
+                                        root_distn=distn, Q_default=Q)
+    assert not st.any()
+    np.testing.assert_allclose(ll, np.log(fx['likelihoods']), rtol=RTOL_LL)
+    assert np.exp(ll).sum() == pytest.approx(1.0, rel=1e-11)
+
+
+def test_kat_four_log_half(ra):
+    fx = load_golden('kat_history')               # tests/test_mc.py:131-150
+    T = tree_from_edges(fx['edges'])
+    P = np.array(fx['P'])
+    allowed = dict((int(k), {v}) for k, v in fx['node_to_state'].items())
+    lk = ra.mcy.get_likelihood(T, 0, 3, node_to_allowed_states=allowed,
+                               root_distn=np.array(fx['root_distn']),
+                               P_default=P)
+    assert np.log(lk) == pytest.approx(4 * np.log(0.5), rel=1e-15)
+
+
+def test_single_node_tree_and_errors(ra):
+    T = nx.Graph()
+    T.add_node(7)
+    Q = np.array([[-1.0, 1.0], [2.0, -2.0]])
+    assert ra.mjp.get_likelihood(T, {7: {0}}, 7, 2, None, Q) == 1
+    lk = ra.mjp.get_likelihood(T, {7: {0, 1}}, 7, 2, np.array([0.25, 0.5]), Q)
+    assert lk == pytest.approx(0.75)
+    with pytest.raises(ra.pkg.StructuralZeroProb):
+        ra.mjp.get_likelihood(T, {7: set()}, 7, 2, None, Q)
+    with pytest.raises(ValueError):
+        ra.mjp.get_likelihood(T, {7: {0}}, 8, 2, None, Q)
+    T2 = nx.Graph()
+    T2.add_edge(0, 1, weight=0.1)
+    with pytest.raises(ValueError):               # no rate matrix at all
+        ra.mjp.get_likelihood(T2, {0: {0}, 1: {0}}, 0, 2, None, None)
+    with pytest.raises(KeyError):                 # _mcy_dense.py:52
+        ra.mjp.get_likelihood(T2, {0: {0}}, 0, 2, None, Q)
+    with pytest.raises(ValueError):               # root shape mismatch
+        ra.mjp.get_likelihood(T2, {0: {0}, 1: {0}}, 0, 2, np.ones(3), Q)
+    # batched API on a single-node tree
+    ll, st = ra.mjp.get_log_likelihoods(T, 7, 2, [7], np.array([[0], [1], [255]],
+                                        dtype=np.uint8), kind='state',
+                                        root_distn=np.array([0.25, 0.5]),
+                                        Q_default=Q)
+    np.testing.assert_allclose(ll, np.log([0.25, 0.5, 0.75]), rtol=1e-15)
+
+
+# ---------------------------------------------------------------------------
+# batched hot path vs golden configs (values computed by the reference)
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize('name', ['c1', 'c2', 'c3', 'c5'])
+def test_config_fixtures_batched(ra, name):
+    fx = load_golden('config_' + name)
+    T, root, n, Q_default, distn, sites = config_from_golden(fx)
+    leaves = fx['leaves']
+    want = np.array(fx['log_likelihoods'])
+    masks = ra.mjp.allowed_states_to_masks(sites, leaves)
+    ll, st = ra.mjp.get_log_likelihoods(T, root, n, leaves, masks, kind='mask',
+                                        root_distn=distn, Q_default=Q_default)
+    assert not st.any()
+    np.testing.assert_allclose(ll, want, rtol=RTOL_LL)
+    dense = np.zeros((len(sites), len(leaves), n))
+    for i, d in enumerate(sites):
+        for k, v in enumerate(leaves):
+            dense[i, k, sorted(d[v])] = 1.0
+    ll2, _ = ra.mjp.get_log_likelihoods(T, root, n, leaves, dense, kind='dense',
+                                        root_distn=distn, Q_default=Q_default)
+    np.testing.assert_array_equal(ll, ll2)
+    if fx['obs_kind'] == 'state':
+        states = np.array(fx['leaf_states'], dtype=np.uint8)
+        ll3, _ = ra.mjp.get_log_likelihoods(T, root, n, leaves, states,
+                                            kind='state', root_distn=distn,
+                                            Q_default=Q_default)
+        np.testing.assert_array_equal(ll, ll3)
+    # single-site reference-shaped call on the first site
+    lk = ra.mjp.get_likelihood(T, sites[0], root, n, root_distn=distn,
+                               Q_default=Q_default)
+    assert np.log(lk) == pytest.approx(want[0], rel=RTOL_LL)
+    # device expm vs the scipy matrices stored in the fixture
+    model = ra.device.TreeModel(T, root, n)
+    model.set_rates(Q_default=Q_default)
+    esd = model.get_transitions()
+    assert not esd[0].any()
+    for k, P in fx['P_scipy'].items():
+        i = model.tree.node_to_index[int(k)]
+        np.testing.assert_allclose(esd[i], np.array(P), rtol=1e-10, atol=1e-15)
+
+
+# ---------------------------------------------------------------------------
+# fast kernels vs the oracle on seeded random inputs
+# ---------------------------------------------------------------------------
+
+def _random_case(ra, rng, n, nnodes, nsites, internal_obs=True, sparse=False):
+    T, root, leaves = ra.synth.random_tree(nnodes, seed=int(rng.randint(1 << 30)),
+                                           max_children=4)
+    ta_nodes = list(T)
+    P = {}
+    for na, nb in nx.bfs_edges(T, root):
+        M = rng.exponential(size=(n, n))
+        if sparse:
+            M *= rng.uniform(size=(n, n)) > 0.4
+            M[np.arange(n), np.arange(n)] += 0.05
+        T[na][nb]['P'] = M / M.sum(axis=1, keepdims=True)
+    obs_nodes = list(leaves)
+    if internal_obs:
+        inner = [v for v in ta_nodes if v not in leaves]
+        obs_nodes += inner[::2]
+    w = rng.uniform(0.0, 1.0, size=n)
+    return T, root, obs_nodes, w
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 4, 5, 8, 13, 16, 20, 33, 48, 61, 64])
+def test_fast_kernels_random_trees(ra, n):
+    rng = np.random.RandomState(100 + n)
+    for nnodes, nsites in ((2, 1), (7, 65), (30, 257), (41, 1000)):
+        T, root, obs_nodes, w = _random_case(ra, rng, n, nnodes, nsites,
+                                             sparse=(nnodes == 30))
+        pre, idx, ptr, esd = orc.get_esd_transitions(T, root, n)
+        oidx = [pre.index(v) for v in obs_nodes]
+        model = ra.device.TreeModel(T, root, n)
+        model.set_transitions(esd)
+        model.set_root_distn(w)
+        # type z: arbitrary likelihoods; a few sites forced to zero probability
+        dense = rng.uniform(0.05, 1.0, size=(nsites, len(obs_nodes), n))
+        dense[rng.uniform(size=dense.shape) < 0.2] = 0.0
+        if nsites > 3:
+            dense[3, 0, :] = 0.0
+        want, wst = orc.batch_log_likelihoods(idx, ptr, esd, oidx, dense, w)
+        batch = model.upload_sites(obs_nodes, dense, kind='dense')
+        ll, st = model.log_likelihoods(batch)
+        np.testing.assert_array_equal(st & 1, wst)
+        ok = wst == 0
+        np.testing.assert_allclose(ll[ok], want[ok], rtol=RTOL_LL)
+        assert np.all(np.isneginf(ll[~ok]))
+        tot = model.fetch_totals(batch)
+        assert tot[1] == (~ok).sum() and tot[2] == nsites
+        assert tot[0] == pytest.approx(want[ok].sum(), rel=1e-11, abs=1e-9)
+        # type y: bit masks
+        if n <= 64:
+            bits = rng.randint(1, 1 << min(n, 30), size=(nsites, len(obs_nodes)))
+            masks = bits.astype(np.uint64)
+            dm = ((masks[..., None] >> np.arange(n, dtype=np.uint64)) & 1
+                  ).astype(np.float64)
+            want, wst = orc.batch_log_likelihoods(idx, ptr, esd, oidx, dm, w)
+            ll, st = model.log_likelihoods(
+                model.upload_sites(obs_nodes, masks, kind='mask'))
+            np.testing.assert_array_equal(st & 1, wst)
+            np.testing.assert_allclose(ll[wst == 0], want[wst == 0], rtol=RTOL_LL)
+        # type x: states with some unobserved
+        states = rng.randint(0, n, size=(nsites, len(obs_nodes))).astype(np.uint8)
+        states[rng.uniform(size=states.shape) < 0.15] = 255
+        dx = np.ones((nsites, len(obs_nodes), n))
+        obs_mask = states != 255
+        dx[obs_mask] = 0.0
+        ii, kk = np.nonzero(obs_mask)
+        dx[ii, kk, states[ii, kk]] = 1.0
+        want, wst = orc.batch_log_likelihoods(idx, ptr, esd, oidx, dx, w)
+        ll, st = model.log_likelihoods(
+            model.upload_sites(obs_nodes, states, kind='state'))
+        np.testing.assert_array_equal(st & 1, wst)
+        np.testing.assert_allclose(ll[wst == 0], want[wst == 0], rtol=RTOL_LL)
+
+
+@pytest.mark.parametrize('n', [4, 20, 61])
+def test_generic_kernel_agrees(ra, n):
+    rng = np.random.RandomState(n)
+    T, root, obs_nodes, w = _random_case(ra, rng, n, 25, 300)
+    pre, idx, ptr, esd = orc.get_esd_transitions(T, root, n)
+    oidx = [pre.index(v) for v in obs_nodes]
+    dense = rng.uniform(0.05, 1.0, size=(300, len(obs_nodes), n))
+    want, _ = orc.batch_log_likelihoods(idx, ptr, esd, oidx, dense, w)
+    model = ra.device.TreeModel(T, root, n)
+    model.set_transitions(esd)
+    model.set_root_distn(w)
+    fast, _ = model.log_likelihoods(model.upload_sites(obs_nodes, dense))
+    ra.lib.check(ra.lib.lib().rt_set_option(b'force_generic', 1))
+    try:
+        gen, _ = model.log_likelihoods(model.upload_sites(obs_nodes, dense))
+        assert ra.ctx.kernel_time(1)[2].startswith('prune_generic')
+    finally:
+        ra.lib.check(ra.lib.lib().rt_set_option(b'force_generic', 0))
+    np.testing.assert_allclose(gen, want, rtol=RTOL_LL)
+    np.testing.assert_allclose(fast, want, rtol=RTOL_LL)
+
+
+def test_deep_caterpillar_and_wide_star(ra):
+    rng = np.random.RandomState(11)
+    n = 4
+    T = nx.Graph()                       # caterpillar: 300 levels deep
+    for i in range(300):
+        T.add_edge(2 * i, 2 * i + 2, weight=0.05)
+        T.add_edge(2 * i, 2 * i + 1, weight=0.08)
+    leaves = [2 * i + 1 for i in range(300)] + [600]
+    Q, pi = ra.synth.hky85()
+    S = nx.Graph()                       # star with 90 leaves
+    for i in range(1, 91):
+        S.add_edge(0, i, weight=0.01 * i)
+    for tree, root, lv in ((T, 0, leaves), (S, 0, list(range(1, 91)))):
+        states = rng.randint(0, n, size=(130, len(lv))).astype(np.uint8)
+        ll, st = ra.mjp.get_log_likelihoods(tree, root, n, lv, states,
+                                            kind='state', root_distn=pi,
+                                            Q_default=Q)
+        pre, idx, ptr, esd = orc.get_expm_augmented_transitions(
+            tree, root, n, Q_default=Q)
+        want, wst = orc.batch_log_likelihoods(
+            idx, ptr, esd, [pre.index(v) for v in lv],
+            ra.synth.one_hot(states, n), pi)
+        np.testing.assert_array_equal(st, wst)
+        np.testing.assert_allclose(ll, want, rtol=RTOL_LL)
+
+
+def test_underflow_is_reported_not_hidden(ra):
+    # the reference never rescales: a likelihood below the
+    # f64 range comes out as zero probability there, and here
+    n = 4
+    T = nx.Graph()
+    for i in range(1, 1400):
+        T.add_edge(0, i, weight=1.0)
+    Q, pi = ra.synth.jukes_cantor(4)
+    states = np.zeros((2, 1399), dtype=np.uint8)
+    states[1, ::2] = 1
+    ll, st = ra.mjp.get_log_likelihoods(T, 0, n, list(range(1, 1400)), states,
+                                        kind='state', root_distn=pi, Q_default=Q)
+    pre, idx, ptr, esd = orc.get_expm_augmented_transitions(T, 0, n, Q_default=Q)
+    want, wst = orc.batch_log_likelihoods(idx, ptr, esd, list(range(1, 1400)),
+                                          ra.synth.one_hot(states, n), pi)
+    np.testing.assert_array_equal(st, wst)
+    assert wst.all() and np.all(np.isneginf(ll))
+
+
+# ---------------------------------------------------------------------------
+# full BASELINE sizes: oracle on everything it can finish in seconds +
+# size-independent properties
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize('name,nsites', [('c2', 100000), ('c3', 10000),
+                                         ('c5', 50000)])
+def test_full_size_configs(ra, name, nsites):
+    cfg = ra.synth.make_config(name, nsites=nsites)
+    T, root, n = cfg['T'], cfg['root'], cfg['nstates']
+    leaves, distn = cfg['leaves'], cfg['root_distn']
+    dense = ra.synth.leaf_likelihoods(cfg)
+    model = ra.device.TreeModel(T, root, n)
+    model.set_rates(Q_default=cfg['Q_default'])
+    model.set_root_distn(distn)
+    batch = model.upload_sites(leaves, dense, kind='dense')
+    ll, st = model.log_likelihoods(batch)
+    tot = model.fetch_totals(batch)
+    assert not st.any() and np.isfinite(ll).all()
+    # oracle (scipy expm + numpy pruning) on the full batch
+    pre, idx, ptr, esd = orc.get_expm_augmented_transitions(
+        T, root, n, Q_default=cfg['Q_default'])
+    oidx = [pre.index(v) for v in leaves]
+    want, _ = orc.batch_log_likelihoods(idx, ptr, esd, oidx, dense, distn)
+    np.testing.assert_allclose(ll, want, rtol=RTOL_LL)
+    assert tot[0] == pytest.approx(want.sum(), rel=RTOL_LL)
+    # properties: the batch sum is the sum of the per-site values; identical
+    # columns give identical values; permuting sites permutes the output
+    assert tot[0] == pytest.approx(ll.sum(), rel=1e-12)
+    perm = np.random.RandomState(0).permutation(nsites)
+    ll2, _ = model.log_likelihoods(model.upload_sites(leaves, dense[perm]))
+    np.testing.assert_array_equal(ll2, ll[perm])
+    # golden sites (values from the reference) are the first sites of the batch
+    fx = load_golden('config_' + name)
+    k = len(fx['log_likelihoods'])
+    np.testing.assert_allclose(ll[:k], fx['log_likelihoods'], rtol=RTOL_LL)
+    # re-running the per-edge expm from the resident rates changes nothing
+    model.recompute_transitions()
+    ll3, _ = model.log_likelihoods(batch)
+    np.testing.assert_array_equal(ll3, ll)
+
+
+def test_reversible_model_rerooting_invariance_full_batch(ra):
+    # reference tests/test_mjp.py:126-137 property at batch scale
+    cfg = ra.synth.make_config('c2', nsites=5000)
+    T, n, leaves = cfg['T'], cfg['nstates'], cfg['leaves']
+    states = cfg['leaf_states'].astype(np.uint8)
+    base = None
+    for root in (0, 5, 126, 64):
+        ll, st = ra.mjp.get_log_likelihoods(
+            T, root, n, leaves, states, kind='state',
+            root_distn=cfg['root_distn'], Q_default=cfg['Q_default'])
+        assert not st.any()
+        if base is None:
+            base = ll
+        else:
+            np.testing.assert_allclose(ll, base, rtol=1e-10)
+
+
+def test_timing_and_clone(ra):
+    cfg = ra.synth.make_config('c2', nsites=2000)
+    model = ra.device.TreeModel(cfg['T'], cfg['root'], cfg['nstates'])
+    model.set_root_distn(cfg['root_distn'])
+    ctx = model.ctx
+    ctx.set_timing(True)
+    ctx.reset_timing()
+    model.set_rates(Q_default=cfg['Q_default'])
+    batch = model.upload_sites(cfg['leaves'], cfg['leaf_states'].astype(np.uint8),
+                               kind='state')
+    twin = batch.clone()
+    for _ in range(3):
+        model.prune(batch)
+        model.prune(twin)
+    a, _ = model.fetch_log_likelihoods(batch)
+    b, _ = model.fetch_log_likelihoods(twin)
+    np.testing.assert_array_equal(a, b)
+    ms, cnt, name = ctx.kernel_time(1)
+    assert cnt == 6 and ms > 0 and name.startswith('prune_lane')
+    ms, cnt, name = ctx.kernel_time(0)
+    assert cnt == 1 and name == 'expm_lds'
+    ctx.set_timing(False)
+    assert batch.device_bytes == 32 * 64 * 64 * 4 * 8

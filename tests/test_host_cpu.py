@@ -1,0 +1,163 @@
+"""
+CPU-side tests of the product's host logic (no GPU, no compute calls):
+* the C-ABI library loads and exports every symbol include/raoteh_hip.h declares
+* the post-order schedule the kernels interpret (rt_build_schedule) is a valid
+  stack program: emulating it in numpy reproduces the oracle's likelihoods
+* tree marshalling matches the oracle's restatement of the reference layout
+* the product package never imports the oracle
+"""
+import ctypes
+import os
+import re
+
+import networkx as nx
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden, tree_from_edges
+from oracle import oracle_numpy as orc
+from raoteh_amd import _lib, synth
+from raoteh_amd._tree import TreeArrays
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, 'include', 'raoteh_hip.h')).read()
+    header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+    declared = set(re.findall(r'\b(rt_[a-z0-9_]+)\s*\(', header))
+    assert len(declared) >= 30
+    L = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    assert declared == set(_lib.SIGNATURES), (
+        declared.symmetric_difference(set(_lib.SIGNATURES)))
+    assert L.rt_version() >= 100
+
+
+def test_no_gpu_fails_loudly():
+    L = _lib.lib()
+    n = ctypes.c_int(0)
+    rc = L.rt_device_count(ctypes.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip('a GPU is present')
+    h = ctypes.c_void_p()
+    assert L.rt_ctx_create(0, ctypes.byref(h)) < 0
+    from raoteh_amd.device import Context
+    with pytest.raises(Exception):
+        Context(0)
+
+
+def build_schedule(indices, indptr):
+    L = _lib.lib()
+    nnodes = len(indptr) - 1
+    ops = np.zeros((nnodes, 4), dtype=np.int32)
+    depth = ctypes.c_int32(0)
+    idx = np.ascontiguousarray(indices, dtype=np.int64)
+    ptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    rc = L.rt_build_schedule(
+        nnodes, idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+        ptr.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+        ops.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), ctypes.byref(depth))
+    assert rc == 0, _lib.last_error()
+    return ops, depth.value
+
+
+def emulate(ops, depth, esd, obs_nodes, obs, root_w):
+    """What the kernels do with the schedule, in numpy (all sites at once)."""
+    nsites, n = obs.shape[0], esd.shape[1]
+    slot_of = dict((int(v), k) for k, v in enumerate(obs_nodes))
+    stack = [None] * max(depth, 1)
+    lik = None
+    for node, _, pop, dst in ops:
+        x = np.ones((nsites, n))
+        if pop >= 0:
+            assert stack[pop] is not None
+            x = stack[pop]
+            stack[pop] = None
+        if node in slot_of:
+            x = x * obs[:, slot_of[node], :]
+        if dst < 0:
+            lik = np.maximum(x, 0) @ root_w
+            break
+        t = x @ esd[node].T
+        slot, first = dst & 255, dst >> 8
+        if first:
+            assert stack[slot] is None
+            stack[slot] = t
+        else:
+            stack[slot] = stack[slot] * t
+    assert all(s is None for s in stack)
+    return lik
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_schedule_is_a_valid_stack_program(seed):
+    rng = np.random.RandomState(seed)
+    if seed == 0:
+        T, root, leaves = synth.balanced_tree(64, seed=0)
+    elif seed == 1:   # caterpillar: deep tree, shallow stack
+        T = nx.Graph()
+        for i in range(40):
+            T.add_edge(2 * i, 2 * i + 2, weight=0.1)
+            T.add_edge(2 * i, 2 * i + 1, weight=0.2)
+        root, leaves = 0, [2 * i + 1 for i in range(40)] + [80]
+    else:
+        T, root, leaves = synth.random_tree(int(rng.randint(2, 40)), seed=seed,
+                                            max_children=4)
+    n = int(rng.randint(2, 7))
+    ta = TreeArrays(T, root)
+    pre, idx, ptr = orc.tree_to_arrays(T, root)
+    assert pre == ta.preorder_nodes
+    np.testing.assert_array_equal(idx, ta.indices)
+    np.testing.assert_array_equal(ptr, ta.indptr)
+    ops, depth = build_schedule(ta.indices, ta.indptr)
+    nleaves = sum(1 for v in T if T.degree(v) <= 1 or
+                  (v != root and T.degree(v) == 1))
+    assert depth <= int(np.floor(np.log2(max(nleaves, 1)))) + 2
+    if seed == 0:
+        assert depth == 6
+    if seed == 1:
+        assert depth <= 2
+    assert sorted(ops[:, 0].tolist()) == list(range(ta.nnodes))   # every node once
+    assert ops[-1, 0] == 0 and ops[-1, 3] < 0                      # root last
+    esd = rng.uniform(0.0, 1.0, size=(ta.nnodes, n, n))
+    esd[0] = 0
+    obs_nodes = [ta.node_to_index[v] for v in leaves]
+    obs = rng.uniform(0.1, 1.0, size=(5, len(obs_nodes), n))
+    w = rng.uniform(0.1, 1.0, size=n)
+    want, _ = orc.batch_upward(ta.indices, ta.indptr, esd, obs_nodes, obs, w)
+    got = emulate(ops, depth, esd, obs_nodes, obs, w)
+    np.testing.assert_allclose(got, want, rtol=1e-13)
+
+
+def test_single_node_schedule():
+    ops, depth = build_schedule(np.zeros(0, dtype=np.int64),
+                                np.array([0, 0], dtype=np.int64))
+    assert ops.tolist() == [[0, -1, -1, -1]] and depth == 0
+
+
+def test_marshal_rate_matrices_and_esd():
+    fx = load_golden('config_c5')
+    T = tree_from_edges(fx['edges'])
+    for na, nb in nx.bfs_edges(T, fx['root']):
+        T[na][nb]['Q'] = np.array(fx['Q_edges'][str(nb)])
+    ta = TreeArrays(T, fx['root'])
+    Q, node_q = ta.rate_matrices(fx['nstates'])
+    assert Q.shape == (ta.nnodes - 1, 20, 20)
+    for i in range(1, ta.nnodes):
+        np.testing.assert_array_equal(
+            Q[node_q[i]], np.array(fx['Q_edges'][str(ta.preorder_nodes[i])]))
+    with pytest.raises(ValueError):
+        TreeArrays(T, 12345)
+    T2 = tree_from_edges(fx['edges'])
+    with pytest.raises(ValueError):          # no Q anywhere
+        TreeArrays(T2, fx['root']).rate_matrices(20, None)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'raoteh_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', text, re.M), f
+                assert 'oracle_numpy' not in text, f
