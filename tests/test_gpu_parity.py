@@ -480,10 +480,18 @@ def test_full_size_configs(ra, name, nsites):
     perm = np.random.RandomState(0).permutation(nsites)
     ll2, _ = model.log_likelihoods(model.upload_sites(leaves, dense[perm]))
     np.testing.assert_array_equal(ll2, ll[perm])
-    # golden sites (values from the reference) are the first sites of the batch
+    # the golden sites (values computed by the reference) appended to a slice
+    # of this batch come out the same as in their own small batch
     fx = load_golden('config_' + name)
-    k = len(fx['log_likelihoods'])
-    np.testing.assert_allclose(ll[:k], fx['log_likelihoods'], rtol=RTOL_LL)
+    _, _, _, _, _, gsites = config_from_golden(fx)
+    gd = np.zeros((len(gsites), len(leaves), n))
+    for i, d in enumerate(gsites):
+        for k, v in enumerate(fx['leaves']):
+            gd[i, k, sorted(d[v])] = 1.0
+    mixed = np.concatenate([dense[:1000], gd])
+    ll4, _ = model.log_likelihoods(model.upload_sites(leaves, mixed))
+    np.testing.assert_allclose(ll4[1000:], fx['log_likelihoods'], rtol=RTOL_LL)
+    np.testing.assert_array_equal(ll4[:1000], ll[:1000])
     # re-running the per-edge expm from the resident rates changes nothing
     model.recompute_transitions()
     ll3, _ = model.log_likelihoods(batch)
