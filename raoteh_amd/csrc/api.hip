@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 // ---- errors ----------------------------------------------------------------------
 
@@ -517,10 +518,45 @@ extern "C" int rt_sites_destroy(rt_sites *s)
     if (!s) return RT_OK;
     hipSetDevice(s->model->ctx->device);
     hipStreamSynchronize(s->model->ctx->stream);
-    hipFree(s->d_ops); hipFree(s->d_obs); hipFree(s->d_loglik); hipFree(s->d_status);
+    hipFree(s->d_ops); hipFree(s->d_lane_ops); hipFree(s->d_obs); hipFree(s->d_loglik); hipFree(s->d_status);
     hipFree(s->d_partial); hipFree(s->d_totals); hipFree(s->d_scratch);
     delete s;
     return RT_OK;
+}
+
+// Lane-kernel program: simulate the register cache of the top accumulator and
+// turn slots into LDS byte offsets (see LOP_* in prune.hip).
+static std::vector<int32_t> lane_program(const rt_sites *s)
+{
+    enum { INTERNAL = 1, X_CUR = 2, FIRST = 4, ROOT = 8, SPILL = 16, DST_CUR = 32, OBS = 64 };
+    const int64_t n = s->model->n;
+    std::vector<int32_t> prog(s->ops.size() * 4, 0);
+    int cur = -1;                              // slot cached in registers
+    for (size_t k = 0; k < s->ops.size(); ++k) {
+        const rt_op &op = s->ops[k];
+        int flags = 0, pop_off = 0, dst_off = 0, spill_off = 0;
+        if (op.obs >= 0) flags |= OBS;
+        if (op.pop >= 0) {
+            flags |= INTERNAL;
+            if (cur == op.pop) { flags |= X_CUR; cur = -1; }
+            else pop_off = (int)(op.pop * n * 512);
+        }
+        if (op.dst < 0) flags |= ROOT;
+        else {
+            const int d = op.dst & 255;
+            if (op.dst >> 8) {
+                flags |= FIRST;
+                if (cur >= 0) { flags |= SPILL; spill_off = (int)(cur * n * 512); }
+                cur = d;
+            } else if (cur == d) flags |= DST_CUR;
+            else dst_off = (int)(d * n * 512);
+        }
+        prog[4 * k] = flags;
+        prog[4 * k + 1] = pop_off;
+        prog[4 * k + 2] = dst_off;
+        prog[4 * k + 3] = spill_off;
+    }
+    return prog;
 }
 
 static int sites_alloc(rt_sites *s, bool generic)
@@ -559,6 +595,12 @@ static int sites_alloc(rt_sites *s, bool generic)
     if (e == hipSuccess)
         e = hipMemcpy(s->d_ops, s->ops.data(), s->ops.size() * sizeof(rt_op),
                       hipMemcpyHostToDevice);
+    if (e == hipSuccess && s->layout == RT_LAYOUT_LANE && !generic) {
+        const std::vector<int32_t> prog = lane_program(s);
+        e = hipMalloc((void **)&s->d_lane_ops, prog.size() * 4);
+        if (e == hipSuccess)
+            e = hipMemcpy(s->d_lane_ops, prog.data(), prog.size() * 4, hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) {
         rt_set_error("rt_sites: %s", hipGetErrorString(e));
         return e == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_HIP;
@@ -607,6 +649,10 @@ extern "C" int rt_sites_create(rt_model *m, int64_t nsites, int kind, int64_t no
     }
     const bool generic = g_force_generic || m->max_depth > RT_FAST_MAX_DEPTH;
     s->layout = (generic || m->n <= 4) ? RT_LAYOUT_LANE : RT_LAYOUT_MFMA;
+    // tuning knobs of the lane family (A/B measurements)
+    if (const char *v = getenv("RAOTEH_LANE_VARIANT")) s->lane_dma = strcmp(v, "dma") == 0;
+    if (const char *r = getenv("RAOTEH_LANE_RING")) s->lane_ring = atoi(r);
+    else s->lane_ring = s->lane_dma ? 5 : 8;
     int rc = sites_alloc(s, generic);
     if (rc == RT_OK) rc = rt_sites_pack(s, kind, src_of_k.data(), data);
     if (rc != RT_OK) {
@@ -628,6 +674,8 @@ extern "C" int rt_sites_clone(rt_sites *src, rt_sites **out)
     s->nsites = src->nsites;
     s->nobs = src->nobs;
     s->layout = src->layout;
+    s->lane_dma = src->lane_dma;
+    s->lane_ring = src->lane_ring;
     s->node_obs = src->node_obs;
     s->ops = src->ops;
     int rc = sites_alloc(s, src->d_scratch != nullptr);

@@ -107,11 +107,14 @@ struct rt_sites {
     int64_t nsites = 0;
     int64_t nobs = 0;
     int layout = RT_LAYOUT_LANE;
+    bool lane_dma = false;          // lane family: LDS-DMA ring instead of VGPR ring
+    int lane_ring = 8;              // ring depth of the lane kernel
     int64_t nblocks = 0;            // site blocks (64 or 16 sites each)
     int64_t obs_bytes = 0;
     std::vector<int32_t> node_obs;  // per node: stream position or -1
     std::vector<rt_op> ops;         // model ops with .obs filled in
     rt_op *d_ops = nullptr;
+    int32_t *d_lane_ops = nullptr;  // lane-kernel program (int32[nops][4])
     double *d_obs = nullptr;
     double *d_loglik = nullptr;     // [nblocks * sites per block]
     int32_t *d_status = nullptr;

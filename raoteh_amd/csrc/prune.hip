@@ -28,6 +28,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
@@ -90,12 +91,243 @@ __device__ __forceinline__ void finish_site(double lik, bool negative,
 #define RT_OP_IS_FIRST(op) (((op).dst >> 8) != 0)
 
 // ---------------------------------------------------------------------------
-// n <= 4: one wave per workgroup, lane per site, LDS-DMA ring, scalar-cache P
+// n <= 4: one wave per workgroup, lane per site
+// ---------------------------------------------------------------------------
+//
+// HBM -> VGPR streaming, no LDS staging: the observation stream of a wave (the
+// leaf vectors of its 64 sites, in schedule order) is consumed strictly in
+// order whatever the tree shape, so the kernel is an outer loop over the
+// stream, unrolled R times, with a register ring of R slots whose indices are
+// all static; between two stream elements an inner loop runs the steps that
+// carry no observation (internal nodes).  Each slot is NP/2 fully coalesced
+// 16-byte loads per lane (layout [block][slot][pair][lane][2]), R - 1 slots
+// ((R - 1) * NP * 512 B per wave) stay in flight, and the compiler's own
+// counted vmcnt waits retire them in order.  P_e arrives through the scalar
+// cache as FMA operands; pending accumulators sit in a conflict-free LDS stack
+// ([slot][state][lane], 512*N bytes per slot).
+
+// Lane-kernel step encoding (built on the host by rt_lane_program, api.hip).
+// The top accumulator is cached in registers ("cur"); the host simulates that
+// cache and tells every step where its operands live:
+//   x = flags & LOP_INTERNAL ? (flags & LOP_X_CUR ? cur : lds[pop_off]) : 1
+//   t = P * (x * obs)
+//   FIRST: (SPILL ? lds[spill_off] = cur : -) ; cur = t
+//   else : DST_CUR ? cur *= t : lds[dst_off] *= t
+// In a cherry (two leaves + parent) nothing touches LDS at all.
+enum {
+    LOP_INTERNAL = 1, LOP_X_CUR = 2, LOP_FIRST = 4, LOP_ROOT = 8, LOP_SPILL = 16,
+    LOP_DST_CUR = 32, LOP_OBS = 64
+};
+
+template <int N, bool PLDS>
+struct LaneCtx {
+    const RT_CONST_AS int4_t *ops_c;
+    const RT_CONST_AS double *P_c;       // step-ordered P through the scalar cache
+    const double *P_l;                   // ... or the copy of it in LDS (PLDS)
+    const RT_CONST_AS double *w_c;
+    unsigned char *stack;          // LDS, + lane * 8 bytes
+    int nops;
+    int i;                         // index of the current step
+    int4_t op;                     // current step: {flags, pop_off, dst_off, spill_off}
+    double p[N * N];               // its transition matrix (SGPRs)
+    double cur[N];                 // register-cached top accumulator
+    double lik;
+    bool negative;
+
+    __device__ __forceinline__ void load_current()
+    {
+        const int ii = i < nops ? i : nops - 1;
+        op = ops_c[ii];
+        if (PLDS) {
+            // wave-uniform address: every ds_read is a broadcast
+#pragma unroll
+            for (int j = 0; j < N * N; ++j) p[j] = P_l[ii * N * N + j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < N * N; ++j) p[j] = P_c[(long)ii * N * N + j];
+        }
+    }
+
+    __device__ __forceinline__ double lds_get(int off, int j) const
+    {
+        return *(const double *)(stack + off + j * 512);
+    }
+    __device__ __forceinline__ void lds_put(int off, int j, double v)
+    {
+        *(double *)(stack + off + j * 512) = v;
+    }
+
+    // Execute the current step with observation vector o (ignored unless
+    // HAS_OBS) and move to the next step.
+    template <bool HAS_OBS>
+    __device__ __forceinline__ void step(const double (&o)[N])
+    {
+        const int flags = op.x;
+        double x[N];
+        if (flags & LOP_INTERNAL) {
+            if (flags & LOP_X_CUR) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) x[j] = cur[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < N; ++j) x[j] = lds_get(op.y, j);
+            }
+            if (HAS_OBS) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) x[j] *= o[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < N; ++j) x[j] = HAS_OBS ? o[j] : 1.0;
+        }
+        if (flags & LOP_ROOT) {
+            // root reduction (_mc0_dense.py:184-209)
+            double sacc = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                negative |= x[j] < 0.0;
+                sacc += w_c[j] * fmax(x[j], 0.0);
+            }
+            lik = sacc;
+        } else {
+            double t[N];
+#pragma unroll
+            for (int r = 0; r < N; ++r) {
+                double sacc = p[r * N] * x[0];
+#pragma unroll
+                for (int j = 1; j < N; ++j) sacc = fma(p[r * N + j], x[j], sacc);
+                t[r] = sacc;
+            }
+            if (flags & LOP_FIRST) {
+                if (flags & LOP_SPILL) {
+#pragma unroll
+                    for (int r = 0; r < N; ++r) lds_put(op.w, r, cur[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < N; ++r) cur[r] = t[r];
+            } else if (flags & LOP_DST_CUR) {
+#pragma unroll
+                for (int r = 0; r < N; ++r) cur[r] *= t[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < N; ++r) lds_put(op.z, r, lds_get(op.z, r) * t[r]);
+            }
+        }
+        // fetch the next step (single SGPR buffer: the FMAs above have already
+        // read p when these scalar loads are issued)
+        i += 1;
+        load_current();
+    }
+
+    // run the steps that carry no observation
+    __device__ __forceinline__ void run_plain()
+    {
+        const double none[N] = {};
+        while (i < nops && !(op.x & LOP_OBS)) step<false>(none);
+    }
+};
+
+// PLDS = true: four waves per workgroup share one copy of the whole step-ordered
+// P table in LDS (one barrier at kernel start, none afterwards); the scalar
+// cache cannot hold P for a 64-leaf tree (16 KB + schedule), and an L2 round
+// trip per step is what the wave then waits for.  PLDS = false: one wave per
+// workgroup, P through the scalar cache (trees whose P table does not fit LDS).
+template <int N, int R, bool PLDS>
+__global__ void __launch_bounds__(PLDS ? 256 : 64)
+prune_lane_kernel(const double *__restrict__ Pord,   // [nops][N][N]
+                  const int4_t *__restrict__ ops, int nops,   // lane program
+                  const double *__restrict__ obs, int K,  // [blk][K][NP/2][64][2]
+                  const double *__restrict__ root_w, int depth,
+                  double *__restrict__ loglik, int *__restrict__ status,
+                  double *__restrict__ partial, long nsites, long nblocks)
+{
+    constexpr int NP = (N + 1) & ~1;
+    constexpr int HP = NP / 2;                // 16-byte pairs per site
+    constexpr int WPB = PLDS ? 4 : 1;         // waves per workgroup
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long gw = (long)blockIdx.x * WPB + wave;    // site block of this wave
+
+    LaneCtx<N, PLDS> C;
+    unsigned char *stack_base = smem;
+    if (PLDS) {
+        double *pl = (double *)smem;
+        for (int e = threadIdx.x; e < nops * N * N; e += 256) pl[e] = Pord[e];
+        stack_base = smem + (((size_t)nops * N * N * 8 + 15) & ~(size_t)15);
+        __syncthreads();
+        if (gw >= nblocks) return;            // wave-uniform, after the only barrier
+        C.P_l = pl;
+    } else {
+        C.P_l = nullptr;
+    }
+    const double2 *g = (const double2 *)obs + (size_t)gw * K * HP * 64 + lane;
+    C.ops_c = (const RT_CONST_AS int4_t *)ops;
+    C.P_c = (const RT_CONST_AS double *)Pord;
+    C.w_c = (const RT_CONST_AS double *)root_w;
+    C.stack = stack_base + (size_t)wave * depth * N * 512 + lane * 8;
+    C.nops = nops;
+    C.i = 0;
+    C.lik = 0.0;
+    C.negative = false;
+#pragma unroll
+    for (int j = 0; j < N; ++j) C.cur[j] = 1.0;
+
+    // prologue: R slots in flight
+    double2 ring[R][HP];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+#pragma unroll
+        for (int h = 0; h < HP; ++h) ring[j][h] = make_double2(1.0, 1.0);
+        if (j < K) {
+#pragma unroll
+            for (int h = 0; h < HP; ++h) ring[j][h] = g[((size_t)j * HP + h) * 64];
+        }
+    }
+
+    C.load_current();
+    C.run_plain();
+    for (int k0 = 0; k0 < K; k0 += R) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int k = k0 + j;
+            if (k < K) {              // wave-uniform; the current step consumes slot k
+                double o[N];
+#pragma unroll
+                for (int q = 0; q < N; ++q)
+                    o[q] = (q & 1) ? ring[j][q >> 1].y : ring[j][q >> 1].x;
+                C.template step<true>(o);
+                if (k + R < K) {
+#pragma unroll
+                    for (int h = 0; h < HP; ++h)
+                        ring[j][h] = g[((size_t)(k + R) * HP + h) * 64];
+                }
+                C.run_plain();
+            }
+        }
+    }
+
+    const long site = gw * 64 + lane;
+    double sum, nzero;
+    finish_site(C.lik, C.negative, site < nsites, loglik, status, site, sum, nzero);
+    sum = wave_sum(sum);
+    nzero = wave_sum(nzero);
+    if (lane == 0) {
+        partial[gw * 2] = sum;
+        partial[gw * 2 + 1] = nzero;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// n <= 4, variant B: the same walk with the leaf vectors staged through an
+// LDS-DMA ring (global_load_lds, 1 KiB per wave-instruction, data layout
+// [block][slot][lane][np]).  Kept for A/B measurements (RAOTEH_LANE_VARIANT=dma).
 // ---------------------------------------------------------------------------
 
 template <int N, int R>
 __global__ void __launch_bounds__(64)
-prune_lane_kernel(const double *__restrict__ Pord,   // [nops][N][N]
+prune_lanedma_kernel(const double *__restrict__ Pord,   // [nops][N][N]
                   const rt_op *__restrict__ ops, int nops,
                   const double *__restrict__ obs, int K,
                   const double *__restrict__ root_w,
@@ -541,18 +773,30 @@ __device__ __forceinline__ double obs_value(int kind, const void *data, long sit
     return ((m >> s) & 1ull) ? 1.0 : 0.0;
 }
 
+// lane family: [blk64][k][pair][lane][2]; the generic fallback keeps the simpler
 // [blk64][k][lane][np]
 __global__ void pack_sites_lane_kernel(int kind, const void *__restrict__ data,
                                        const int *__restrict__ src_of_k, long nsites,
-                                       long nobs, int K, int n, int np,
+                                       long nobs, int K, int n, int np, int paired,
                                        double *__restrict__ out, size_t total)
 {
+    const int hp = np / 2;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (size_t)gridDim.x * blockDim.x) {
-        const int s = e % np;
-        const size_t r = e / np;
-        const int lane = r & 63;
-        const size_t r2 = r >> 6;
+        int s, lane;
+        size_t r2;
+        if (paired) {
+            const int e2 = e & 1;
+            lane = (e >> 1) & 63;
+            const size_t r = e >> 7;
+            s = 2 * (int)(r % hp) + e2;
+            r2 = r / hp;
+        } else {
+            s = e % np;
+            const size_t r = e / np;
+            lane = r & 63;
+            r2 = r >> 6;
+        }
         const int k = r2 % K;
         const long blk = r2 / K;
         const long site = blk * 64 + lane;
@@ -640,9 +884,10 @@ int rt_sites_pack(rt_sites *s, int kind, const int64_t *src_of_k, const void *da
         if (blocks > 65536) blocks = 65536;
         if (s->layout == RT_LAYOUT_LANE) {
             const int np = (n + 1) & ~1;
+            const int paired = s->d_scratch == nullptr && !s->lane_dma;
             hipLaunchKernelGGL(pack_sites_lane_kernel, dim3((unsigned)blocks), dim3(256),
                                0, st, kind, d_in, d_src, (long)s->nsites, (long)K, K, n,
-                               np, s->d_obs, total);
+                               np, paired, s->d_obs, total);
         } else {
             const int KP = (ks_of(n) + 1) / 2;
             hipLaunchKernelGGL(pack_sites_mfma_kernel, dim3((unsigned)blocks), dim3(256),
@@ -657,28 +902,79 @@ int rt_sites_pack(rt_sites *s, int kind, const int64_t *src_of_k, const void *da
     return RT_OK;
 }
 
+template <int N, int R>
+static int launch_lane_reg(rt_model *m, rt_sites *s, bool *plds_out)
+{
+    const int depth = std::max(1, m->max_depth);
+    const int nops = (int)s->ops.size();
+    const int stack = depth * N * 512;                        // per wave
+    const int ptab = (nops * N * N * 8 + 15) & ~15;
+    // P table in LDS when two 4-wave workgroups still fit on a CU
+    const bool plds = ptab + 4 * stack <= 80 * 1024 && !getenv("RAOTEH_LANE_NO_PLDS");
+    *plds_out = plds;
+    if (plds) {
+        const int lds = ptab + 4 * stack;
+        auto kern = prune_lane_kernel<N, R, true>;
+        RT_HIP(hipFuncSetAttribute((const void *)kern,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)((s->nblocks + 3) / 4)), dim3(256), lds,
+                           m->ctx->stream, m->d_Pfrag, (const int4_t *)s->d_lane_ops, nops,
+                           s->d_obs, (int)s->nobs, m->d_root, depth, s->d_loglik,
+                           s->d_status, s->d_partial, (long)s->nsites, (long)s->nblocks);
+    } else {
+        auto kern = prune_lane_kernel<N, R, false>;
+        RT_HIP(hipFuncSetAttribute((const void *)kern,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, stack));
+        hipLaunchKernelGGL(kern, dim3((unsigned)s->nblocks), dim3(64), stack,
+                           m->ctx->stream, m->d_Pfrag, (const int4_t *)s->d_lane_ops, nops,
+                           s->d_obs, (int)s->nobs, m->d_root, depth, s->d_loglik,
+                           s->d_status, s->d_partial, (long)s->nsites, (long)s->nblocks);
+    }
+    return RT_OK;
+}
+
+template <int N, int R>
+static int launch_lane_dma(rt_model *m, rt_sites *s)
+{
+    constexpr int NP = (N + 1) & ~1;
+    const int depth = std::max(1, m->max_depth);
+    const int lds = R * 64 * NP * 8 + depth * N * 512;
+    auto kern = prune_lanedma_kernel<N, R>;
+    RT_HIP(hipFuncSetAttribute((const void *)kern,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)s->nblocks), dim3(64), lds, m->ctx->stream,
+                       m->d_Pfrag, s->d_ops, (int)s->ops.size(), s->d_obs, (int)s->nobs,
+                       m->d_root, s->d_loglik, s->d_status, s->d_partial,
+                       (long)s->nsites);
+    return RT_OK;
+}
+
 template <int N>
 static int launch_lane(rt_model *m, rt_sites *s, const char **name)
 {
-    constexpr int NP = (N + 1) & ~1;
-    constexpr int SLOT = 64 * NP * 8;
-    static const char *names[5] = {"", "prune_lane<1>", "prune_lane<2>", "prune_lane<3>",
-                                   "prune_lane<4>"};
-    *name = names[N];
-    const int depth = std::max(1, m->max_depth);
-    const int stack_bytes = depth * N * 512;
-    const unsigned grid = (unsigned)s->nblocks;
-    // ring depth: 8 slots in flight when at least 6 waves still fit on a CU,
-    // otherwise 4
-    const bool deep = (8 * SLOT + stack_bytes) * 6 <= 160 * 1024;
-    const int lds = (deep ? 8 : 4) * SLOT + stack_bytes;
-    auto kern = deep ? prune_lane_kernel<N, 8> : prune_lane_kernel<N, 4>;
-    RT_HIP(hipFuncSetAttribute((const void *)kern,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, m->ctx->stream, m->d_Pfrag,
-                       s->d_ops, (int)s->ops.size(), s->d_obs, (int)s->nobs, m->d_root,
-                       s->d_loglik, s->d_status, s->d_partial, (long)s->nsites);
-    return RT_OK;
+    static char buf[5][48];
+    const int R = s->lane_ring;
+    int rc;
+    bool plds = false;
+    if (s->lane_dma) {
+        switch (R) {
+        case 4: rc = launch_lane_dma<N, 4>(m, s); break;
+        case 5: rc = launch_lane_dma<N, 5>(m, s); break;
+        case 6: rc = launch_lane_dma<N, 6>(m, s); break;
+        default: rc = launch_lane_dma<N, 8>(m, s); break;
+        }
+    } else {
+        switch (R) {
+        case 4: rc = launch_lane_reg<N, 4>(m, s, &plds); break;
+        case 6: rc = launch_lane_reg<N, 6>(m, s, &plds); break;
+        case 12: rc = launch_lane_reg<N, 12>(m, s, &plds); break;
+        default: rc = launch_lane_reg<N, 8>(m, s, &plds); break;
+        }
+    }
+    snprintf(buf[N], sizeof(buf[N]), "prune_lane<%d,%s,R%d>", N,
+             s->lane_dma ? "dma" : (plds ? "reg+ldsP" : "reg"), R);
+    *name = buf[N];
+    return rc;
 }
 
 template <int NT, int KS>
