@@ -24,8 +24,6 @@ from __future__ import annotations
 import argparse
 import json
 import os
-import socket
-import struct
 import sys
 import time
 
@@ -46,87 +44,6 @@ WORKLOADS = {
     'c5': dict(desc='20-state blinking compound process, 32-leaf tree, per-edge Q, '
                     '50000 sites/GPU, dense f64 0/1 leaf masks', bound='hbm'),
 }
-
-
-# ---------------------------------------------------------------------------
-# tiny single-node control plane (no torch in the workers)
-# ---------------------------------------------------------------------------
-
-class Control(object):
-    """all-gather of small byte strings among the ranks of one node."""
-
-    def __init__(self, rank, world):
-        self.rank, self.world = rank, world
-        self.peers = []
-        self.sock = None
-        if world == 1:
-            return
-        token = '%s_%s' % (os.environ.get('MASTER_PORT', '0'), os.getppid())
-        path = '/tmp/raoteh_bench_rdzv_%s' % token
-        if rank == 0:
-            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind(('127.0.0.1', 0))
-            srv.listen(world)
-            with open(path + '.tmp', 'w') as f:
-                f.write(str(srv.getsockname()[1]))
-            os.rename(path + '.tmp', path)
-            conns = {}
-            while len(conns) < world - 1:
-                c, _ = srv.accept()
-                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                r = struct.unpack('i', self._recv(c, 4))[0]
-                conns[r] = c
-            self.peers = [conns[r] for r in range(1, world)]
-            srv.close()
-            try:
-                os.unlink(path)
-            except OSError:
-                pass
-        else:
-            deadline = time.time() + 300
-            while not os.path.exists(path):
-                if time.time() > deadline:
-                    raise RuntimeError('rendezvous file never appeared')
-                time.sleep(0.05)
-            port = int(open(path).read())
-            self.sock = socket.create_connection(('127.0.0.1', port))
-            self.sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            self.sock.sendall(struct.pack('i', rank))
-
-    @staticmethod
-    def _recv(c, n):
-        buf = b''
-        while len(buf) < n:
-            chunk = c.recv(n - len(buf))
-            if not chunk:
-                raise RuntimeError('peer closed the control connection')
-            buf += chunk
-        return buf
-
-    def allgather(self, payload):
-        """payload: bytes of equal length on every rank -> list per rank."""
-        if self.world == 1:
-            return [payload]
-        n = len(payload)
-        if self.rank == 0:
-            parts = [payload] + [self._recv(c, n) for c in self.peers]
-            blob = b''.join(parts)
-            for c in self.peers:
-                c.sendall(blob)
-        else:
-            self.sock.sendall(payload)
-            blob = self._recv(self.sock, n * self.world)
-        return [blob[i * n:(i + 1) * n] for i in range(self.world)]
-
-    def barrier(self):
-        self.allgather(b'\0')
-
-    def allreduce(self, values, op):
-        vals = np.asarray(values, dtype=np.float64)
-        parts = self.allgather(vals.tobytes())
-        arr = np.stack([np.frombuffer(p, dtype=np.float64) for p in parts])
-        return op(arr, axis=0)
 
 
 # ---------------------------------------------------------------------------
@@ -171,6 +88,28 @@ def cpu_baseline(cfg, gpu_ll, budget_s):
     out['amortised_numpy_sites_per_s'] = m / dt
     out['amortised_max_rel_err'] = float(np.max(
         np.abs(ll - gpu_ll[:m]) / np.abs(ll)))
+    # compiled scalar C restatement (oracle/oracle.c), 1 thread, both modes
+    try:
+        from oracle import oracle_c
+        from raoteh_amd._tree import TreeArrays
+        ta = TreeArrays(T, root)
+        Q, node_q = ta.rate_matrices(n, cfg['Q_default'])
+        oidx = [ta.node_to_index[v] for v in cfg['leaves']]
+        mf = max(2, min(m, int(3.0 * out['value'] * (40 if n > 20 else 8))))
+        t0 = time.perf_counter()
+        llc, _ = oracle_c.batch_loglik_faithful(ta.indices, ta.indptr, Q, node_q,
+                                                ta.branch_lengths(), oidx,
+                                                dense[:mf], cfg['root_distn'])
+        out['c_port_faithful_sites_per_s'] = mf / (time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        lla, _ = oracle_c.batch_loglik(ta.indices, ta.indptr, esd, oidx, dense,
+                                       cfg['root_distn'])
+        out['c_port_amortised_sites_per_s'] = m / (time.perf_counter() - t0)
+        out['c_port_max_rel_err'] = float(max(
+            np.max(np.abs(llc - gpu_ll[:mf]) / np.abs(llc)),
+            np.max(np.abs(lla - gpu_ll[:m]) / np.abs(lla))))
+    except Exception as e:                       # the C port is optional here
+        out['c_port_error'] = str(e)
     return out
 
 
@@ -199,7 +138,8 @@ def main():
         args.gpus = world
 
     from raoteh_amd import synth, device, _lib     # fails loudly without the .so
-    ctl = Control(rank, world)
+    from raoteh_amd.dist import SocketControl, init_rccl
+    ctl = SocketControl(rank, world)
     ctx = device.Context(local_rank)
 
     wl = WORKLOADS[args.workload]
@@ -228,17 +168,7 @@ def main():
     # RCCL communicator for the data-path reduce
     reduce_kind = 'none'
     if world > 1:
-        reduce_kind = 'rccl'
-        ok = 1.0
-        try:
-            uid = device.Context.comm_unique_id() if rank == 0 else bytes(128)
-            uid = ctl.allgather(uid)[0]
-            ctx.comm_init(world, rank, uid)
-        except Exception as e:          # keep the job alive, say what happened
-            sys.stderr.write('rank %d: RCCL unavailable (%s)\n' % (rank, e))
-            ok = 0.0
-        if ctl.allreduce([ok], np.min)[0] < 1.0:
-            reduce_kind = 'host-socket-fallback'
+        reduce_kind = 'rccl' if init_rccl(ctx, ctl) else 'host-socket-fallback'
 
     def step(j):
         b = batches[j % len(batches)]

@@ -1,0 +1,223 @@
+"""
+Multi-GPU: sites shard, nothing else does.
+
+Sites (alignment columns) are independent given (tree, Q, branch lengths); the
+reference sums their log-likelihoods in a plain loop
+(examples/p53/p53.py:88-100).  One process per GPU owns a contiguous block of
+sites; tree, rates and root distribution are replicated and every GPU runs the
+per-edge expm itself (deterministic, a few KB..MB).  The only data-path
+exchange is the sum of three doubles (sum log-lik, #zero-probability sites,
+#sites): ncclAllReduce over RCCL/xGMI inside libraoteh_hip.so
+(rt_allreduce_totals).  The control plane (unique-id exchange, barriers,
+max-over-ranks timing) is host-side and tiny; two interchangeable
+implementations are provided:
+
+* ``SocketControl``  -- a few bytes over a local TCP socket (single node, no
+  torch import in the worker processes; used by bench.py)
+* ``TorchControl``   -- an already-initialised ``torch.distributed`` process
+  group (gloo on CPU in the tests, any backend elsewhere)
+"""
+from __future__ import annotations
+
+import os
+import socket
+import struct
+import time
+
+import numpy as np
+
+__all__ = ['shard_range', 'SocketControl', 'TorchControl', 'env_rank_world',
+           'reduce_totals', 'init_rccl', 'ShardedLikelihood']
+
+
+def shard_range(nsites, rank, world):
+    """Contiguous block of sites of ``rank``: site i lives on GPU
+    floor(i * world / nsites)."""
+    if not (0 <= rank < world):
+        raise ValueError('rank %d not in [0, %d)' % (rank, world))
+    lo = -(-rank * nsites // world)            # ceil(rank * nsites / world)
+    hi = -(-(rank + 1) * nsites // world)
+    return lo, hi
+
+
+def env_rank_world():
+    """(rank, local_rank, world) from the torchrun environment."""
+    return (int(os.environ.get('RANK', '0')),
+            int(os.environ.get('LOCAL_RANK', '0')),
+            int(os.environ.get('WORLD_SIZE', '1')))
+
+
+class SocketControl(object):
+    """all-gather of small equal-length byte strings among the ranks of ONE
+    node.  Rendezvous: rank 0 listens on an ephemeral 127.0.0.1 port and
+    publishes it in a file keyed by MASTER_PORT and the launcher's pid (all
+    workers of one torchrun share their parent)."""
+
+    def __init__(self, rank, world, token=None, timeout=300.0):
+        self.rank, self.world = rank, world
+        self.peers, self.sock = [], None
+        if world == 1:
+            return
+        if token is None:
+            token = '%s_%s' % (os.environ.get('MASTER_PORT', '0'), os.getppid())
+        path = '/tmp/raoteh_rdzv_%s' % token
+        if rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind(('127.0.0.1', 0))
+            srv.listen(world)
+            srv.settimeout(timeout)
+            with open(path + '.tmp', 'w') as f:
+                f.write(str(srv.getsockname()[1]))
+            os.rename(path + '.tmp', path)
+            conns = {}
+            try:
+                while len(conns) < world - 1:
+                    c, _ = srv.accept()
+                    c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    conns[struct.unpack('i', self._recv(c, 4))[0]] = c
+            finally:
+                srv.close()
+                try:
+                    os.unlink(path)
+                except OSError:
+                    pass
+            self.peers = [conns[r] for r in range(1, world)]
+        else:
+            deadline = time.time() + timeout
+            while not os.path.exists(path):
+                if time.time() > deadline:
+                    raise RuntimeError('rendezvous file %s never appeared' % path)
+                time.sleep(0.02)
+            port = int(open(path).read())
+            self.sock = socket.create_connection(('127.0.0.1', port),
+                                                 timeout=timeout)
+            self.sock.settimeout(None)
+            self.sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            self.sock.sendall(struct.pack('i', rank))
+
+    @staticmethod
+    def _recv(c, n):
+        buf = b''
+        while len(buf) < n:
+            chunk = c.recv(n - len(buf))
+            if not chunk:
+                raise RuntimeError('peer closed the control connection')
+            buf += chunk
+        return buf
+
+    def allgather(self, payload):
+        if self.world == 1:
+            return [payload]
+        n = len(payload)
+        if self.rank == 0:
+            blob = b''.join([payload] + [self._recv(c, n) for c in self.peers])
+            for c in self.peers:
+                c.sendall(blob)
+        else:
+            self.sock.sendall(payload)
+            blob = self._recv(self.sock, n * self.world)
+        return [blob[i * n:(i + 1) * n] for i in range(self.world)]
+
+    def barrier(self):
+        self.allgather(b'\0')
+
+    def allreduce(self, values, op=np.sum):
+        vals = np.ascontiguousarray(values, dtype=np.float64)
+        parts = self.allgather(vals.tobytes())
+        return op(np.stack([np.frombuffer(p, dtype=np.float64) for p in parts]),
+                  axis=0)
+
+    def close(self):
+        for c in self.peers:
+            c.close()
+        if self.sock is not None:
+            self.sock.close()
+        self.peers, self.sock = [], None
+
+
+class TorchControl(object):
+    """Same interface on top of an initialised torch.distributed group."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError('torch.distributed is not initialised')
+        self._dist, self._group = dist, group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def allgather(self, payload):
+        import torch
+        mine = torch.frombuffer(bytearray(payload), dtype=torch.uint8)
+        outs = [torch.empty_like(mine) for _ in range(self.world)]
+        self._dist.all_gather(outs, mine, group=self._group)
+        return [bytes(o.numpy().tobytes()) for o in outs]
+
+    def barrier(self):
+        self._dist.barrier(group=self._group)
+
+    def allreduce(self, values, op=np.sum):
+        import torch
+        t = torch.from_numpy(np.array(values, dtype=np.float64, copy=True))
+        ops = {np.sum: self._dist.ReduceOp.SUM, np.max: self._dist.ReduceOp.MAX,
+               np.min: self._dist.ReduceOp.MIN}
+        self._dist.all_reduce(t, op=ops[op], group=self._group)
+        return t.numpy()
+
+    def close(self):
+        pass
+
+
+def reduce_totals(local_totals, control):
+    """Host-side sum over ranks of the (sum log-lik, #zero, #sites) triple --
+    the fallback of the RCCL reduce and what the CPU tests exercise."""
+    return control.allreduce(np.asarray(local_totals, dtype=np.float64), np.sum)
+
+
+def init_rccl(ctx, control):
+    """Create the RCCL communicator of ``ctx`` across the ranks of ``control``.
+    Returns True on every rank or False on every rank (never mixed)."""
+    ok = 1.0
+    if control.world > 1:
+        try:
+            from .device import Context
+            uid = Context.comm_unique_id() if control.rank == 0 else bytes(128)
+            uid = control.allgather(uid)[0]
+            ctx.comm_init(control.world, control.rank, uid)
+        except Exception as e:                      # keep the job alive
+            import sys
+            sys.stderr.write('rank %d: RCCL unavailable: %s\n' % (control.rank, e))
+            ok = 0.0
+        ok = float(control.allreduce([ok], np.min)[0])
+    return ok >= 1.0
+
+
+class ShardedLikelihood(object):
+    """Total log-likelihood of a site batch sharded over the ranks.
+
+    Every rank passes the FULL observation array (or its own slice with
+    ``presharded=True``); each uploads only its block.  ``total()`` returns the
+    global (sum log-lik or -inf, #zero-probability sites, #sites) on every
+    rank."""
+
+    def __init__(self, model, control, obs_nodes, data, kind='dense',
+                 presharded=False, use_rccl=True):
+        self.model, self.control = model, control
+        data = np.asarray(data)
+        if not presharded:
+            lo, hi = shard_range(data.shape[0], control.rank, control.world)
+            data = data[lo:hi]
+        self.batch = model.upload_sites(obs_nodes, data, kind=kind)
+        self.rccl = bool(use_rccl and control.world > 1 and
+                         init_rccl(model.ctx, control))
+
+    def total(self):
+        self.model.prune(self.batch)
+        if self.rccl:
+            self.model.allreduce(self.batch)
+            tot = self.model.fetch_totals(self.batch)
+        else:
+            tot = reduce_totals(self.model.fetch_totals(self.batch), self.control)
+        nzero = int(tot[1])
+        return (-np.inf if nzero else float(tot[0])), nzero, int(tot[2])

@@ -1,0 +1,62 @@
+"""Worker of tests/test_dist_cpu.py: launched by torch.distributed.run with
+WORLD_SIZE ranks on the CPU.  Each rank evaluates its shard of sites with the
+oracle (standing in for the GPU, which this container lacks), then the product's
+sharding + reduction code (raoteh_amd.dist) combines the shards over (a) a gloo
+process group and (b) the socket control plane bench.py uses."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch.distributed as dist                      # noqa: E402
+
+from oracle import oracle_numpy as orc                # noqa: E402
+from raoteh_amd import synth                          # noqa: E402
+from raoteh_amd.dist import (SocketControl, TorchControl, env_rank_world,  # noqa: E402
+                             reduce_totals, shard_range)
+
+
+def main():
+    out_path = sys.argv[1]
+    rank, local_rank, world = env_rank_world()
+    dist.init_process_group('gloo')
+    cfg = synth.make_config('c2', nsites=1003)
+    T, root, n = cfg['T'], cfg['root'], cfg['nstates']
+    dense = synth.leaf_likelihoods(cfg)
+    dense[17, 0, :] = 0.0                              # one zero-probability site
+    pre, idx, ptr, esd = orc.get_expm_augmented_transitions(
+        T, root, n, Q_default=cfg['Q_default'])
+    oidx = [pre.index(v) for v in cfg['leaves']]
+    lo, hi = shard_range(dense.shape[0], rank, world)
+    ll, st = orc.batch_log_likelihoods(idx, ptr, esd, oidx, dense[lo:hi],
+                                       cfg['root_distn'])
+    local = np.array([ll[st == 0].sum(), float((st != 0).sum()), float(hi - lo)])
+    results = {}
+    tc = TorchControl()
+    assert (tc.rank, tc.world) == (rank, world)
+    results['gloo'] = reduce_totals(local, tc).tolist()
+    tc.barrier()
+    gathered = tc.allgather(np.array([lo, hi], dtype=np.int64).tobytes())
+    results['ranges'] = [np.frombuffer(g, dtype=np.int64).tolist() for g in gathered]
+    sc = SocketControl(rank, world)
+    results['socket'] = reduce_totals(local, sc).tolist()
+    results['max_rank'] = float(sc.allreduce([float(rank)], np.max)[0])
+    sc.barrier()
+    sc.close()
+    if rank == 0:
+        full, fst = orc.batch_log_likelihoods(idx, ptr, esd, oidx, dense,
+                                              cfg['root_distn'])
+        results['want'] = [float(full[fst == 0].sum()), float((fst != 0).sum()),
+                           float(dense.shape[0])]
+        with open(out_path, 'w') as f:
+            json.dump(results, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,68 @@
+"""
+The N > 1 path on CPU: world_size-2 (and 3) process groups over gloo exercise
+the product's sharding and reduction code (raoteh_amd/dist.py) -- shard ranges,
+the host-side reduce of the (sum log-lik, #zero, #sites) triple that backs up
+the RCCL all-reduce, and the socket control plane bench.py uses.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from raoteh_amd.dist import shard_range
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_shard_ranges_partition_the_sites():
+    for nsites in (1, 7, 64, 1003, 100000):
+        for world in (1, 2, 3, 8):
+            prev = 0
+            for rank in range(world):
+                lo, hi = shard_range(nsites, rank, world)
+                assert lo == prev and hi >= lo
+                prev = hi
+                for i in (lo, hi - 1):
+                    if lo < hi:
+                        assert i * world // nsites == rank
+            assert prev == nsites
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_reduce_matches_single_process(tmp_path, world):
+    out = tmp_path / 'result.json'
+    env = dict(os.environ)
+    env['PYTHONPATH'] = ROOT + os.pathsep + env.get('PYTHONPATH', '')
+    env['OMP_NUM_THREADS'] = '1'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()),
+           os.path.join(ROOT, 'tests', '_dist_worker.py'), str(out)]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.STDOUT, timeout=600)
+    assert proc.returncode == 0, proc.stdout.decode()[-3000:]
+    res = json.load(open(out))
+    want = res['want']
+    assert want[1] == 1.0 and want[2] == 1003.0
+    for key in ('gloo', 'socket'):
+        got = res[key]
+        assert got[1:] == want[1:]
+        assert got[0] == pytest.approx(want[0], rel=1e-13)
+    assert res['max_rank'] == world - 1
+    ranges = res['ranges']
+    assert ranges[0][0] == 0 and ranges[-1][1] == 1003
+    for a, b in zip(ranges, ranges[1:]):
+        assert a[1] == b[0]
