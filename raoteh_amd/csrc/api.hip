@@ -203,7 +203,7 @@ extern "C" int rt_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *Q,
     if (e == hipSuccess) e = hipMemcpyAsync(dQ, Q, nq * nn * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(dt, t, count * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(dqi, qi.data(), count * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) rc = rt_launch_expm(ctx, n, count, dQ, dqi, dt, dP, dinfo);
+    if (e == hipSuccess) rc = rt_launch_expm(ctx, n, count, dQ, dqi, dt, dP, dinfo, nullptr, 0, nullptr);
     if (e == hipSuccess && rc == RT_OK)
         e = hipMemcpyAsync(P, dP, count * nn * 8, hipMemcpyDeviceToHost, ctx->stream);
     std::vector<int32_t> hinfo((size_t)count * 2, 0);
@@ -323,7 +323,7 @@ extern "C" int rt_model_destroy(rt_model *m)
     hipStreamSynchronize(m->ctx->stream);
     hipFree(m->d_indices); hipFree(m->d_indptr); hipFree(m->d_ops); hipFree(m->d_P);
     hipFree(m->d_Pfrag); hipFree(m->d_root); hipFree(m->d_Q); hipFree(m->d_qidx);
-    hipFree(m->d_t); hipFree(m->d_info);
+    hipFree(m->d_t); hipFree(m->d_info); hipFree(m->d_step_of_node);
     delete m;
     return RT_OK;
 }
@@ -376,6 +376,11 @@ extern "C" int rt_model_create(rt_ctx *ctx, int64_t nnodes, int64_t n,
     if (e == hipSuccess)
         e = hipMemcpy(m->d_ops, m->ops.data(), m->ops.size() * sizeof(rt_op),
                       hipMemcpyHostToDevice);
+    std::vector<int32_t> step_of((size_t)nnodes, -1);
+    for (size_t k = 0; k < m->ops.size(); ++k) step_of[(size_t)m->ops[k].node] = (int32_t)k;
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_step_of_node, nnodes * 4);
+    if (e == hipSuccess)
+        e = hipMemcpy(m->d_step_of_node, step_of.data(), nnodes * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(m->d_P, 0, nnodes * nn * 8);
     if (e == hipSuccess) e = hipMemset(m->d_info, 0, nnodes * 8);
     std::vector<double> ones((size_t)n, 1.0);
@@ -391,11 +396,12 @@ extern "C" int rt_model_create(rt_ctx *ctx, int64_t nnodes, int64_t n,
 
 static int model_run_expm(rt_model *m)
 {
+    // the expm epilogue also writes the step-ordered layout the pruning kernel reads
     RT_TRY(rt_launch_expm(m->ctx, m->n, m->nnodes, m->d_Q, m->d_qidx, m->d_t, m->d_P,
-                          m->d_info));
+                          m->d_info, m->d_step_of_node, m->n <= 4 ? 0 : 1, m->d_Pfrag));
     m->have_P = true;
-    m->frag_dirty = true;
-    return rt_launch_pfrag(m);
+    m->frag_dirty = false;
+    return RT_OK;
 }
 
 extern "C" int rt_model_set_rates(rt_model *m, const double *Q, int64_t nq,

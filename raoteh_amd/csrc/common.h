@@ -91,6 +91,7 @@ struct rt_model {
     int32_t *d_qidx = nullptr;      // [nnodes]
     double *d_t = nullptr;          // [nnodes]
     int32_t *d_info = nullptr;      // [nnodes][2]
+    int32_t *d_step_of_node = nullptr;  // [nnodes] schedule step of each node
     bool have_P = false;
     bool frag_dirty = true;
 };
@@ -132,7 +133,8 @@ void rt_time_end(rt_ctx *ctx, int kernel, hipEvent_t start);
 
 int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
                    const int32_t *d_qidx, const double *d_t, double *d_P,
-                   int32_t *d_info);
+                   int32_t *d_info, const int32_t *d_step_of_node, int frag_kind,
+                   double *d_Pfrag);
 int rt_launch_pfrag(rt_model *m);
 int rt_launch_prune(rt_model *m, rt_sites *s);
 int rt_sites_pack(rt_sites *s, int kind, const int64_t *obs_order,

@@ -1,5 +1,5 @@
 // P = expm(Q * t) for a batch of small dense rate matrices, f64, one workgroup
-// per matrix, every intermediate resident in LDS.
+// (4 waves) per matrix, every intermediate resident in LDS or registers.
 //
 // Replaces scipy.linalg.expm(Q * weight) at raoteh/sampler/_mjp_dense.py:24-25
 // (one call per edge per site in the reference, _mjp_dense.py:352-358) and
@@ -8,14 +8,21 @@
 // Algorithm: N. J. Higham, "The scaling and squaring method for the matrix
 // exponential revisited", SIAM J. Matrix Anal. Appl. 26(4), 2005, Algorithm 2.3:
 // degree m in {3,5,7,9,13} chosen from ||A||_1 against theta_m, scaling by 2^-s
-// for m = 13, [m/m] Pade approximant r = (V-U)^-1 (V+U), s squarings.  The
-// linear solve is Gauss-Jordan elimination with partial (row) pivoting on the
-// augmented system, rows kept in place and un-permuted at the end.
+// for m = 13, [m/m] Pade approximant r = (V-U)^-1 (V+U), s squarings.
 //
-// LDS budget: five n x ld f64 buffers (ld = n | 1 so that column walks do not
-// sit on one bank) -- 148.8 KB at n = 61 -- every matrix product is accumulated
-// in registers and written back after a barrier, so products may overwrite
-// their own operands and no sixth buffer is needed.
+// * Matrix products: v_mfma_f64_16x16x4_f64 on n padded to 16*NT; the NT*NT
+//   output tiles are dealt over the four waves; every product is accumulated
+//   in registers and stored after a barrier, so a product may overwrite its own
+//   operands and five n x (n|1) LDS buffers suffice (148.8 KB at n = 61).
+// * Linear solve: Gauss-Jordan with partial pivoting on the augmented system
+//   [V-U | V+U], held ENTIRELY IN REGISTERS in a 2-D cyclic distribution
+//   (thread (ri, ci) owns rows ri+16a, columns ci+16b: 4 x 8 elements).  Per
+//   pivot step only the pivot column and the pivot row travel through LDS (two
+//   barriers), every wave finds the pivot itself (wave-wide argmax), rows are
+//   never swapped: the permutation is undone when X is written back.
+// * Epilogue: P is written in the reference's esd order and, fused, in the
+//   step-ordered layout the pruning kernel of this model reads (lane family:
+//   [step][n][n]; MFMA family: A-fragment order), which removes a launch.
 #include "common.h"
 
 namespace {
@@ -38,73 +45,96 @@ __constant__ double c_b13[14] = {64764752532480000., 32382376266240000.,
                                  40840800., 960960., 16380., 182., 1.};
 
 constexpr int TPB = 256;
+typedef double double4_t __attribute__((ext_vector_type(4)));
 
-// C = A * B for n x n matrices in LDS (leading dimension ld).  Each thread owns
-// a 4x4 tile of C, accumulates it in registers, and stores it after a barrier,
-// so C may alias A and/or B.
-__device__ __forceinline__ void lds_matmul(const double *A, const double *B,
-                                           double *C, int n, int ld)
+// C = A * B (n x n, leading dimension ld, in LDS) on the f64 matrix pipe.
+// A lane l: A[16m + (l&15)][4kk + (l>>4)], B lane l: B[4kk + (l>>4)][16j + (l&15)],
+// D lane l reg r: C[16m + 4r + (l>>4)][16j + (l&15)].  Elements outside n x n
+// read as zero.  C may alias A and/or B.
+__device__ __forceinline__ void lds_matmul(const double *A, const double *B, double *C,
+                                           int n, int ld, int NT, int KS)
 {
-    const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
-    int ri[4], cj[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int nitems = NT * NT;
+    double4_t acc[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        ri[r] = min(4 * ti + r, n - 1);
-        cj[r] = min(4 * tj + r, n - 1);
-    }
-    double acc[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
-    for (int k = 0; k < n; ++k) {
-        double a[4], b[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) a[r] = A[ri[r] * ld + k];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) b[c] = B[k * ld + cj[c]];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[r][c] = fma(a[r], b[c], acc[r][c]);
+    for (int it = 0; it < 4; ++it) {
+        acc[it] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        const int item = wave + 4 * it;
+        if (item < nitems) {
+            const int m = item / NT, j = item - m * NT;
+            const int arow = 16 * m + lr, bcol = 16 * j + lr;
+            const bool aok = arow < n, bok = bcol < n;
+            const double *ap = A + (aok ? arow : 0) * ld;
+            const double *bp = B + (bok ? bcol : 0);
+            for (int kk = 0; kk < KS; ++kk) {
+                const int k = 4 * kk + lq;
+                const bool kok = k < n;
+                const double a = (aok && kok) ? ap[kok ? k : 0] : 0.0;
+                const double b = (bok && kok) ? bp[(kok ? k : 0) * ld] : 0.0;
+                acc[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[it], 0, 0, 0);
+            }
+        }
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int it = 0; it < 4; ++it) {
+        const int item = wave + 4 * it;
+        if (item < nitems) {
+            const int m = item / NT, j = item - m * NT;
+            const int col = 16 * j + lr;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int i = 4 * ti + r, j = 4 * tj + c;
-            if (i < n && j < n) C[i * ld + j] = acc[r][c];
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * m + 4 * r + lq;
+                if (row < n && col < n) C[row * ld + col] = acc[it][r];
+            }
         }
+    }
     __syncthreads();
 }
 
 __global__ void __launch_bounds__(TPB)
-expm_lds_kernel(int n, const double *__restrict__ Q,
-                const int *__restrict__ qidx, const double *__restrict__ tt,
-                double *__restrict__ P, int *__restrict__ info)
+expm_kernel(int n, const double *__restrict__ Q, const int *__restrict__ qidx,
+            const double *__restrict__ tt, double *__restrict__ P,
+            int *__restrict__ info,
+            // fused repack (all optional): step of each node, layout, output
+            const int *__restrict__ step_of_node, int frag_kind,
+            double *__restrict__ Pfrag)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int ld = n | 1;
     const int msz = n * ld;
+    const int NT = (n + 15) / 16;
+    const int KS = (n + 3) / 4;
     double *B0 = (double *)smem;
     double *B1 = B0 + msz;
     double *B2 = B1 + msz;
     double *B3 = B2 + msz;
     double *B4 = B3 + msz;
-    double *colsum = B4 + msz;                 // [64]
-    int *ibuf = (int *)(colsum + 64);          // [0]=m [1]=s [2]=pivot row
-    int *rowof = ibuf + 8;                     // [64]
-    int *used = rowof + 64;                    // [64]
+    double *colbuf = B4 + msz;                 // [2][64]
+    double *rowbuf = colbuf + 128;             // [128]
+    double *dinv = rowbuf + 128;               // [64] 1 / pivot of the row
+    int *ibuf = (int *)(dinv + 64);            // [0]=m [1]=s [2]=singular
+    int *kof = ibuf + 8;                       // [64] pivot column of each row
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
     const int nn = n * n;
     double *Pb = P + (long)b * nn;
     const int qi = qidx[b];
+    const int step = step_of_node ? step_of_node[b] : -1;
     if (qi < 0) {                              // root slot: zeros (_density.py:171)
         for (int e = tid; e < nn; e += TPB) Pb[e] = 0.0;
         if (info && tid == 0) { info[2 * b] = 0; info[2 * b + 1] = 0; }
+        if (step >= 0 && frag_kind == 0)
+            for (int e = tid; e < nn; e += TPB) Pfrag[(long)step * nn + e] = 0.0;
+        if (step >= 0 && frag_kind == 1) {
+            const int total = NT * ((KS + 1) / 2) * 128;
+            for (int e = tid; e < total; e += TPB) Pfrag[(long)step * total + e] = 0.0;
+        }
         return;
     }
     const double *Qb = Q + (long)qi * nn;
@@ -116,36 +146,33 @@ expm_lds_kernel(int n, const double *__restrict__ Q,
         B0[i * ld + j] = Qb[e] * t;
     }
     __syncthreads();
-    // ||A||_1 = max column sum
-    if (tid < n) {
+    // ||A||_1 = max column sum; every wave computes it (no second barrier)
+    double nrm;
+    {
         double s = 0.0;
-        for (int i = 0; i < n; ++i) s += fabs(B0[i * ld + tid]);
-        colsum[tid] = s;
+        if (lane < n)
+            for (int i = 0; i < n; ++i) s += fabs(B0[i * ld + lane]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s = fmax(s, __shfl_xor(s, o, 64));
+        nrm = s;
     }
-    __syncthreads();
-    if (tid == 0) {
-        double nrm = 0.0;
-        for (int j = 0; j < n; ++j) nrm = fmax(nrm, colsum[j]);
-        int m = 13, s = 0;
-        if (nrm <= c_theta[0]) m = 3;
-        else if (nrm <= c_theta[1]) m = 5;
-        else if (nrm <= c_theta[2]) m = 7;
-        else if (nrm <= c_theta[3]) m = 9;
-        else if (nrm > c_theta[4]) {
-            // s = ceil(log2(nrm / theta13)), exact via frexp on the ratio
-            int e;
-            const double f = frexp(nrm / c_theta[4], &e);   // ratio = f * 2^e
-            s = (f == 0.5) ? e - 1 : e;
-            if (s < 0) s = 0;
-        }
-        ibuf[0] = m;
-        ibuf[1] = s;
+    int m = 13, s = 0;
+    if (nrm <= c_theta[0]) m = 3;
+    else if (nrm <= c_theta[1]) m = 5;
+    else if (nrm <= c_theta[2]) m = 7;
+    else if (nrm <= c_theta[3]) m = 9;
+    else if (nrm > c_theta[4]) {
+        // s = ceil(log2(nrm / theta13)), exact via frexp on the ratio
+        int e;
+        const double f = frexp(nrm / c_theta[4], &e);       // ratio = f * 2^e
+        s = (f == 0.5) ? e - 1 : e;
+        if (s < 0) s = 0;
     }
-    __syncthreads();
-    const int m = ibuf[0];
-    const int s = ibuf[1];
+    m = __builtin_amdgcn_readfirstlane(m);
+    s = __builtin_amdgcn_readfirstlane(s);
     if (info && tid == 0) { info[2 * b] = m; info[2 * b + 1] = s; }
     if (s > 0) {
+        __syncthreads();
         const double sc = ldexp(1.0, -s);
         for (int e = tid; e < nn; e += TPB) {
             const int i = e / n, j = e - i * n;
@@ -154,44 +181,43 @@ expm_lds_kernel(int n, const double *__restrict__ Q,
         __syncthreads();
     }
 
-    double *U, *V;     // results of the Pade stage
-    double *Mb, *Rb, *Xb;
+    double *U, *V, *Xb;
     if (m == 13) {
-        lds_matmul(B0, B0, B1, n, ld);         // A2
-        lds_matmul(B1, B1, B2, n, ld);         // A4
-        lds_matmul(B2, B1, B3, n, ld);         // A6
+        lds_matmul(B0, B0, B1, n, ld, NT, KS);         // A2
+        lds_matmul(B1, B1, B2, n, ld, NT, KS);         // A4
+        lds_matmul(B2, B1, B3, n, ld, NT, KS);         // A6
         for (int e = tid; e < nn; e += TPB) {
             const int i = e / n, j = e - i * n, o = i * ld + j;
             B4[o] = c_b13[13] * B3[o] + c_b13[11] * B2[o] + c_b13[9] * B1[o];
         }
         __syncthreads();
-        lds_matmul(B3, B4, B4, n, ld);         // A6 * (...)
+        lds_matmul(B3, B4, B4, n, ld, NT, KS);         // A6 * (...)
         for (int e = tid; e < nn; e += TPB) {
             const int i = e / n, j = e - i * n, o = i * ld + j;
             B4[o] += c_b13[7] * B3[o] + c_b13[5] * B2[o] + c_b13[3] * B1[o] +
                      (i == j ? c_b13[1] : 0.0);
         }
         __syncthreads();
-        lds_matmul(B0, B4, B4, n, ld);         // U = A * W
-        for (int e = tid; e < nn; e += TPB) {  // A is dead: reuse B0
+        lds_matmul(B0, B4, B4, n, ld, NT, KS);         // U = A * W
+        for (int e = tid; e < nn; e += TPB) {          // A is dead: reuse B0
             const int i = e / n, j = e - i * n, o = i * ld + j;
             B0[o] = c_b13[12] * B3[o] + c_b13[10] * B2[o] + c_b13[8] * B1[o];
         }
         __syncthreads();
-        lds_matmul(B3, B0, B0, n, ld);
+        lds_matmul(B3, B0, B0, n, ld, NT, KS);
         for (int e = tid; e < nn; e += TPB) {
             const int i = e / n, j = e - i * n, o = i * ld + j;
             B0[o] += c_b13[6] * B3[o] + c_b13[4] * B2[o] + c_b13[2] * B1[o] +
                      (i == j ? c_b13[0] : 0.0);
         }
         __syncthreads();
-        U = B4; V = B0; Mb = B1; Rb = B2; Xb = B3;
+        U = B4; V = B0; Xb = B1;
     } else {
         const double *bc = (m == 3) ? c_b3 : (m == 5) ? c_b5 : (m == 7) ? c_b7 : c_b9;
-        lds_matmul(B0, B0, B1, n, ld);                       // A2
-        if (m >= 5) lds_matmul(B1, B1, B2, n, ld);           // A4
-        if (m >= 7) lds_matmul(B2, B1, B3, n, ld);           // A6
-        if (m >= 9) lds_matmul(B3, B1, B4, n, ld);           // A8
+        lds_matmul(B0, B0, B1, n, ld, NT, KS);                       // A2
+        if (m >= 5) lds_matmul(B1, B1, B2, n, ld, NT, KS);           // A4
+        if (m >= 7) lds_matmul(B2, B1, B3, n, ld, NT, KS);           // A6
+        if (m >= 9) lds_matmul(B3, B1, B4, n, ld, NT, KS);           // A8
         // W (odd coefficients) -> B4, V (even coefficients) -> B3, elementwise
         for (int e = tid; e < nn; e += TPB) {
             const int i = e / n, j = e - i * n, o = i * ld + j;
@@ -208,72 +234,139 @@ expm_lds_kernel(int n, const double *__restrict__ Q,
             B3[o] = v;
         }
         __syncthreads();
-        lds_matmul(B0, B4, B4, n, ld);                       // U = A * W
-        U = B4; V = B3; Mb = B1; Rb = B2; Xb = B0;
+        lds_matmul(B0, B4, B4, n, ld, NT, KS);                       // U = A * W
+        U = B4; V = B3; Xb = B0;
     }
 
-    // M = V - U, R = V + U
-    for (int e = tid; e < nn; e += TPB) {
-        const int i = e / n, j = e - i * n, o = i * ld + j;
-        const double u = U[o], v = V[o];
-        Mb[o] = v - u;
-        Rb[o] = v + u;
-    }
-    if (tid < 64) used[tid] = 0;
-    __syncthreads();
-
-    // Gauss-Jordan with partial pivoting, rows left in place
-    int singular = 0;
-    for (int k = 0; k < n; ++k) {
-        if (tid < 64) {
-            double v = -1.0;
-            int r = tid;
-            if (tid < n && !used[tid]) v = fabs(Mb[tid * ld + k]);
+    // ---- Gauss-Jordan on [M | R] = [V - U | V + U] in registers -------------
+    // thread (ri, ci): rows ri + 16a (a < 4), augmented columns ci + 16b (b < 8)
+    const int ri = tid & 15, ci = tid >> 4;
+    double g[4][8];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const double ov = __shfl_xor(v, o, 64);
-                const int orow = __shfl_xor(r, o, 64);
-                if (ov > v || (ov == v && orow < r)) { v = ov; r = orow; }
+    for (int a = 0; a < 4; ++a) {
+        const int i = ri + 16 * a;
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) {
+            const int c = ci + 16 * bb;
+            double v = 0.0;
+            if (i < n && c < 2 * n) {
+                const int j = c < n ? c : c - n;
+                const double u = U[i * ld + j], w = V[i * ld + j];
+                v = c < n ? w - u : w + u;
             }
-            if (tid == 0) {
-                ibuf[2] = r;
-                ibuf[3] = (v > 0.0) ? 0 : 1;
-                used[r] = 1;
-                rowof[k] = r;
+            g[a][bb] = v;
+        }
+    }
+    // column 0 -> colbuf[0]
+    if (ci == 0) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) colbuf[ri + 16 * a] = g[a][0];
+    }
+    if (tid == 0) ibuf[2] = 0;
+    __syncthreads();
+    bool used = lane >= n;              // replicated in every wave: row = lane
+    for (int k = 0; k < n; ++k) {
+        const double *cb = colbuf + (k & 1) * 64;
+        // every wave finds the pivot row itself
+        double pv = used ? -1.0 : fabs(cb[lane]);
+        int pr = lane;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(pv, o, 64);
+            const int orow = __shfl_xor(pr, o, 64);
+            if (ov > pv || (ov == pv && orow < pr)) { pv = ov; pr = orow; }
+        }
+        pr = __builtin_amdgcn_readfirstlane(pr);
+        if (!(pv > 0.0)) {                       // singular (or NaN): wave-uniform
+            if (tid == 0) ibuf[2] = 1;
+            break;
+        }
+        if (lane == pr) used = true;
+        const double rinv = 1.0 / cb[pr];
+        if (tid == 0) { dinv[pr] = rinv; kof[pr] = k; }
+        // pivot-row owners publish their 8 columns
+        if (ri == (pr & 15)) {
+            const int a0 = pr >> 4;
+#pragma unroll
+            for (int bb = 0; bb < 8; ++bb) {
+                const double v = a0 == 0 ? g[0][bb] : a0 == 1 ? g[1][bb]
+                               : a0 == 2 ? g[2][bb] : g[3][bb];
+                rowbuf[ci + 16 * bb] = v;
             }
         }
         __syncthreads();
-        const int pr = ibuf[2];
-        if (ibuf[3]) { singular = 1; break; }
-        const double rinv = 1.0 / Mb[pr * ld + k];
-        // rows i != pr: M[i][j>k] -= f * M[pr][j], R[i][:] -= f * R[pr][:]
-        const int tx = tid & 63, ty = tid >> 6;
-        for (int i = ty; i < n; i += 4) {
-            if (i == pr) continue;
-            const double f = Mb[i * ld + k] * rinv;
-            for (int cc = k + 1 + tx; cc < 2 * n; cc += 64) {
-                if (cc < n) Mb[i * ld + cc] = fma(-f, Mb[pr * ld + cc], Mb[i * ld + cc]);
-                else Rb[i * ld + cc - n] = fma(-f, Rb[pr * ld + cc - n], Rb[i * ld + cc - n]);
+        double f[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int i = ri + 16 * a;
+            f[a] = (i == pr || i >= n) ? 0.0 : cb[i] * rinv;
+        }
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) {
+            const int c = ci + 16 * bb;
+            // columns <= k of M are finished; skipping them keeps the pivots exact
+            const double prow = (c > k && c < 2 * n) ? rowbuf[c] : 0.0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) g[a][bb] = fma(-f[a], prow, g[a][bb]);
+        }
+        // owners of column k+1 publish it for the next step (other colbuf half)
+        if (k + 1 < n && ci == ((k + 1) & 15)) {
+            const int b1 = (k + 1) >> 4;
+            double *nb = colbuf + ((k + 1) & 1) * 64;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const double v = b1 == 0 ? g[a][0] : b1 == 1 ? g[a][1]
+                               : b1 == 2 ? g[a][2] : g[a][3];
+                nb[ri + 16 * a] = v;
             }
         }
         __syncthreads();
     }
-    if (singular) {
+    __syncthreads();
+    if (ibuf[2]) {
         for (int e = tid; e < nn; e += TPB) Pb[e] = __builtin_nan("");
         if (info && tid == 0) info[2 * b] = -1;
         return;
     }
-    // X[k][:] = R[rowof[k]][:] / M[rowof[k]][k]
-    for (int e = tid; e < nn; e += TPB) {
-        const int k = e / n, j = e - k * n;
-        const int r = rowof[k];
-        Xb[k * ld + j] = Rb[r * ld + j] / Mb[r * ld + k];
+    // X[kof[i]][j] = R[i][j] / pivot(i)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int i = ri + 16 * a;
+        if (i < n) {
+            const double d = dinv[i];
+            const int xr = kof[i];
+#pragma unroll
+            for (int bb = 0; bb < 8; ++bb) {
+                const int c = ci + 16 * bb;
+                if (c >= n && c < 2 * n) Xb[xr * ld + (c - n)] = g[a][bb] * d;
+            }
+        }
     }
     __syncthreads();
-    for (int q = 0; q < s; ++q) lds_matmul(Xb, Xb, Xb, n, ld);
+    for (int q = 0; q < s; ++q) lds_matmul(Xb, Xb, Xb, n, ld, NT, KS);
+
     for (int e = tid; e < nn; e += TPB) {
         const int i = e / n, j = e - i * n;
         Pb[e] = Xb[i * ld + j];
+    }
+    if (step >= 0 && frag_kind == 0) {
+        for (int e = tid; e < nn; e += TPB) {
+            const int i = e / n, j = e - i * n;
+            Pfrag[(long)step * nn + e] = Xb[i * ld + j];
+        }
+    } else if (step >= 0 && frag_kind == 1) {
+        // Pfrag[step][m][q][lane][e2] = P[16m + (lane&15)][4(2q+e2) + (lane>>4)]
+        const int KP = (KS + 1) / 2;
+        const int total = NT * KP * 128;
+        for (int e = tid; e < total; e += TPB) {
+            const int e2 = e & 1;
+            const int ln = (e >> 1) & 63;
+            const int q = (e >> 7) % KP;
+            const int mm = (e >> 7) / KP;
+            const int row = 16 * mm + (ln & 15);
+            const int col = 4 * (2 * q + e2) + (ln >> 4);
+            Pfrag[(long)step * total + e] = (row < n && col < n) ? Xb[row * ld + col] : 0.0;
+        }
     }
 }
 
@@ -281,7 +374,8 @@ expm_lds_kernel(int n, const double *__restrict__ Q,
 
 int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
                    const int32_t *d_qidx, const double *d_t, double *d_P,
-                   int32_t *d_info)
+                   int32_t *d_info, const int32_t *d_step_of_node, int frag_kind,
+                   double *d_Pfrag)
 {
     if (n < 1 || n > RT_MAX_EXPM_STATES) {
         rt_set_error("expm: n=%lld outside 1..%d", (long long)n, RT_MAX_EXPM_STATES);
@@ -289,18 +383,19 @@ int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
     }
     if (count <= 0) return RT_OK;
     const int ld = (int)n | 1;
-    const size_t lds = (size_t)5 * n * ld * 8 + 64 * 8 + (8 + 64 + 64) * 4;
+    const size_t lds = (size_t)5 * n * ld * 8 + (128 + 128 + 64) * 8 + (8 + 64) * 4;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
-        RT_HIP(hipFuncSetAttribute((const void *)expm_lds_kernel,
+        RT_HIP(hipFuncSetAttribute((const void *)expm_kernel,
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
         attr_lds = lds;
     }
     hipEvent_t ev = nullptr;
-    rt_time_begin(ctx, RT_K_EXPM, "expm_lds", &ev);
-    hipLaunchKernelGGL(expm_lds_kernel, dim3((unsigned)count), dim3(TPB), lds,
-                       ctx->stream, (int)n, d_Q, d_qidx, d_t, d_P, d_info);
+    rt_time_begin(ctx, RT_K_EXPM, "expm_mfma_regsolve", &ev);
+    hipLaunchKernelGGL(expm_kernel, dim3((unsigned)count), dim3(TPB), lds, ctx->stream,
+                       (int)n, d_Q, d_qidx, d_t, d_P, d_info, d_step_of_node, frag_kind,
+                       d_Pfrag);
     RT_HIP(hipGetLastError());
     rt_time_end(ctx, RT_K_EXPM, ev);
     return RT_OK;

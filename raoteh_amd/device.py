@@ -13,6 +13,7 @@ per site (examples/p53/p53.py:88-100).
 """
 from __future__ import annotations
 
+import atexit
 import ctypes
 from ctypes import byref, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p
 
@@ -22,6 +23,12 @@ from . import _lib
 from ._tree import TreeArrays, check_square_dense
 
 __all__ = ['Context', 'get_context', 'TreeModel', 'SiteBatch', 'device_count']
+
+# At interpreter shutdown objects are finalised in arbitrary order (a model
+# after its context, say); the process is going away, so skip the native
+# destructors then instead of handing the library dangling handles.
+_shutting_down = []
+atexit.register(_shutting_down.append, True)
 
 _KINDS = {'dense': _lib.RT_OBS_DENSE, 'state': _lib.RT_OBS_STATE,
           'mask': _lib.RT_OBS_MASK}
@@ -54,7 +61,7 @@ class Context(object):
         self.device = int(device)
 
     def close(self):
-        if self._h:
+        if self._h and not _shutting_down:
             _lib.lib().rt_ctx_destroy(self._h)
             self._h = c_void_p()
 
@@ -193,7 +200,7 @@ class SiteBatch(object):
         return _lib.lib().rt_sites_device_bytes(self._h)
 
     def close(self):
-        if self._h:
+        if self._h and not _shutting_down:
             _lib.lib().rt_sites_destroy(self._h)
             self._h = c_void_p()
 
@@ -218,7 +225,7 @@ class TreeModel(object):
             _ptr(ta.indptr, c_int64), byref(self._h)))
 
     def close(self):
-        if self._h:
+        if self._h and not _shutting_down:
             _lib.lib().rt_model_destroy(self._h)
             self._h = c_void_p()
 

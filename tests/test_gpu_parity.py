@@ -535,6 +535,6 @@ def test_timing_and_clone(ra):
     ms, cnt, name = ctx.kernel_time(1)
     assert cnt == 6 and ms > 0 and name.startswith('prune_lane')
     ms, cnt, name = ctx.kernel_time(0)
-    assert cnt == 1 and name == 'expm_lds'
+    assert cnt == 1 and name.startswith('expm')
     ctx.set_timing(False)
     assert batch.device_bytes == 32 * 64 * 64 * 4 * 8
