@@ -532,10 +532,9 @@ extern "C" int rt_sites_destroy(rt_sites *s)
 
 // Lane-kernel program: simulate the register cache of the top accumulator and
 // turn slots into LDS byte offsets (see LOP_* in prune.hip).
-static std::vector<int32_t> lane_program(const rt_sites *s)
+static std::vector<int32_t> lane_program(const rt_sites *s, int64_t slot_bytes)
 {
     enum { INTERNAL = 1, X_CUR = 2, FIRST = 4, ROOT = 8, SPILL = 16, DST_CUR = 32, OBS = 64 };
-    const int64_t n = s->model->n;
     std::vector<int32_t> prog(s->ops.size() * 4, 0);
     int cur = -1;                              // slot cached in registers
     for (size_t k = 0; k < s->ops.size(); ++k) {
@@ -545,17 +544,17 @@ static std::vector<int32_t> lane_program(const rt_sites *s)
         if (op.pop >= 0) {
             flags |= INTERNAL;
             if (cur == op.pop) { flags |= X_CUR; cur = -1; }
-            else pop_off = (int)(op.pop * n * 512);
+            else pop_off = (int)(op.pop * slot_bytes);
         }
         if (op.dst < 0) flags |= ROOT;
         else {
             const int d = op.dst & 255;
             if (op.dst >> 8) {
                 flags |= FIRST;
-                if (cur >= 0) { flags |= SPILL; spill_off = (int)(cur * n * 512); }
+                if (cur >= 0) { flags |= SPILL; spill_off = (int)(cur * slot_bytes); }
                 cur = d;
             } else if (cur == d) flags |= DST_CUR;
-            else dst_off = (int)(d * n * 512);
+            else dst_off = (int)(d * slot_bytes);
         }
         prog[4 * k] = flags;
         prog[4 * k + 1] = pop_off;
@@ -601,8 +600,10 @@ static int sites_alloc(rt_sites *s, bool generic)
     if (e == hipSuccess)
         e = hipMemcpy(s->d_ops, s->ops.data(), s->ops.size() * sizeof(rt_op),
                       hipMemcpyHostToDevice);
-    if (e == hipSuccess && s->layout == RT_LAYOUT_LANE && !generic) {
-        const std::vector<int32_t> prog = lane_program(s);
+    if (e == hipSuccess && !generic) {
+        // lane family: N doubles per slot and lane; MFMA family: 4 (own rows)
+        const std::vector<int32_t> prog =
+            lane_program(s, s->layout == RT_LAYOUT_LANE ? n * 512 : 2048);
         e = hipMalloc((void **)&s->d_lane_ops, prog.size() * 4);
         if (e == hipSuccess)
             e = hipMemcpy(s->d_lane_ops, prog.data(), prog.size() * 4, hipMemcpyHostToDevice);

@@ -465,9 +465,9 @@ prune_lanedma_kernel(const double *__restrict__ Pord,   // [nops][N][N]
 template <int NT, int KS>
 __global__ void __launch_bounds__((NT == 3 ? 3 : 4) * 64)
 prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
-                  const rt_op *__restrict__ ops, int nops,
+                  const int4_t *__restrict__ prog, int nops,   // LOP_* program
                   const double *__restrict__ obs, int K,  // [blk16][K][KP][64][2]
-                  const double *__restrict__ root_w, int n, int depth,
+                  const double *__restrict__ root_w, int n, int lds_slots,
                   double *__restrict__ loglik, int *__restrict__ status,
                   double *__restrict__ partial, long nsites, long nblocks16)
 {
@@ -485,12 +485,13 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
     const bool live = gt < nblocks16;
     const long blk = live ? gt : nblocks16 - 1;           // keep barriers uniform
 
-    double *xbuf = (double *)smem;                         // [2][TILES][XB]
-    double *red = xbuf + 2 * TILES * XB;                   // [TILES][NT][16]
-    double *stack = red + TILES * NT * 16 +
-                    (size_t)wave * depth * 256 + lane;     // [slot][4][64]
+    double *xb = (double *)smem + tile * XB;               // [TILES][XB], single buffer
+    double *red = (double *)smem + TILES * XB;             // [TILES][NT][16]
+    // this wave's rows of the spilled accumulators: [slot][4][64], + lane
+    unsigned char *stack = (unsigned char *)(red + TILES * NT * 16) +
+                           (size_t)wave * lds_slots * 2048 + lane * 8;
 
-    const RT_CONST_AS int4_t *ops_c = (const RT_CONST_AS int4_t *)ops;
+    const RT_CONST_AS int4_t *prog_c = (const RT_CONST_AS int4_t *)prog;
     // A fragments of this wave: [op][m][q][lane][2]
     const double *ag = Pfrag + ((size_t)m * KP * 64 + lane) * 2;
     constexpr size_t ASTRIDE = (size_t)NT * KP * 128;
@@ -498,23 +499,24 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
     const double *og = obs + (size_t)blk * K * (KP * 128) + lane * 2;
 
     double an[2 * KP];            // A fragments of the NEXT step
-    double on[4];                 // own rows of the next step's observation
+    double on[4];                 // own rows of the next observation in the stream
 #pragma unroll
     for (int j = 0; j < 4; ++j) on[j] = 1.0;
 
-    rt_op op = load_op(ops_c, 0);
+    int4_t op = prog_c[0];
+    int knext = 0;                // stream position `on` holds / will hold
 #pragma unroll
     for (int q = 0; q < KP; ++q) {
         const double2 v = *(const double2 *)(ag + q * 128);
         an[2 * q] = v.x;
         an[2 * q + 1] = v.y;
     }
-    if (op.obs >= 0) {
+    if (K > 0) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int q = 2 * m + h;
             double2 v = {0.0, 0.0};
-            if (q < KP) v = *(const double2 *)(og + ((size_t)op.obs * KP + q) * 128);
+            if (q < KP) v = *(const double2 *)(og + (size_t)q * 128);
             on[2 * h] = v.x;
             on[2 * h + 1] = v.y;
         }
@@ -522,22 +524,30 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
 
     double lik = 0.0;
     bool negative = false;
+    double cur[4] = {1.0, 1.0, 1.0, 1.0};      // register-cached top accumulator
 
     for (int i = 0; i < nops; ++i) {
+        const int flags = op.x;
         // own rows of L_v = (accumulator of v) * (observation at v)
         double x[4];
-        if (RT_OP_IS_INTERNAL(op)) {
+        if (flags & LOP_INTERNAL) {
+            if (flags & LOP_X_CUR) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x[r] = stack[(op.pop * 4 + r) * 64];
+                for (int r = 0; r < 4; ++r) x[r] = cur[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] = *(const double *)(stack + op.y + r * 512);
+            }
+            if (flags & LOP_OBS) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] *= on[r];
+            }
         } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x[r] = 1.0;
+            for (int r = 0; r < 4; ++r) x[r] = (flags & LOP_OBS) ? on[r] : 1.0;
         }
-        if (op.obs >= 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) x[r] *= on[r];
-        }
-        if (RT_OP_IS_ROOT(op)) {
+        if (flags & LOP_OBS) knext += 1;
+        if (flags & LOP_ROOT) {
             double s = 0.0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -558,7 +568,7 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
             }
             break;
         }
-        double *xb = xbuf + ((i & 1) * TILES + tile) * XB;
+        __syncthreads();      // every wave is done reading the previous step's x
 #pragma unroll
         for (int r = 0; r < 4; ++r) xb[((4 * m + r) * 64) + lane] = x[r];
 
@@ -570,8 +580,8 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
 
         // start everything the next step needs
         const int inext = (i + 1 < nops) ? i + 1 : i;
-        const rt_op opn = load_op(ops_c, inext);
-        if (!RT_OP_IS_ROOT(opn)) {
+        const int4_t opn = prog_c[inext];
+        if (!(opn.x & LOP_ROOT)) {
 #pragma unroll
             for (int q = 0; q < KP; ++q) {
                 const double2 v = *(const double2 *)(ag + (size_t)inext * ASTRIDE + q * 128);
@@ -579,12 +589,12 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
                 an[2 * q + 1] = v.y;
             }
         }
-        if (opn.obs >= 0) {
+        if ((flags & LOP_OBS) && knext < K) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int q = 2 * m + h;
                 double2 v = {0.0, 0.0};
-                if (q < KP) v = *(const double2 *)(og + ((size_t)opn.obs * KP + q) * 128);
+                if (q < KP) v = *(const double2 *)(og + ((size_t)knext * KP + q) * 128);
                 on[2 * h] = v.x;
                 on[2 * h + 1] = v.y;
             }
@@ -597,13 +607,22 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], b, acc, 0, 0, 0);
         }
 
-        double *d = stack + (op.dst & 255) * 256;
-        if (RT_OP_IS_FIRST(op)) {
+        if (flags & LOP_FIRST) {
+            if (flags & LOP_SPILL) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) d[r * 64] = acc[r];
+                for (int r = 0; r < 4; ++r) *(double *)(stack + op.w + r * 512) = cur[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cur[r] = acc[r];
+        } else if (flags & LOP_DST_CUR) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cur[r] *= acc[r];
         } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) d[r * 64] *= acc[r];
+            for (int r = 0; r < 4; ++r) {
+                double *d = (double *)(stack + op.z + r * 512);
+                *d = *d * acc[r];
+            }
         }
         op = opn;
     }
@@ -982,16 +1001,19 @@ static int launch_mfma_inst(rt_model *m, rt_sites *s)
 {
     constexpr int WAVES = (NT == 3) ? 3 : 4;
     constexpr int TILES = WAVES / NT;
-    const int depth = std::max(1, m->max_depth);
-    const int lds = (2 * TILES * NT * 4 * 64 + TILES * NT * 16) * 8 + WAVES * depth * 2048;
+    // the deepest accumulator never leaves the register cache
+    const int lds_slots = std::max(1, m->max_depth - 1);
+
+    const int lds = (TILES * NT * 4 * 64 + TILES * NT * 16) * 8 + WAVES * lds_slots * 2048;
     const unsigned grid = (unsigned)((s->nblocks + TILES - 1) / TILES);
     auto kern = prune_mfma_kernel<NT, KS>;
     RT_HIP(hipFuncSetAttribute((const void *)kern,
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, m->ctx->stream,
-                       m->d_Pfrag, s->d_ops, (int)s->ops.size(), s->d_obs,
-                       (int)s->nobs, m->d_root, (int)m->n, depth, s->d_loglik,
-                       s->d_status, s->d_partial, (long)s->nsites, (long)s->nblocks);
+                       m->d_Pfrag, (const int4_t *)s->d_lane_ops, (int)s->ops.size(),
+                       s->d_obs, (int)s->nobs, m->d_root, (int)m->n, lds_slots,
+                       s->d_loglik, s->d_status, s->d_partial, (long)s->nsites,
+                       (long)s->nblocks);
     return RT_OK;
 }
 
