@@ -534,27 +534,43 @@ extern "C" int rt_sites_destroy(rt_sites *s)
 // turn slots into LDS byte offsets (see LOP_* in prune.hip).
 static std::vector<int32_t> lane_program(const rt_sites *s, int64_t slot_bytes)
 {
-    enum { INTERNAL = 1, X_CUR = 2, FIRST = 4, ROOT = 8, SPILL = 16, DST_CUR = 32, OBS = 64 };
+    enum { INTERNAL = 1, X_CUR = 2, FIRST = 4, ROOT = 8, SPILL = 16, DST_CUR = 32, OBS = 64,
+           FAST = 128 };
     std::vector<int32_t> prog(s->ops.size() * 4, 0);
     int cur = -1;                              // slot cached in registers
     for (size_t k = 0; k < s->ops.size(); ++k) {
         const rt_op &op = s->ops[k];
         int flags = 0, pop_off = 0, dst_off = 0, spill_off = 0;
+        bool x_ok;                             // x is the observation or the cache
         if (op.obs >= 0) flags |= OBS;
         if (op.pop >= 0) {
             flags |= INTERNAL;
-            if (cur == op.pop) { flags |= X_CUR; cur = -1; }
-            else pop_off = (int)(op.pop * slot_bytes);
+            if (cur == op.pop) { flags |= X_CUR; cur = -1; x_ok = op.obs < 0; }
+            else { pop_off = (int)(op.pop * slot_bytes); x_ok = false; }
+        } else {
+            x_ok = op.obs >= 0;
         }
         if (op.dst < 0) flags |= ROOT;
         else {
             const int d = op.dst & 255;
+            // the parent's own step follows immediately <=> this is its last child
+            const bool parent_next = k + 1 < s->ops.size() && s->ops[k + 1].pop == d;
             if (op.dst >> 8) {
                 flags |= FIRST;
                 if (cur >= 0) { flags |= SPILL; spill_off = (int)(cur * slot_bytes); }
                 cur = d;
-            } else if (cur == d) flags |= DST_CUR;
-            else dst_off = (int)(d * slot_bytes);
+                if (x_ok) flags |= FAST;
+            } else if (cur == d) {
+                flags |= DST_CUR;
+                if (x_ok) flags |= FAST;
+            } else {
+                dst_off = (int)(d * slot_bytes);
+                if (x_ok && cur < 0 && parent_next) {
+                    // un-spill: cur = lds[d] * t; the LDS copy is dead afterwards
+                    flags |= FAST;
+                    cur = d;
+                }
+            }
         }
         prog[4 * k] = flags;
         prog[4 * k + 1] = pop_off;
@@ -659,7 +675,7 @@ extern "C" int rt_sites_create(rt_model *m, int64_t nsites, int kind, int64_t no
     // tuning knobs of the lane family (A/B measurements)
     if (const char *v = getenv("RAOTEH_LANE_VARIANT")) s->lane_dma = strcmp(v, "dma") == 0;
     if (const char *r = getenv("RAOTEH_LANE_RING")) s->lane_ring = atoi(r);
-    else s->lane_ring = s->lane_dma ? 5 : 8;
+    else s->lane_ring = s->lane_dma ? 3 : 8;
     int rc = sites_alloc(s, generic);
     if (rc == RT_OK) rc = rt_sites_pack(s, kind, src_of_k.data(), data);
     if (rc != RT_OK) {

@@ -116,7 +116,11 @@ __device__ __forceinline__ void finish_site(double lik, bool negative,
 // In a cherry (two leaves + parent) nothing touches LDS at all.
 enum {
     LOP_INTERNAL = 1, LOP_X_CUR = 2, LOP_FIRST = 4, LOP_ROOT = 8, LOP_SPILL = 16,
-    LOP_DST_CUR = 32, LOP_OBS = 64
+    LOP_DST_CUR = 32, LOP_OBS = 64,
+    // fast path (set by the host for the common steps): x is the observation
+    // (leaf) or the register cache (internal node), and the result stays in the
+    // register cache: cur = t * {1 | cur | lds[dst_off]}
+    LOP_FAST = 128
 };
 
 template <int N, bool PLDS>
@@ -129,15 +133,14 @@ struct LaneCtx {
     int nops;
     int i;                         // index of the current step
     int4_t op;                     // current step: {flags, pop_off, dst_off, spill_off}
-    double p[N * N];               // its transition matrix (SGPRs)
+    int4_t opn;                    // the step after it (fetched a whole step ahead)
+    double p[N * N];               // transition matrix of the current step
     double cur[N];                 // register-cached top accumulator
     double lik;
     bool negative;
 
-    __device__ __forceinline__ void load_current()
+    __device__ __forceinline__ void load_p(int ii)
     {
-        const int ii = i < nops ? i : nops - 1;
-        op = ops_c[ii];
         if (PLDS) {
             // wave-uniform address: every ds_read is a broadcast
 #pragma unroll
@@ -146,6 +149,14 @@ struct LaneCtx {
 #pragma unroll
             for (int j = 0; j < N * N; ++j) p[j] = P_c[(long)ii * N * N + j];
         }
+    }
+
+    __device__ __forceinline__ void load_current()
+    {
+        const int last = nops - 1;
+        op = ops_c[i < last ? i : last];
+        opn = ops_c[i + 1 < last ? i + 1 : last];
+        load_p(i < last ? i : last);
     }
 
     __device__ __forceinline__ double lds_get(int off, int j) const
@@ -163,6 +174,38 @@ struct LaneCtx {
     __device__ __forceinline__ void step(const double (&o)[N])
     {
         const int flags = op.x;
+        if (flags & LOP_FAST) {
+            if (flags & LOP_SPILL) {
+#pragma unroll
+                for (int r = 0; r < N; ++r) lds_put(op.w, r, cur[r]);
+            }
+            double t[N];
+#pragma unroll
+            for (int r = 0; r < N; ++r) {
+                double sacc = p[r * N] * (HAS_OBS ? o[0] : cur[0]);
+#pragma unroll
+                for (int j = 1; j < N; ++j)
+                    sacc = fma(p[r * N + j], HAS_OBS ? o[j] : cur[j], sacc);
+                t[r] = sacc;
+            }
+            if (flags & LOP_FIRST) {
+#pragma unroll
+                for (int r = 0; r < N; ++r) cur[r] = t[r];
+            } else if (flags & LOP_DST_CUR) {
+#pragma unroll
+                for (int r = 0; r < N; ++r) cur[r] *= t[r];
+            } else {                       // un-spill: the parent's step is next
+#pragma unroll
+                for (int r = 0; r < N; ++r) cur[r] = lds_get(op.z, r) * t[r];
+            }
+            i += 1;
+            const int last = nops - 1;
+            const int4_t opnn = ops_c[i + 1 < last ? i + 1 : last];
+            load_p(i < last ? i : last);
+            op = opn;
+            opn = opnn;
+            return;
+        }
         double x[N];
         if (flags & LOP_INTERNAL) {
             if (flags & LOP_X_CUR) {
@@ -213,10 +256,16 @@ struct LaneCtx {
                 for (int r = 0; r < N; ++r) lds_put(op.z, r, lds_get(op.z, r) * t[r]);
             }
         }
-        // fetch the next step (single SGPR buffer: the FMAs above have already
-        // read p when these scalar loads are issued)
+        // Fetch ahead.  p is a single buffer: the FMAs above have read it, so the
+        // next step's matrix can be requested now; the schedule entry is fetched
+        // TWO steps ahead so that the branchy head of the next step never waits
+        // for the scalar cache.
         i += 1;
-        load_current();
+        const int last = nops - 1;
+        const int4_t opnn = ops_c[i + 1 < last ? i + 1 : last];
+        load_p(i < last ? i : last);
+        op = opn;
+        opn = opnn;
     }
 
     // run the steps that carry no observation
@@ -237,12 +286,15 @@ __global__ void __launch_bounds__(PLDS ? 256 : 64)
 prune_lane_kernel(const double *__restrict__ Pord,   // [nops][N][N]
                   const int4_t *__restrict__ ops, int nops,   // lane program
                   const double *__restrict__ obs, int K,  // [blk][K][NP/2][64][2]
-                  const double *__restrict__ root_w, int depth,
+                  const double *__restrict__ root_w, int depth_arg,
                   double *__restrict__ loglik, int *__restrict__ status,
                   double *__restrict__ partial, long nsites, long nblocks)
 {
     constexpr int NP = (N + 1) & ~1;
     constexpr int HP = NP / 2;                // 16-byte pairs per site
+    // timing experiment only (RAOTEH_LANE_NOLOAD): skip the HBM stream
+    const bool noload = depth_arg < 0;
+    const int depth = noload ? -depth_arg : depth_arg;
     constexpr int WPB = PLDS ? 4 : 1;         // waves per workgroup
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -280,7 +332,7 @@ prune_lane_kernel(const double *__restrict__ Pord,   // [nops][N][N]
     for (int j = 0; j < R; ++j) {
 #pragma unroll
         for (int h = 0; h < HP; ++h) ring[j][h] = make_double2(1.0, 1.0);
-        if (j < K) {
+        if (j < K && !noload) {
 #pragma unroll
             for (int h = 0; h < HP; ++h) ring[j][h] = g[((size_t)j * HP + h) * 64];
         }
@@ -298,7 +350,7 @@ prune_lane_kernel(const double *__restrict__ Pord,   // [nops][N][N]
                 for (int q = 0; q < N; ++q)
                     o[q] = (q & 1) ? ring[j][q >> 1].y : ring[j][q >> 1].x;
                 C.template step<true>(o);
-                if (k + R < K) {
+                if (k + R < K && !noload) {
 #pragma unroll
                     for (int h = 0; h < HP; ++h)
                         ring[j][h] = g[((size_t)(k + R) * HP + h) * 64];
@@ -320,36 +372,53 @@ prune_lane_kernel(const double *__restrict__ Pord,   // [nops][N][N]
 }
 
 // ---------------------------------------------------------------------------
-// n <= 4, variant B: the same walk with the leaf vectors staged through an
-// LDS-DMA ring (global_load_lds, 1 KiB per wave-instruction, data layout
-// [block][slot][lane][np]).  Kept for A/B measurements (RAOTEH_LANE_VARIANT=dma).
+// n <= 4, variant B: the same walk (LaneCtx) with the leaf vectors landing in an
+// LDS ring by LDS-DMA (global_load_lds, 1 KiB per wave-instruction, data layout
+// [block][slot][lane][np]).  Data in flight lives in LDS, not in VGPRs, so the
+// kernel owns its vmcnt waits: exactly the slots younger than the one being
+// consumed stay outstanding ((R-1)*IPS instructions), nothing is ever drained.
 // ---------------------------------------------------------------------------
 
 template <int N, int R>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 prune_lanedma_kernel(const double *__restrict__ Pord,   // [nops][N][N]
-                  const rt_op *__restrict__ ops, int nops,
-                  const double *__restrict__ obs, int K,
-                  const double *__restrict__ root_w,
-                  double *__restrict__ loglik, int *__restrict__ status,
-                  double *__restrict__ partial, long nsites)
+                     const int4_t *__restrict__ ops, int nops,   // lane program
+                     const double *__restrict__ obs, int K,  // [blk][K][64][NP]
+                     const double *__restrict__ root_w, int depth,
+                     double *__restrict__ loglik, int *__restrict__ status,
+                     double *__restrict__ partial, long nsites, long nblocks)
 {
-    constexpr int NP = (N + 1) & ~1;          // states per site in HBM (even)
-    constexpr int SLOT = 64 * NP * 8;         // bytes of one obs slot
+    constexpr int NP = (N + 1) & ~1;
+    constexpr int SLOT = 64 * NP * 8;         // bytes of one obs slot of one wave
     constexpr int IPS = SLOT / 1024;          // LDS-DMA instructions per slot
-    constexpr int NN = N * N;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int lane = threadIdx.x;
-    const long gw = blockIdx.x;               // site block of this wave
-    unsigned char *ring = smem;
-    double *stack = (double *)(smem + R * SLOT) + lane;   // [slot][N][64]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long gw = (long)blockIdx.x * 4 + wave;      // site block of this wave
+
+    LaneCtx<N, true> C;
+    double *pl = (double *)smem;
+    for (int e = threadIdx.x; e < nops * N * N; e += 256) pl[e] = Pord[e];
+    unsigned char *wbase = smem + (((size_t)nops * N * N * 8 + 15) & ~(size_t)15) +
+                           (size_t)wave * (R * SLOT + depth * N * 512);
+    __syncthreads();
+    if (gw >= nblocks) return;                // wave-uniform, after the only barrier
+    unsigned char *ring = wbase;
+    C.P_l = pl;
+    C.ops_c = (const RT_CONST_AS int4_t *)ops;
+    C.P_c = (const RT_CONST_AS double *)Pord;
+    C.w_c = (const RT_CONST_AS double *)root_w;
+    C.stack = wbase + R * SLOT + lane * 8;
+    C.nops = nops;
+    C.i = 0;
+    C.lik = 0.0;
+    C.negative = false;
+#pragma unroll
+    for (int j = 0; j < N; ++j) C.cur[j] = 1.0;
+
     const unsigned char *g =
         (const unsigned char *)obs + (size_t)gw * K * SLOT + lane * 16;
-    const RT_CONST_AS int4_t *ops_c = (const RT_CONST_AS int4_t *)ops;
-    const RT_CONST_AS double *P_c = (const RT_CONST_AS double *)Pord;
-    const RT_CONST_AS double *w_c = (const RT_CONST_AS double *)root_w;
-
     // prologue: fill the ring
 #pragma unroll
     for (int k = 0; k < R; ++k) {
@@ -362,80 +431,33 @@ prune_lanedma_kernel(const double *__restrict__ Pord,   // [nops][N][N]
         }
     }
 
-    double lik = 0.0;
-    bool negative = false;
-    rt_op op = load_op(ops_c, 0);
-
-    for (int i = 0; i < nops; ++i) {
-        // this step's transition matrix: scalar loads, consumed as FMA operands
-        double p[NN];
+    C.load_current();
+    C.run_plain();
+    int rs = 0;                               // ring slot of stream position k
+    for (int k = 0; k < K; ++k) {
+        if (k + R <= K)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 1) * IPS) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const double *o_l = (const double *)(ring + rs * SLOT) + lane * NP;
+        double o[N];
 #pragma unroll
-        for (int j = 0; j < NN; ++j) p[j] = P_c[(long)i * NN + j];
-        const int inext = (i + 1 < nops) ? i + 1 : i;
-        const rt_op opn = load_op(ops_c, inext);
-
-        double x[N];
-        if (RT_OP_IS_INTERNAL(op)) {
+        for (int j = 0; j < N; ++j) o[j] = o_l[j];
+        C.template step<true>(o);
+        if (k + R < K) {
 #pragma unroll
-            for (int j = 0; j < N; ++j) x[j] = stack[(op.pop * N + j) * 64];
-        } else {
-#pragma unroll
-            for (int j = 0; j < N; ++j) x[j] = 1.0;
+            for (int j = 0; j < IPS; ++j)
+                __builtin_amdgcn_global_load_lds(
+                    (glb_void *)(g + (size_t)(k + R) * SLOT + j * 1024),
+                    (lds_void *)(ring + rs * SLOT + j * 1024), 16, 0, 0);
         }
-        if (op.obs >= 0) {
-            const int k = op.obs;
-            if (k + R <= K)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 1) * IPS) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int rs = k % R;
-            const double *o = (const double *)(ring + rs * SLOT) + lane * NP;
-            double ov[NP];
-#pragma unroll
-            for (int j = 0; j < NP; ++j) ov[j] = o[j];
-#pragma unroll
-            for (int j = 0; j < N; ++j) x[j] *= ov[j];
-            if (k + R < K) {
-#pragma unroll
-                for (int j = 0; j < IPS; ++j)
-                    __builtin_amdgcn_global_load_lds(
-                        (glb_void *)(g + (size_t)(k + R) * SLOT + j * 1024),
-                        (lds_void *)(ring + rs * SLOT + j * 1024), 16, 0, 0);
-            }
-        }
-        if (RT_OP_IS_ROOT(op)) {
-            // root reduction (_mc0_dense.py:184-209)
-            double s = 0.0;
-#pragma unroll
-            for (int j = 0; j < N; ++j) {
-                negative |= x[j] < 0.0;
-                s += w_c[j] * fmax(x[j], 0.0);
-            }
-            lik = s;
-        } else {
-            double t[N];
-#pragma unroll
-            for (int r = 0; r < N; ++r) {
-                double s = p[r * N] * x[0];
-#pragma unroll
-                for (int j = 1; j < N; ++j) s = fma(p[r * N + j], x[j], s);
-                t[r] = s;
-            }
-            double *d = stack + (op.dst & 255) * N * 64;
-            if (RT_OP_IS_FIRST(op)) {
-#pragma unroll
-                for (int r = 0; r < N; ++r) d[r * 64] = t[r];
-            } else {
-#pragma unroll
-                for (int r = 0; r < N; ++r) d[r * 64] *= t[r];
-            }
-        }
-        op = opn;
+        rs = (rs + 1 == R) ? 0 : rs + 1;
+        C.run_plain();
     }
 
     const long site = gw * 64 + lane;
     double sum, nzero;
-    finish_site(lik, negative, site < nsites, loglik, status, site, sum, nzero);
+    finish_site(C.lik, C.negative, site < nsites, loglik, status, site, sum, nzero);
     sum = wave_sum(sum);
     nzero = wave_sum(nzero);
     if (lane == 0) {
@@ -617,6 +639,10 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
         } else if (flags & LOP_DST_CUR) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) cur[r] *= acc[r];
+        } else if (flags & LOP_FAST) {     // un-spill: the parent's step is next
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                cur[r] = *(const double *)(stack + op.z + r * 512) * acc[r];
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -924,13 +950,15 @@ int rt_sites_pack(rt_sites *s, int kind, const int64_t *src_of_k, const void *da
 template <int N, int R>
 static int launch_lane_reg(rt_model *m, rt_sites *s, bool *plds_out)
 {
-    const int depth = std::max(1, m->max_depth);
+    // the deepest accumulator never leaves the register cache
+    const int depth = std::max(1, m->max_depth - 1);
     const int nops = (int)s->ops.size();
     const int stack = depth * N * 512;                        // per wave
     const int ptab = (nops * N * N * 8 + 15) & ~15;
     // P table in LDS when two 4-wave workgroups still fit on a CU
     const bool plds = ptab + 4 * stack <= 80 * 1024 && !getenv("RAOTEH_LANE_NO_PLDS");
     *plds_out = plds;
+    const int depth_arg = getenv("RAOTEH_LANE_NOLOAD") ? -depth : depth;
     if (plds) {
         const int lds = ptab + 4 * stack;
         auto kern = prune_lane_kernel<N, R, true>;
@@ -938,7 +966,7 @@ static int launch_lane_reg(rt_model *m, rt_sites *s, bool *plds_out)
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)((s->nblocks + 3) / 4)), dim3(256), lds,
                            m->ctx->stream, m->d_Pfrag, (const int4_t *)s->d_lane_ops, nops,
-                           s->d_obs, (int)s->nobs, m->d_root, depth, s->d_loglik,
+                           s->d_obs, (int)s->nobs, m->d_root, depth_arg, s->d_loglik,
                            s->d_status, s->d_partial, (long)s->nsites, (long)s->nblocks);
     } else {
         auto kern = prune_lane_kernel<N, R, false>;
@@ -956,15 +984,17 @@ template <int N, int R>
 static int launch_lane_dma(rt_model *m, rt_sites *s)
 {
     constexpr int NP = (N + 1) & ~1;
-    const int depth = std::max(1, m->max_depth);
-    const int lds = R * 64 * NP * 8 + depth * N * 512;
+    const int depth = std::max(1, m->max_depth - 1);
+    const int nops = (int)s->ops.size();
+    const int ptab = (nops * N * N * 8 + 15) & ~15;
+    const int lds = ptab + 4 * (R * 64 * NP * 8 + depth * N * 512);
     auto kern = prune_lanedma_kernel<N, R>;
     RT_HIP(hipFuncSetAttribute((const void *)kern,
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)s->nblocks), dim3(64), lds, m->ctx->stream,
-                       m->d_Pfrag, s->d_ops, (int)s->ops.size(), s->d_obs, (int)s->nobs,
-                       m->d_root, s->d_loglik, s->d_status, s->d_partial,
-                       (long)s->nsites);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((s->nblocks + 3) / 4)), dim3(256), lds,
+                       m->ctx->stream, m->d_Pfrag, (const int4_t *)s->d_lane_ops, nops,
+                       s->d_obs, (int)s->nobs, m->d_root, depth, s->d_loglik, s->d_status,
+                       s->d_partial, (long)s->nsites, (long)s->nblocks);
     return RT_OK;
 }
 
@@ -977,10 +1007,11 @@ static int launch_lane(rt_model *m, rt_sites *s, const char **name)
     bool plds = false;
     if (s->lane_dma) {
         switch (R) {
+        case 2: rc = launch_lane_dma<N, 2>(m, s); break;
         case 4: rc = launch_lane_dma<N, 4>(m, s); break;
         case 5: rc = launch_lane_dma<N, 5>(m, s); break;
         case 6: rc = launch_lane_dma<N, 6>(m, s); break;
-        default: rc = launch_lane_dma<N, 8>(m, s); break;
+        default: rc = launch_lane_dma<N, 3>(m, s); break;
         }
     } else {
         switch (R) {
