@@ -673,6 +673,15 @@ extern "C" int rt_sites_create(rt_model *m, int64_t nsites, int kind, int64_t no
     const bool generic = g_force_generic || m->max_depth > RT_FAST_MAX_DEPTH;
     s->layout = (generic || m->n <= 4) ? RT_LAYOUT_LANE : RT_LAYOUT_MFMA;
     // tuning knobs of the lane family (A/B measurements)
+    // Default: leaf vectors through the LDS-DMA ring (3 slots) when two 4-wave
+    // workgroups (shared P table + rings + accumulator stacks) fit on a CU;
+    // otherwise the VGPR-ring variant, whose LDS need is only the stacks.
+    if (s->layout == RT_LAYOUT_LANE && !generic) {
+        const int64_t np = (m->n + 1) & ~1ll;
+        const int64_t stack = std::max<int64_t>(1, m->max_depth - 1) * m->n * 512;
+        const int64_t ptab = ((int64_t)m->ops.size() * m->n * m->n * 8 + 15) & ~15ll;
+        s->lane_dma = ptab + 4 * (3 * 64 * np * 8 + stack) <= 80 * 1024;
+    }
     if (const char *v = getenv("RAOTEH_LANE_VARIANT")) s->lane_dma = strcmp(v, "dma") == 0;
     if (const char *r = getenv("RAOTEH_LANE_RING")) s->lane_ring = atoi(r);
     else s->lane_ring = s->lane_dma ? 3 : 8;

@@ -988,6 +988,11 @@ static int launch_lane_dma(rt_model *m, rt_sites *s)
     const int nops = (int)s->ops.size();
     const int ptab = (nops * N * N * 8 + 15) & ~15;
     const int lds = ptab + 4 * (R * 64 * NP * 8 + depth * N * 512);
+    if (lds > 160 * 1024) {
+        rt_set_error("LDS-DMA lane kernel: %d bytes of LDS needed (tree too large); "
+                     "unset RAOTEH_LANE_VARIANT", lds);
+        return RT_ERR_UNSUPPORTED;
+    }
     auto kern = prune_lanedma_kernel<N, R>;
     RT_HIP(hipFuncSetAttribute((const void *)kern,
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
