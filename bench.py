@@ -182,7 +182,9 @@ def main():
         step(j)
     ctx.sync()
     ll0, st0 = model.fetch_log_likelihoods(batch0)
-    ctx.set_timing(True)
+    # HIP events on the kernels' own stream, sampled: every 8th launch of each
+    # kernel (an event pair per kernel per step would cost ~22 us per step)
+    ctx.set_timing(0 if os.environ.get('RAOTEH_BENCH_NO_EVENTS') else 8)
     ctx.reset_timing()
 
     ctl.barrier()
@@ -215,6 +217,8 @@ def main():
     alg_bytes = nsites * (8.0 * n * nleaves + 8.0)
     alg_flops = nsites * (2.0 * n * n * nedges + n * nedges + 2.0 * n)
     avg_prune_s = prune_ms / max(prune_cnt, 1) * 1e-3
+    if prune_cnt == 0:          # events disabled (overhead experiment only)
+        avg_prune_s = float('nan')
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'traffic_%s.json' % args.workload)
     if os.path.exists(tpath):
@@ -232,7 +236,7 @@ def main():
                     unit='TFLOP/s', frac=achieved / F64_MFMA_PEAK_TFLOPS,
                     traffic=traffic)
     roof.update(kernel=prune_name, avg_kernel_us=avg_prune_s * 1e6,
-                launches=prune_cnt, algorithmic_bytes_per_launch=alg_bytes,
+                launches_timed=prune_cnt, algorithmic_bytes_per_launch=alg_bytes,
                 algorithmic_flops_per_launch=alg_flops,
                 hbm_gbs=alg_bytes / avg_prune_s / 1e9)
 

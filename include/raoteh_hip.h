@@ -78,7 +78,7 @@ int         rt_ctx_sync(rt_ctx *ctx);         /* wait for the ctx stream      */
  * the kernels are launched on).  rt_ctx_kernel_time drains finished events
  * and returns the accumulated device time and launch count since the last
  * reset; `name` receives a static string with the kernel variant used.      */
-int         rt_ctx_set_timing(rt_ctx *ctx, int enabled);
+int         rt_ctx_set_timing(rt_ctx *ctx, int enabled); /* N > 1: every N-th launch */
 int         rt_ctx_reset_timing(rt_ctx *ctx);
 int         rt_ctx_kernel_time(rt_ctx *ctx, int kernel, double *total_ms,
                                int64_t *launches, const char **name);

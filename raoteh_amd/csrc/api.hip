@@ -113,7 +113,10 @@ extern "C" int rt_ctx_destroy(rt_ctx *ctx)
 extern "C" int rt_ctx_set_timing(rt_ctx *ctx, int enabled)
 {
     RT_REQUIRE(ctx, "null context");
+    // enabled = N > 0: time every N-th launch of each kernel (events cost a few
+    // microseconds each, so a benchmark samples instead of timing every launch)
     ctx->timing = enabled != 0;
+    ctx->timing_period = enabled > 1 ? enabled : 1;
     return RT_OK;
 }
 
@@ -125,6 +128,7 @@ extern "C" int rt_ctx_reset_timing(rt_ctx *ctx)
         drain_slot(s, true);
         s.total_ms = 0.0;
         s.launches = 0;
+        s.seen = 0;
     }
     return RT_OK;
 }
@@ -148,6 +152,7 @@ void rt_time_begin(rt_ctx *ctx, int kernel, const char *name, hipEvent_t *start)
     rt_timing_slot &s = ctx->slots[kernel];
     if (name && name[0]) s.name = name;
     if (!ctx->timing) return;
+    if ((s.seen++ % ctx->timing_period) != 0) return;
     hipEvent_t ev = nullptr;
     if (!s.pool.empty()) { ev = s.pool.back(); s.pool.pop_back(); }
     else if (hipEventCreate(&ev) != hipSuccess) return;

@@ -48,6 +48,7 @@ struct rt_timing_slot {
     std::vector<hipEvent_t> pool;
     double total_ms = 0.0;
     int64_t launches = 0;
+    int64_t seen = 0;
     const char *name = "";
 };
 
@@ -56,6 +57,7 @@ struct rt_ctx {
     hipStream_t stream = nullptr;
     int num_cus = 0;
     bool timing = false;
+    int timing_period = 1;
     rt_timing_slot slots[RT_K_COUNT];
     void *comm = nullptr;          // ncclComm_t
     void *rccl = nullptr;          // dlopen handle

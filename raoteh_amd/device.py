@@ -75,7 +75,9 @@ class Context(object):
         _lib.check(_lib.lib().rt_ctx_sync(self._h))
 
     def set_timing(self, enabled):
-        _lib.check(_lib.lib().rt_ctx_set_timing(self._h, int(bool(enabled))))
+        """False/0: off; True/1: every launch; N > 1: every N-th launch of each
+        kernel (each HIP event pair costs a few microseconds of stream time)."""
+        _lib.check(_lib.lib().rt_ctx_set_timing(self._h, int(enabled)))
 
     def reset_timing(self):
         _lib.check(_lib.lib().rt_ctx_reset_timing(self._h))
