@@ -25,6 +25,8 @@
 //   [step][n][n]; MFMA family: A-fragment order), which removes a launch.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace {
 
 __constant__ double c_theta[5] = {1.495585217958292e-2, 2.539398330063230e-1,
@@ -370,6 +372,197 @@ expm_kernel(int n, const double *__restrict__ Q, const int *__restrict__ qidx,
     }
 }
 
+// ---------------------------------------------------------------------------
+// n <= 4: one LANE per matrix, everything in registers (compile-time N, fully
+// unrolled, statically indexed).  A 64-leaf 4-state tree has 126 matrices: the
+// workgroup-per-matrix kernel above spends its time in barriers there, and the
+// tolerance processes of the reference (n = 3, a different Q on every edge,
+// _tmjp.py:863-893) want exactly this shape.  Same algorithm (Higham 2005);
+// the solve is Gaussian elimination with partial pivoting by predicated row
+// swaps + back substitution.
+// ---------------------------------------------------------------------------
+
+template <int N>
+struct SmallMat {
+    double a[N][N];
+};
+
+template <int N>
+__device__ __forceinline__ void sm_mul(const SmallMat<N> &A, const SmallMat<N> &B,
+                                       SmallMat<N> &C)
+{
+    SmallMat<N> T;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            double acc = A.a[i][0] * B.a[0][j];
+#pragma unroll
+            for (int k = 1; k < N; ++k) acc = fma(A.a[i][k], B.a[k][j], acc);
+            T.a[i][j] = acc;
+        }
+    C = T;
+}
+
+// C = alpha*A + beta*B + gamma*Cin + delta*I   (any of the matrices may be unused)
+template <int N>
+__device__ __forceinline__ void sm_comb(SmallMat<N> &out, double ca, const SmallMat<N> &A,
+                                        double cb, const SmallMat<N> &B, double cc,
+                                        const SmallMat<N> &C, double ci)
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            out.a[i][j] = ca * A.a[i][j] + cb * B.a[i][j] + cc * C.a[i][j] +
+                          (i == j ? ci : 0.0);
+}
+
+template <int N>
+__global__ void __launch_bounds__(64)
+expm_small_kernel(int count, const double *__restrict__ Q, const int *__restrict__ qidx,
+                  const double *__restrict__ tt, double *__restrict__ P,
+                  int *__restrict__ info, const int *__restrict__ step_of_node,
+                  double *__restrict__ Pfrag)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= count) return;
+    constexpr int NN = N * N;
+    double *Pb = P + (long)b * NN;
+    const int qi = qidx[b];
+    const int step = step_of_node ? step_of_node[b] : -1;
+    if (qi < 0) {                              // root slot: zeros (_density.py:171)
+#pragma unroll
+        for (int e = 0; e < NN; ++e) Pb[e] = 0.0;
+        if (info) { info[2 * b] = 0; info[2 * b + 1] = 0; }
+        if (step >= 0)
+#pragma unroll
+            for (int e = 0; e < NN; ++e) Pfrag[(long)step * NN + e] = 0.0;
+        return;
+    }
+    const double *Qb = Q + (long)qi * NN;
+    const double t = tt[b];
+    SmallMat<N> A;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) A.a[i][j] = Qb[i * N + j] * t;
+    double nrm = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double cs = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) cs += fabs(A.a[i][j]);
+        nrm = fmax(nrm, cs);
+    }
+    int m = 13, s = 0;
+    if (nrm <= c_theta[0]) m = 3;
+    else if (nrm <= c_theta[1]) m = 5;
+    else if (nrm <= c_theta[2]) m = 7;
+    else if (nrm <= c_theta[3]) m = 9;
+    else if (nrm > c_theta[4]) {
+        int e;
+        const double f = frexp(nrm / c_theta[4], &e);
+        s = (f == 0.5) ? e - 1 : e;
+        if (s < 0) s = 0;
+    }
+    if (info) { info[2 * b] = m; info[2 * b + 1] = s; }
+    if (s > 0) {
+        const double sc = ldexp(1.0, -s);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) A.a[i][j] *= sc;
+    }
+    SmallMat<N> A2, A4, A6, U, V, W, Z;
+    sm_comb(Z, 0.0, A, 0.0, A, 0.0, A, 0.0);           // Z = 0
+    sm_mul(A, A, A2);
+    A4 = Z; A6 = Z;
+    if (m >= 5) sm_mul(A2, A2, A4);
+    if (m >= 7) sm_mul(A4, A2, A6);
+    if (m == 13) {
+        sm_comb(W, c_b13[13], A6, c_b13[11], A4, c_b13[9], A2, 0.0);
+        sm_mul(A6, W, W);
+        sm_comb(U, c_b13[7], A6, c_b13[5], A4, c_b13[3], A2, c_b13[1]);
+        sm_comb(W, 1.0, W, 1.0, U, 0.0, Z, 0.0);
+        sm_mul(A, W, U);
+        sm_comb(W, c_b13[12], A6, c_b13[10], A4, c_b13[8], A2, 0.0);
+        sm_mul(A6, W, W);
+        sm_comb(V, c_b13[6], A6, c_b13[4], A4, c_b13[2], A2, c_b13[0]);
+        sm_comb(V, 1.0, V, 1.0, W, 0.0, Z, 0.0);
+    } else {
+        SmallMat<N> A8 = Z;
+        if (m >= 9) sm_mul(A6, A2, A8);
+        const double *bc = (m == 3) ? c_b3 : (m == 5) ? c_b5 : (m == 7) ? c_b7 : c_b9;
+        const double b5 = m >= 5 ? bc[5] : 0.0, b4 = m >= 5 ? bc[4] : 0.0;
+        const double b7 = m >= 7 ? bc[7] : 0.0, b6 = m >= 7 ? bc[6] : 0.0;
+        const double b9 = m >= 9 ? bc[9] : 0.0, b8 = m >= 9 ? bc[8] : 0.0;
+        sm_comb(W, bc[3], A2, b5, A4, b7, A6, bc[1]);
+        sm_comb(W, 1.0, W, b9, A8, 0.0, Z, 0.0);
+        sm_comb(V, bc[2], A2, b4, A4, b6, A6, bc[0]);
+        sm_comb(V, 1.0, V, b8, A8, 0.0, Z, 0.0);
+        sm_mul(A, W, U);
+    }
+    // solve (V - U) X = (V + U)
+    SmallMat<N> M, X;
+    sm_comb(M, 1.0, V, -1.0, U, 0.0, Z, 0.0);
+    sm_comb(X, 1.0, V, 1.0, U, 0.0, Z, 0.0);
+    bool singular = false;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        // partial pivoting: bring the largest |M[i][k]|, i >= k, to row k
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) {
+            const bool sw = fabs(M.a[i][k]) > fabs(M.a[k][k]);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const double mk = M.a[k][j], mi = M.a[i][j];
+                M.a[k][j] = sw ? mi : mk;
+                M.a[i][j] = sw ? mk : mi;
+                const double xk = X.a[k][j], xi = X.a[i][j];
+                X.a[k][j] = sw ? xi : xk;
+                X.a[i][j] = sw ? xk : xi;
+            }
+        }
+        singular |= !(fabs(M.a[k][k]) > 0.0);
+        const double rinv = 1.0 / M.a[k][k];
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) {
+            const double f = M.a[i][k] * rinv;
+#pragma unroll
+            for (int j = k + 1; j < N; ++j) M.a[i][j] = fma(-f, M.a[k][j], M.a[i][j]);
+#pragma unroll
+            for (int j = 0; j < N; ++j) X.a[i][j] = fma(-f, X.a[k][j], X.a[i][j]);
+        }
+    }
+#pragma unroll
+    for (int k = N - 1; k >= 0; --k) {
+        const double rinv = 1.0 / M.a[k][k];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            double acc = X.a[k][j];
+#pragma unroll
+            for (int i = k + 1; i < N; ++i) acc = fma(-M.a[k][i], X.a[i][j], acc);
+            X.a[k][j] = acc * rinv;
+        }
+    }
+    for (int q = 0; q < s; ++q) sm_mul(X, X, X);
+    if (singular) {
+        if (info) info[2 * b] = -1;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) X.a[i][j] = __builtin_nan("");
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            Pb[i * N + j] = X.a[i][j];
+            if (step >= 0) Pfrag[(long)step * NN + i * N + j] = X.a[i][j];
+        }
+}
+
 }  // namespace
 
 int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
@@ -390,6 +583,25 @@ int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
         attr_lds = lds;
+    }
+    if (n <= 4 && !getenv("RAOTEH_EXPM_NO_SMALL")) {
+        hipEvent_t ev = nullptr;
+        rt_time_begin(ctx, RT_K_EXPM, "expm_small_lane_per_matrix", &ev);
+        const unsigned grid = (unsigned)((count + 63) / 64);
+        const int *son = frag_kind == 0 ? d_step_of_node : nullptr;
+#define RT_SMALL(NV)                                                                 \
+        hipLaunchKernelGGL(expm_small_kernel<NV>, dim3(grid), dim3(64), 0, ctx->stream, \
+                           (int)count, d_Q, d_qidx, d_t, d_P, d_info, son, d_Pfrag)
+        switch ((int)n) {
+        case 1: RT_SMALL(1); break;
+        case 2: RT_SMALL(2); break;
+        case 3: RT_SMALL(3); break;
+        default: RT_SMALL(4); break;
+        }
+#undef RT_SMALL
+        RT_HIP(hipGetLastError());
+        rt_time_end(ctx, RT_K_EXPM, ev);
+        return RT_OK;
     }
     hipEvent_t ev = nullptr;
     rt_time_begin(ctx, RT_K_EXPM, "expm_mfma_regsolve", &ev);
