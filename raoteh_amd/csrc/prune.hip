@@ -171,7 +171,7 @@ struct LaneCtx {
     // Execute the current step with observation vector o (ignored unless
     // HAS_OBS) and move to the next step.
     template <bool HAS_OBS>
-    __device__ __forceinline__ void step(const double (&o)[N])
+    __device__ __forceinline__ void compute(const double (&o)[N])
     {
         const int flags = op.x;
         if (flags & LOP_FAST) {
@@ -198,12 +198,6 @@ struct LaneCtx {
 #pragma unroll
                 for (int r = 0; r < N; ++r) cur[r] = lds_get(op.z, r) * t[r];
             }
-            i += 1;
-            const int last = nops - 1;
-            const int4_t opnn = ops_c[i + 1 < last ? i + 1 : last];
-            load_p(i < last ? i : last);
-            op = opn;
-            opn = opnn;
             return;
         }
         double x[N];
@@ -256,16 +250,28 @@ struct LaneCtx {
                 for (int r = 0; r < N; ++r) lds_put(op.z, r, lds_get(op.z, r) * t[r]);
             }
         }
-        // Fetch ahead.  p is a single buffer: the FMAs above have read it, so the
-        // next step's matrix can be requested now; the schedule entry is fetched
-        // TWO steps ahead so that the branchy head of the next step never waits
-        // for the scalar cache.
+    }
+
+    // Fetch ahead (call after compute() and after anything that must not wait
+    // for these requests, e.g. the ring refill).  p is a single buffer: the FMAs
+    // of compute() have read it, so the next step's matrix can be requested now;
+    // the schedule entry is fetched TWO steps ahead so that the branchy head of
+    // the next step never waits for the scalar cache.
+    __device__ __forceinline__ void advance()
+    {
         i += 1;
         const int last = nops - 1;
         const int4_t opnn = ops_c[i + 1 < last ? i + 1 : last];
         load_p(i < last ? i : last);
         op = opn;
         opn = opnn;
+    }
+
+    template <bool HAS_OBS>
+    __device__ __forceinline__ void step(const double (&o)[N])
+    {
+        compute<HAS_OBS>(o);
+        advance();
     }
 
     // run the steps that carry no observation
@@ -443,7 +449,10 @@ prune_lanedma_kernel(const double *__restrict__ Pord,   // [nops][N][N]
         double o[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) o[j] = o_l[j];
-        C.template step<true>(o);
+        C.template compute<true>(o);
+        // refill BEFORE the fetch-ahead: the LDS-DMA must wait for the reads of
+        // the slot it overwrites (lgkmcnt(0)), which are long done here, and
+        // must not wait for the P / schedule requests advance() issues
         if (k + R < K) {
 #pragma unroll
             for (int j = 0; j < IPS; ++j)
@@ -451,6 +460,7 @@ prune_lanedma_kernel(const double *__restrict__ Pord,   // [nops][N][N]
                     (glb_void *)(g + (size_t)(k + R) * SLOT + j * 1024),
                     (lds_void *)(ring + rs * SLOT + j * 1024), 16, 0, 0);
         }
+        C.advance();
         rs = (rs + 1 == R) ? 0 : rs + 1;
         C.run_plain();
     }
