@@ -537,15 +537,43 @@ extern "C" int rt_sites_destroy(rt_sites *s)
 
 // Lane-kernel program: simulate the register cache of the top accumulator and
 // turn slots into LDS byte offsets (see LOP_* in prune.hip).
-static std::vector<int32_t> lane_program(const rt_sites *s, int64_t slot_bytes)
+static std::vector<int32_t> lane_program(const rt_sites *s, int64_t slot_bytes, bool fuse)
 {
     enum { INTERNAL = 1, X_CUR = 2, FIRST = 4, ROOT = 8, SPILL = 16, DST_CUR = 32, OBS = 64,
-           FAST = 128 };
-    std::vector<int32_t> prog(s->ops.size() * 4, 0);
+           FAST = 128, CHERRY = 256 };
+    const std::vector<rt_op> &ops = s->ops;
+    std::vector<int32_t> prog;
+    prog.reserve(ops.size() * 4);
     int cur = -1;                              // slot cached in registers
-    for (size_t k = 0; k < s->ops.size(); ++k) {
-        const rt_op &op = s->ops[k];
+    auto leaf_obs = [&](size_t k) {
+        return k < ops.size() && ops[k].pop < 0 && ops[k].obs >= 0 && ops[k].dst >= 0;
+    };
+    for (size_t k = 0; k < ops.size(); ++k) {
+        const rt_op &op = ops[k];
         int flags = 0, pop_off = 0, dst_off = 0, spill_off = 0;
+        // the parent's own step follows immediately <=> this is its last child
+        auto parent_next = [&](size_t kk, int d) {
+            return kk + 1 < ops.size() && ops[kk + 1].pop == d;
+        };
+        // ---- fused cherry: leaf a (first child), leaf b, then their parent ----
+        if (fuse && leaf_obs(k) && (op.dst >> 8) && leaf_obs(k + 1) &&
+            !(ops[k + 1].dst >> 8) && (ops[k + 1].dst & 255) == (op.dst & 255) &&
+            k + 2 < ops.size() && ops[k + 2].pop == (op.dst & 255) &&
+            ops[k + 2].obs < 0 && ops[k + 2].dst >= 0) {
+            const rt_op &par = ops[k + 2];
+            flags = CHERRY | OBS;
+            if (cur >= 0) { flags |= SPILL; spill_off = (int)(cur * slot_bytes); }
+            cur = -1;                          // a, b, p all pass through registers
+            const int d = par.dst & 255;
+            if (par.dst >> 8) { flags |= FIRST; cur = d; }
+            else {
+                dst_off = (int)(d * slot_bytes);
+                if (parent_next(k + 2, d)) { flags |= FAST; cur = d; }   // un-spill
+            }
+            prog.insert(prog.end(), {flags, 0, dst_off, spill_off});
+            k += 2;
+            continue;
+        }
         bool x_ok;                             // x is the observation or the cache
         if (op.obs >= 0) flags |= OBS;
         if (op.pop >= 0) {
@@ -558,8 +586,6 @@ static std::vector<int32_t> lane_program(const rt_sites *s, int64_t slot_bytes)
         if (op.dst < 0) flags |= ROOT;
         else {
             const int d = op.dst & 255;
-            // the parent's own step follows immediately <=> this is its last child
-            const bool parent_next = k + 1 < s->ops.size() && s->ops[k + 1].pop == d;
             if (op.dst >> 8) {
                 flags |= FIRST;
                 if (cur >= 0) { flags |= SPILL; spill_off = (int)(cur * slot_bytes); }
@@ -570,17 +596,14 @@ static std::vector<int32_t> lane_program(const rt_sites *s, int64_t slot_bytes)
                 if (x_ok) flags |= FAST;
             } else {
                 dst_off = (int)(d * slot_bytes);
-                if (x_ok && cur < 0 && parent_next) {
+                if (x_ok && cur < 0 && parent_next(k, d)) {
                     // un-spill: cur = lds[d] * t; the LDS copy is dead afterwards
                     flags |= FAST;
                     cur = d;
                 }
             }
         }
-        prog[4 * k] = flags;
-        prog[4 * k + 1] = pop_off;
-        prog[4 * k + 2] = dst_off;
-        prog[4 * k + 3] = spill_off;
+        prog.insert(prog.end(), {flags, pop_off, dst_off, spill_off});
     }
     return prog;
 }
@@ -623,8 +646,13 @@ static int sites_alloc(rt_sites *s, bool generic)
                       hipMemcpyHostToDevice);
     if (e == hipSuccess && !generic) {
         // lane family: N doubles per slot and lane; MFMA family: 4 (own rows)
+        // cherries are fused only for the LDS-DMA lane kernel (RAOTEH_LANE_NO_FUSE
+        // turns it off for A/B runs)
+        const bool fuse = s->layout == RT_LAYOUT_LANE && s->lane_dma &&
+                          s->lane_ring >= 2 && !getenv("RAOTEH_LANE_NO_FUSE");
         const std::vector<int32_t> prog =
-            lane_program(s, s->layout == RT_LAYOUT_LANE ? n * 512 : 2048);
+            lane_program(s, s->layout == RT_LAYOUT_LANE ? n * 512 : 2048, fuse);
+        s->lane_nprog = (int64_t)(prog.size() / 4);
         e = hipMalloc((void **)&s->d_lane_ops, prog.size() * 4);
         if (e == hipSuccess)
             e = hipMemcpy(s->d_lane_ops, prog.data(), prog.size() * 4, hipMemcpyHostToDevice);

@@ -117,7 +117,8 @@ struct rt_sites {
     std::vector<int32_t> node_obs;  // per node: stream position or -1
     std::vector<rt_op> ops;         // model ops with .obs filled in
     rt_op *d_ops = nullptr;
-    int32_t *d_lane_ops = nullptr;  // lane-kernel program (int32[nops][4])
+    int32_t *d_lane_ops = nullptr;  // lane-kernel program (int32[nprog][4])
+    int64_t lane_nprog = 0;         // its entries (< steps when cherries are fused)
     double *d_obs = nullptr;
     double *d_loglik = nullptr;     // [nblocks * sites per block]
     int32_t *d_status = nullptr;

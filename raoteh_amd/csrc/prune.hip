@@ -120,7 +120,11 @@ enum {
     // fast path (set by the host for the common steps): x is the observation
     // (leaf) or the register cache (internal node), and the result stays in the
     // register cache: cur = t * {1 | cur | lds[dst_off]}
-    LOP_FAST = 128
+    LOP_FAST = 128,
+    // fused step of the LDS-DMA lane kernel: two observed leaves a, b and their
+    // parent p in one go, t = P_p * ((P_a o_a) * (P_b o_b)); three consecutive P
+    // records; spill_off as for a first child, dst flags/offset are the parent's
+    LOP_CHERRY = 256
 };
 
 template <int N, bool PLDS>
@@ -130,8 +134,10 @@ struct LaneCtx {
     const double *P_l;                   // ... or the copy of it in LDS (PLDS)
     const RT_CONST_AS double *w_c;
     unsigned char *stack;          // LDS, + lane * 8 bytes
-    int nops;
-    int i;                         // index of the current step
+    int nops;                      // program entries
+    int nrec;                      // P records (>= nops: a fused entry spans 3)
+    int pidx;                      // P record of the current step
+    int i;                         // index of the current program entry
     int4_t op;                     // current step: {flags, pop_off, dst_off, spill_off}
     int4_t opn;                    // the step after it (fetched a whole step ahead)
     double p[N * N];               // transition matrix of the current step
@@ -156,7 +162,7 @@ struct LaneCtx {
         const int last = nops - 1;
         op = ops_c[i < last ? i : last];
         opn = ops_c[i + 1 < last ? i + 1 : last];
-        load_p(i < last ? i : last);
+        load_p(pidx < nrec - 1 ? pidx : nrec - 1);
     }
 
     __device__ __forceinline__ double lds_get(int off, int j) const
@@ -257,14 +263,62 @@ struct LaneCtx {
     // of compute() have read it, so the next step's matrix can be requested now;
     // the schedule entry is fetched TWO steps ahead so that the branchy head of
     // the next step never waits for the scalar cache.
-    __device__ __forceinline__ void advance()
+    __device__ __forceinline__ void advance(int records = 1)
     {
         i += 1;
+        pidx += records;
         const int last = nops - 1;
         const int4_t opnn = ops_c[i + 1 < last ? i + 1 : last];
-        load_p(i < last ? i : last);
+        load_p(pidx < nrec - 1 ? pidx : nrec - 1);
         op = opn;
         opn = opnn;
+    }
+
+    // Fused cherry (LOP_CHERRY, PLDS only): p already holds P_a.
+    __device__ __forceinline__ void compute_cherry(const double (&oa)[N],
+                                                   const double (&ob)[N])
+    {
+        const int flags = op.x;
+        double pb[N * N], pp[N * N];
+        const double *rec = P_l + (pidx + 1) * N * N;
+#pragma unroll
+        for (int j = 0; j < N * N; ++j) pb[j] = rec[j];
+#pragma unroll
+        for (int j = 0; j < N * N; ++j) pp[j] = rec[N * N + j];
+        if (flags & LOP_SPILL) {
+#pragma unroll
+            for (int r = 0; r < N; ++r) lds_put(op.w, r, cur[r]);
+        }
+        double y[N];
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            double sa = p[r * N] * oa[0];
+            double sb = pb[r * N] * ob[0];
+#pragma unroll
+            for (int j = 1; j < N; ++j) {
+                sa = fma(p[r * N + j], oa[j], sa);
+                sb = fma(pb[r * N + j], ob[j], sb);
+            }
+            y[r] = sa * sb;
+        }
+        double t[N];
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            double sacc = pp[r * N] * y[0];
+#pragma unroll
+            for (int j = 1; j < N; ++j) sacc = fma(pp[r * N + j], y[j], sacc);
+            t[r] = sacc;
+        }
+        if (flags & LOP_FIRST) {
+#pragma unroll
+            for (int r = 0; r < N; ++r) cur[r] = t[r];
+        } else if (flags & LOP_FAST) {          // un-spill
+#pragma unroll
+            for (int r = 0; r < N; ++r) cur[r] = lds_get(op.z, r) * t[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < N; ++r) lds_put(op.z, r, lds_get(op.z, r) * t[r]);
+        }
     }
 
     template <bool HAS_OBS>
@@ -326,6 +380,8 @@ prune_lane_kernel(const double *__restrict__ Pord,   // [nops][N][N]
     C.w_c = (const RT_CONST_AS double *)root_w;
     C.stack = stack_base + (size_t)wave * depth * N * 512 + lane * 8;
     C.nops = nops;
+    C.nrec = nops;
+    C.pidx = 0;
     C.i = 0;
     C.lik = 0.0;
     C.negative = false;
@@ -387,8 +443,8 @@ prune_lane_kernel(const double *__restrict__ Pord,   // [nops][N][N]
 
 template <int N, int R>
 __global__ void __launch_bounds__(256)
-prune_lanedma_kernel(const double *__restrict__ Pord,   // [nops][N][N]
-                     const int4_t *__restrict__ ops, int nops,   // lane program
+prune_lanedma_kernel(const double *__restrict__ Pord,   // [nrec][N][N]
+                     const int4_t *__restrict__ ops, int nops, int nrec,   // program
                      const double *__restrict__ obs, int K,  // [blk][K][64][NP]
                      const double *__restrict__ root_w, int depth,
                      double *__restrict__ loglik, int *__restrict__ status,
@@ -405,8 +461,8 @@ prune_lanedma_kernel(const double *__restrict__ Pord,   // [nops][N][N]
 
     LaneCtx<N, true> C;
     double *pl = (double *)smem;
-    for (int e = threadIdx.x; e < nops * N * N; e += 256) pl[e] = Pord[e];
-    unsigned char *wbase = smem + (((size_t)nops * N * N * 8 + 15) & ~(size_t)15) +
+    for (int e = threadIdx.x; e < nrec * N * N; e += 256) pl[e] = Pord[e];
+    unsigned char *wbase = smem + (((size_t)nrec * N * N * 8 + 15) & ~(size_t)15) +
                            (size_t)wave * (R * SLOT + depth * N * 512);
     __syncthreads();
     if (gw >= nblocks) return;                // wave-uniform, after the only barrier
@@ -417,6 +473,8 @@ prune_lanedma_kernel(const double *__restrict__ Pord,   // [nops][N][N]
     C.w_c = (const RT_CONST_AS double *)root_w;
     C.stack = wbase + R * SLOT + lane * 8;
     C.nops = nops;
+    C.nrec = nrec;
+    C.pidx = 0;
     C.i = 0;
     C.lik = 0.0;
     C.negative = false;
@@ -440,28 +498,62 @@ prune_lanedma_kernel(const double *__restrict__ Pord,   // [nops][N][N]
     C.load_current();
     C.run_plain();
     int rs = 0;                               // ring slot of stream position k
-    for (int k = 0; k < K; ++k) {
-        if (k + R <= K)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 1) * IPS) : "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const double *o_l = (const double *)(ring + rs * SLOT) + lane * NP;
-        double o[N];
+    int k = 0;
+    while (k < K) {
+        if ((C.op.x & LOP_CHERRY) && R >= 2) {
+            // two leaves + parent: stream positions k, k+1
+            if (k + 1 + R <= K)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R >= 2 ? R - 2 : 0) * IPS) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int rs1 = (rs + 1 == R) ? 0 : rs + 1;
+            const double *oa_l = (const double *)(ring + rs * SLOT) + lane * NP;
+            const double *ob_l = (const double *)(ring + rs1 * SLOT) + lane * NP;
+            double oa[N], ob[N];
 #pragma unroll
-        for (int j = 0; j < N; ++j) o[j] = o_l[j];
-        C.template compute<true>(o);
-        // refill BEFORE the fetch-ahead: the LDS-DMA must wait for the reads of
-        // the slot it overwrites (lgkmcnt(0)), which are long done here, and
-        // must not wait for the P / schedule requests advance() issues
-        if (k + R < K) {
+            for (int j = 0; j < N; ++j) { oa[j] = oa_l[j]; ob[j] = ob_l[j]; }
+            C.compute_cherry(oa, ob);
+            if (k + R < K) {
 #pragma unroll
-            for (int j = 0; j < IPS; ++j)
-                __builtin_amdgcn_global_load_lds(
-                    (glb_void *)(g + (size_t)(k + R) * SLOT + j * 1024),
-                    (lds_void *)(ring + rs * SLOT + j * 1024), 16, 0, 0);
+                for (int j = 0; j < IPS; ++j)
+                    __builtin_amdgcn_global_load_lds(
+                        (glb_void *)(g + (size_t)(k + R) * SLOT + j * 1024),
+                        (lds_void *)(ring + rs * SLOT + j * 1024), 16, 0, 0);
+            }
+            if (k + 1 + R < K) {
+#pragma unroll
+                for (int j = 0; j < IPS; ++j)
+                    __builtin_amdgcn_global_load_lds(
+                        (glb_void *)(g + (size_t)(k + 1 + R) * SLOT + j * 1024),
+                        (lds_void *)(ring + rs1 * SLOT + j * 1024), 16, 0, 0);
+            }
+            C.advance(3);
+            rs = (rs1 + 1 == R) ? 0 : rs1 + 1;
+            k += 2;
+        } else {
+            if (k + R <= K)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 1) * IPS) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const double *o_l = (const double *)(ring + rs * SLOT) + lane * NP;
+            double o[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) o[j] = o_l[j];
+            C.template compute<true>(o);
+            // refill BEFORE the fetch-ahead: the LDS-DMA must wait for the reads
+            // of the slot it overwrites (lgkmcnt(0)), which are long done here,
+            // and must not wait for the P / schedule requests advance() issues
+            if (k + R < K) {
+#pragma unroll
+                for (int j = 0; j < IPS; ++j)
+                    __builtin_amdgcn_global_load_lds(
+                        (glb_void *)(g + (size_t)(k + R) * SLOT + j * 1024),
+                        (lds_void *)(ring + rs * SLOT + j * 1024), 16, 0, 0);
+            }
+            C.advance();
+            rs = (rs + 1 == R) ? 0 : rs + 1;
+            k += 1;
         }
-        C.advance();
-        rs = (rs + 1 == R) ? 0 : rs + 1;
         C.run_plain();
     }
 
@@ -995,8 +1087,9 @@ static int launch_lane_dma(rt_model *m, rt_sites *s)
 {
     constexpr int NP = (N + 1) & ~1;
     const int depth = std::max(1, m->max_depth - 1);
-    const int nops = (int)s->ops.size();
-    const int ptab = (nops * N * N * 8 + 15) & ~15;
+    const int nrec = (int)s->ops.size();          // P records = schedule steps
+    const int nops = (int)s->lane_nprog;          // program entries (cherries fused)
+    const int ptab = (nrec * N * N * 8 + 15) & ~15;
     const int lds = ptab + 4 * (R * 64 * NP * 8 + depth * N * 512);
     if (lds > 160 * 1024) {
         rt_set_error("LDS-DMA lane kernel: %d bytes of LDS needed (tree too large); "
@@ -1007,7 +1100,7 @@ static int launch_lane_dma(rt_model *m, rt_sites *s)
     RT_HIP(hipFuncSetAttribute((const void *)kern,
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)((s->nblocks + 3) / 4)), dim3(256), lds,
-                       m->ctx->stream, m->d_Pfrag, (const int4_t *)s->d_lane_ops, nops,
+                       m->ctx->stream, m->d_Pfrag, (const int4_t *)s->d_lane_ops, nops, nrec,
                        s->d_obs, (int)s->nobs, m->d_root, depth, s->d_loglik, s->d_status,
                        s->d_partial, (long)s->nsites, (long)s->nblocks);
     return RT_OK;
