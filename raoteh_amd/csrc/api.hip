@@ -608,6 +608,15 @@ static std::vector<int32_t> lane_program(const rt_sites *s, int64_t slot_bytes, 
     return prog;
 }
 
+// number of LDS stack slots a program touches (offsets are slot * slot_bytes)
+static int program_stack_slots(const std::vector<int32_t> &prog, int64_t slot_bytes)
+{
+    int64_t top = 0;
+    for (size_t k = 0; k + 3 < prog.size(); k += 4)
+        top = std::max<int64_t>(top, std::max(prog[k + 1], std::max(prog[k + 2], prog[k + 3])));
+    return (int)(top / slot_bytes) + 1;
+}
+
 static int sites_alloc(rt_sites *s, bool generic)
 {
     rt_model *m = s->model;
@@ -649,10 +658,13 @@ static int sites_alloc(rt_sites *s, bool generic)
         // cherries are fused only for the LDS-DMA lane kernel (RAOTEH_LANE_NO_FUSE
         // turns it off for A/B runs)
         const bool fuse = s->layout == RT_LAYOUT_LANE && s->lane_dma &&
-                          s->lane_ring >= 2 && !getenv("RAOTEH_LANE_NO_FUSE");
+                          (s->lane_ring == 0 || s->lane_ring >= 2) &&
+                          !getenv("RAOTEH_LANE_NO_FUSE");
         const std::vector<int32_t> prog =
             lane_program(s, s->layout == RT_LAYOUT_LANE ? n * 512 : 2048, fuse);
         s->lane_nprog = (int64_t)(prog.size() / 4);
+        s->lane_stack_slots =
+            program_stack_slots(prog, s->layout == RT_LAYOUT_LANE ? n * 512 : 2048);
         e = hipMalloc((void **)&s->d_lane_ops, prog.size() * 4);
         if (e == hipSuccess)
             e = hipMemcpy(s->d_lane_ops, prog.data(), prog.size() * 4, hipMemcpyHostToDevice);
@@ -717,7 +729,7 @@ extern "C" int rt_sites_create(rt_model *m, int64_t nsites, int kind, int64_t no
     }
     if (const char *v = getenv("RAOTEH_LANE_VARIANT")) s->lane_dma = strcmp(v, "dma") == 0;
     if (const char *r = getenv("RAOTEH_LANE_RING")) s->lane_ring = atoi(r);
-    else s->lane_ring = s->lane_dma ? 3 : 8;
+    else s->lane_ring = s->lane_dma ? 0 : 8;      // 0: rt_launch_prune picks what fits
     int rc = sites_alloc(s, generic);
     if (rc == RT_OK) rc = rt_sites_pack(s, kind, src_of_k.data(), data);
     if (rc != RT_OK) {

@@ -118,6 +118,7 @@ struct rt_sites {
     std::vector<rt_op> ops;         // model ops with .obs filled in
     rt_op *d_ops = nullptr;
     int32_t *d_lane_ops = nullptr;  // lane-kernel program (int32[nprog][4])
+    int lane_stack_slots = 1;       // LDS accumulator slots the program touches
     int64_t lane_nprog = 0;         // its entries (< steps when cherries are fused)
     double *d_obs = nullptr;
     double *d_loglik = nullptr;     // [nblocks * sites per block]

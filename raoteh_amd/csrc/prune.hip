@@ -1086,7 +1086,7 @@ template <int N, int R>
 static int launch_lane_dma(rt_model *m, rt_sites *s)
 {
     constexpr int NP = (N + 1) & ~1;
-    const int depth = std::max(1, m->max_depth - 1);
+    const int depth = s->lane_stack_slots;
     const int nrec = (int)s->ops.size();          // P records = schedule steps
     const int nops = (int)s->lane_nprog;          // program entries (cherries fused)
     const int ptab = (nrec * N * N * 8 + 15) & ~15;
@@ -1110,9 +1110,17 @@ template <int N>
 static int launch_lane(rt_model *m, rt_sites *s, const char **name)
 {
     static char buf[5][48];
-    const int R = s->lane_ring;
+    int R = s->lane_ring;
     int rc;
     bool plds = false;
+    if (s->lane_dma && R == 0) {
+        // deepest ring (2..4 slots) with which two workgroups still fit on a CU
+        constexpr int NPv = (N + 1) & ~1;
+        const int ptab = ((int)s->ops.size() * N * N * 8 + 15) & ~15;
+        for (R = 4; R > 2; --R)
+            if (ptab + 4 * (R * 64 * NPv * 8 + s->lane_stack_slots * N * 512) <= 80 * 1024)
+                break;
+    }
     if (s->lane_dma) {
         switch (R) {
         case 2: rc = launch_lane_dma<N, 2>(m, s); break;
