@@ -169,6 +169,10 @@ def main():
     reduce_kind = 'none'
     if world > 1:
         reduce_kind = 'rccl' if init_rccl(ctx, ctl) else 'host-socket-fallback'
+    elif os.environ.get('RAOTEH_BENCH_FORCE_RCCL'):
+        # single-GPU rehearsal of the N > 1 data path: a 1-rank communicator
+        ctx.comm_init(1, 0, device.Context.comm_unique_id())
+        reduce_kind = 'rccl'
 
     def step(j):
         b = batches[j % len(batches)]

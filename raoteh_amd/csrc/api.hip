@@ -71,6 +71,7 @@ extern "C" int rt_ctx_sync(rt_ctx *ctx)
 {
     RT_REQUIRE(ctx, "null context");
     RT_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->comm_stream) RT_HIP(hipStreamSynchronize(ctx->comm_stream));
     return RT_OK;
 }
 
@@ -531,6 +532,9 @@ extern "C" int rt_sites_destroy(rt_sites *s)
     hipStreamSynchronize(s->model->ctx->stream);
     hipFree(s->d_ops); hipFree(s->d_lane_ops); hipFree(s->d_obs); hipFree(s->d_loglik); hipFree(s->d_status);
     hipFree(s->d_partial); hipFree(s->d_totals); hipFree(s->d_scratch);
+    if (s->model->ctx->comm_stream) hipStreamSynchronize(s->model->ctx->comm_stream);
+    if (s->ev_reduced) hipEventDestroy(s->ev_reduced);
+    if (s->ev_comm_done) hipEventDestroy(s->ev_comm_done);
     delete s;
     return RT_OK;
 }
@@ -803,6 +807,8 @@ extern "C" int rt_sites_get_totals(rt_sites *s, double totals[3])
     RT_REQUIRE(s && totals, "null pointer");
     RT_HIP(hipSetDevice(s->model->ctx->device));
     RT_HIP(hipStreamSynchronize(s->model->ctx->stream));
+    if (s->model->ctx->comm_stream)
+        RT_HIP(hipStreamSynchronize(s->model->ctx->comm_stream));
     RT_HIP(hipMemcpy(totals, s->d_totals, 3 * 8, hipMemcpyDeviceToHost));
     return RT_OK;
 }

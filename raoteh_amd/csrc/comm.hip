@@ -88,6 +88,9 @@ extern "C" int rt_comm_init(rt_ctx *ctx, int nranks, int rank, const unsigned ch
     const int rc = g_rccl.CommInitRank(&comm, nranks, uid, rank);
     if (rc != 0) return rccl_fail("ncclCommInitRank", rc);
     ctx->comm = comm;
+    // collectives run on their own stream so the 24-byte all-reduce of step j
+    // overlaps the kernels of step j+1 (it is pure latency)
+    RT_HIP(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
     return RT_OK;
 }
 
@@ -96,8 +99,11 @@ extern "C" int rt_comm_destroy(rt_ctx *ctx)
     if (!ctx || !ctx->comm) return RT_OK;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    if (ctx->comm_stream) hipStreamSynchronize(ctx->comm_stream);
     g_rccl.CommDestroy((nccl_comm)ctx->comm);
     ctx->comm = nullptr;
+    if (ctx->comm_stream) hipStreamDestroy(ctx->comm_stream);
+    ctx->comm_stream = nullptr;
     return RT_OK;
 }
 
@@ -106,8 +112,17 @@ extern "C" int rt_allreduce_totals(rt_ctx *ctx, rt_sites *s)
     RT_REQUIRE(ctx && s, "null pointer");
     RT_REQUIRE(ctx->comm, "rt_comm_init has not been called");
     RT_HIP(hipSetDevice(ctx->device));
+    if (!s->ev_reduced) {
+        RT_HIP(hipEventCreateWithFlags(&s->ev_reduced, hipEventDisableTiming));
+        RT_HIP(hipEventCreateWithFlags(&s->ev_comm_done, hipEventDisableTiming));
+    }
+    // comm stream: wait for this batch's totals, reduce them in place, signal
+    RT_HIP(hipEventRecord(s->ev_reduced, ctx->stream));
+    RT_HIP(hipStreamWaitEvent(ctx->comm_stream, s->ev_reduced, 0));
     const int rc = g_rccl.AllReduce(s->d_totals, s->d_totals, 3, NCCL_FLOAT64, NCCL_SUM,
-                                    (nccl_comm)ctx->comm, ctx->stream);
+                                    (nccl_comm)ctx->comm, ctx->comm_stream);
     if (rc != 0) return rccl_fail("ncclAllReduce", rc);
+    RT_HIP(hipEventRecord(s->ev_comm_done, ctx->comm_stream));
+    s->comm_pending = true;
     return RT_OK;
 }

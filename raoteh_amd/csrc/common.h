@@ -60,6 +60,7 @@ struct rt_ctx {
     int timing_period = 1;
     rt_timing_slot slots[RT_K_COUNT];
     void *comm = nullptr;          // ncclComm_t
+    hipStream_t comm_stream = nullptr;   // collectives overlap the next step's kernels
     void *rccl = nullptr;          // dlopen handle
 };
 
@@ -126,6 +127,9 @@ struct rt_sites {
     double *d_partial = nullptr;    // [npartials][2] (sum, nzero)
     int64_t npartials = 0;
     double *d_totals = nullptr;     // [3]
+    hipEvent_t ev_reduced = nullptr;    // totals written (compute stream)
+    hipEvent_t ev_comm_done = nullptr;  // all-reduce of the totals finished (comm stream)
+    bool comm_pending = false;
     double *d_scratch = nullptr;    // generic kernel message stack
     int64_t scratch_bytes = 0;
 };

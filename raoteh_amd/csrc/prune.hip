@@ -1236,6 +1236,12 @@ int rt_launch_prune(rt_model *m, rt_sites *s)
     ctx->slots[RT_K_PRUNE].name = name;
     rt_time_end(ctx, RT_K_PRUNE, ev);
 
+    if (s->comm_pending) {
+        // the previous all-reduce of this batch's totals must have finished before
+        // the totals are rewritten
+        RT_HIP(hipStreamWaitEvent(ctx->stream, s->ev_comm_done, 0));
+        s->comm_pending = false;
+    }
     rt_time_begin(ctx, RT_K_REDUCE, "reduce_partials", &ev);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, ctx->stream,
                        s->d_partial, (long)s->npartials, s->d_totals,
