@@ -566,13 +566,18 @@ static std::vector<int32_t> lane_program(const rt_sites *s, int64_t slot_bytes, 
             ops[k + 2].obs < 0 && ops[k + 2].dst >= 0) {
             const rt_op &par = ops[k + 2];
             flags = CHERRY | OBS;
-            if (cur >= 0) { flags |= SPILL; spill_off = (int)(cur * slot_bytes); }
-            cur = -1;                          // a, b, p all pass through registers
+            // a, b and p pass through temporaries: the register cache is only
+            // touched by the parent's result
             const int d = par.dst & 255;
-            if (par.dst >> 8) { flags |= FIRST; cur = d; }
-            else {
+            if (par.dst >> 8) {                // p is a first child: cur = t
+                flags |= FIRST;
+                if (cur >= 0) { flags |= SPILL; spill_off = (int)(cur * slot_bytes); }
+                cur = d;
+            } else if (cur == d) {             // the grandparent's accumulator is cached
+                flags |= DST_CUR;
+            } else {
                 dst_off = (int)(d * slot_bytes);
-                if (parent_next(k + 2, d)) { flags |= FAST; cur = d; }   // un-spill
+                if (cur < 0 && parent_next(k + 2, d)) { flags |= FAST; cur = d; }  // un-spill
             }
             prog.insert(prog.end(), {flags, 0, dst_off, spill_off});
             k += 2;

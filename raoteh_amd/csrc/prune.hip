@@ -312,6 +312,9 @@ struct LaneCtx {
         if (flags & LOP_FIRST) {
 #pragma unroll
             for (int r = 0; r < N; ++r) cur[r] = t[r];
+        } else if (flags & LOP_DST_CUR) {
+#pragma unroll
+            for (int r = 0; r < N; ++r) cur[r] *= t[r];
         } else if (flags & LOP_FAST) {          // un-spill
 #pragma unroll
             for (int r = 0; r < N; ++r) cur[r] = lds_get(op.z, r) * t[r];
@@ -1114,10 +1117,11 @@ static int launch_lane(rt_model *m, rt_sites *s, const char **name)
     int rc;
     bool plds = false;
     if (s->lane_dma && R == 0) {
-        // deepest ring (2..4 slots) with which two workgroups still fit on a CU
+        // 3 slots when two workgroups then still fit on a CU, else 2 (measured on
+        // C2: 4 slots are slower than 3 even where they fit)
         constexpr int NPv = (N + 1) & ~1;
         const int ptab = ((int)s->ops.size() * N * N * 8 + 15) & ~15;
-        for (R = 4; R > 2; --R)
+        for (R = 3; R > 2; --R)
             if (ptab + 4 * (R * 64 * NPv * 8 + s->lane_stack_slots * N * 512) <= 80 * 1024)
                 break;
     }
