@@ -317,7 +317,7 @@ extern "C" int rt_build_schedule(int64_t nnodes, const int64_t *idx, const int64
 static int64_t pfrag_doubles(const rt_model *m)
 {
     const int64_t nops = (int64_t)m->ops.size();
-    if (m->n <= 4) return nops * m->n * m->n;
+    if (m->n <= 4) return (nops + 1) * m->n * m->n;   // + one zero record (fetch-ahead)
     const int64_t nt = (m->n + 15) / 16, kp = ((m->n + 3) / 4 + 1) / 2;
     return nops * nt * kp * 128;
 }
@@ -372,6 +372,7 @@ extern "C" int rt_model_create(rt_ctx *ctx, int64_t nnodes, int64_t n,
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_ops, m->ops.size() * sizeof(rt_op));
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_P, nnodes * nn * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_Pfrag, pfrag_doubles(m) * 8);
+    if (e == hipSuccess) e = hipMemset(m->d_Pfrag, 0, pfrag_doubles(m) * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_root, n * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_qidx, nnodes * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_t, nnodes * 8);
@@ -614,6 +615,7 @@ static std::vector<int32_t> lane_program(const rt_sites *s, int64_t slot_bytes, 
         }
         prog.insert(prog.end(), {flags, pop_off, dst_off, spill_off});
     }
+    prog.insert(prog.end(), {512 /* LOP_STOP */, 0, 0, 0});     // sentinel
     return prog;
 }
 
@@ -671,7 +673,7 @@ static int sites_alloc(rt_sites *s, bool generic)
                           !getenv("RAOTEH_LANE_NO_FUSE");
         const std::vector<int32_t> prog =
             lane_program(s, s->layout == RT_LAYOUT_LANE ? n * 512 : 2048, fuse);
-        s->lane_nprog = (int64_t)(prog.size() / 4);
+        s->lane_nprog = (int64_t)(prog.size() / 4) - 1;     // without the sentinel
         s->lane_stack_slots =
             program_stack_slots(prog, s->layout == RT_LAYOUT_LANE ? n * 512 : 2048);
         e = hipMalloc((void **)&s->d_lane_ops, prog.size() * 4);
@@ -733,7 +735,7 @@ extern "C" int rt_sites_create(rt_model *m, int64_t nsites, int kind, int64_t no
     if (s->layout == RT_LAYOUT_LANE && !generic) {
         const int64_t np = (m->n + 1) & ~1ll;
         const int64_t stack = std::max<int64_t>(1, m->max_depth - 1) * m->n * 512;
-        const int64_t ptab = ((int64_t)m->ops.size() * m->n * m->n * 8 + 15) & ~15ll;
+        const int64_t ptab = ((int64_t)(m->ops.size() + 1) * m->n * m->n * 8 + 15) & ~15ll;
         s->lane_dma = ptab + 4 * (3 * 64 * np * 8 + stack) <= 80 * 1024;
     }
     if (const char *v = getenv("RAOTEH_LANE_VARIANT")) s->lane_dma = strcmp(v, "dma") == 0;

@@ -124,7 +124,8 @@ enum {
     // fused step of the LDS-DMA lane kernel: two observed leaves a, b and their
     // parent p in one go, t = P_p * ((P_a o_a) * (P_b o_b)); three consecutive P
     // records; spill_off as for a first child, dst flags/offset are the parent's
-    LOP_CHERRY = 256
+    LOP_CHERRY = 256,
+    LOP_STOP = 512      // sentinel entry after the last step (lane kernels)
 };
 
 template <int N, bool PLDS>
@@ -139,7 +140,6 @@ struct LaneCtx {
     int pidx;                      // P record of the current step
     int i;                         // index of the current program entry
     int4_t op;                     // current step: {flags, pop_off, dst_off, spill_off}
-    int4_t opn;                    // the step after it (fetched a whole step ahead)
     double p[N * N];               // transition matrix of the current step
     double cur[N];                 // register-cached top accumulator
     double lik;
@@ -157,12 +157,13 @@ struct LaneCtx {
         }
     }
 
+    // The program carries a STOP sentinel after its last entry and the P table
+    // one extra (zero) record, so fetching "the next" entry / matrix never needs
+    // a bounds clamp.
     __device__ __forceinline__ void load_current()
     {
-        const int last = nops - 1;
-        op = ops_c[i < last ? i : last];
-        opn = ops_c[i + 1 < last ? i + 1 : last];
-        load_p(pidx < nrec - 1 ? pidx : nrec - 1);
+        op = ops_c[i];
+        load_p(pidx);
     }
 
     __device__ __forceinline__ double lds_get(int off, int j) const
@@ -267,11 +268,8 @@ struct LaneCtx {
     {
         i += 1;
         pidx += records;
-        const int last = nops - 1;
-        const int4_t opnn = ops_c[i + 1 < last ? i + 1 : last];
-        load_p(pidx < nrec - 1 ? pidx : nrec - 1);
-        op = opn;
-        opn = opnn;
+        op = ops_c[i];
+        load_p(pidx);
     }
 
     // Fused cherry (LOP_CHERRY, PLDS only): p already holds P_a.
@@ -335,7 +333,7 @@ struct LaneCtx {
     __device__ __forceinline__ void run_plain()
     {
         const double none[N] = {};
-        while (i < nops && !(op.x & LOP_OBS)) step<false>(none);
+        while (!(op.x & (LOP_OBS | LOP_STOP))) step<false>(none);
     }
 };
 
@@ -369,8 +367,8 @@ prune_lane_kernel(const double *__restrict__ Pord,   // [nops][N][N]
     unsigned char *stack_base = smem;
     if (PLDS) {
         double *pl = (double *)smem;
-        for (int e = threadIdx.x; e < nops * N * N; e += 256) pl[e] = Pord[e];
-        stack_base = smem + (((size_t)nops * N * N * 8 + 15) & ~(size_t)15);
+        for (int e = threadIdx.x; e < (nops + 1) * N * N; e += 256) pl[e] = Pord[e];
+        stack_base = smem + (((size_t)(nops + 1) * N * N * 8 + 15) & ~(size_t)15);
         __syncthreads();
         if (gw >= nblocks) return;            // wave-uniform, after the only barrier
         C.P_l = pl;
@@ -464,8 +462,8 @@ prune_lanedma_kernel(const double *__restrict__ Pord,   // [nrec][N][N]
 
     LaneCtx<N, true> C;
     double *pl = (double *)smem;
-    for (int e = threadIdx.x; e < nrec * N * N; e += 256) pl[e] = Pord[e];
-    unsigned char *wbase = smem + (((size_t)nrec * N * N * 8 + 15) & ~(size_t)15) +
+    for (int e = threadIdx.x; e < (nrec + 1) * N * N; e += 256) pl[e] = Pord[e];
+    unsigned char *wbase = smem + (((size_t)(nrec + 1) * N * N * 8 + 15) & ~(size_t)15) +
                            (size_t)wave * (R * SLOT + depth * N * 512);
     __syncthreads();
     if (gw >= nblocks) return;                // wave-uniform, after the only barrier
@@ -1059,7 +1057,7 @@ static int launch_lane_reg(rt_model *m, rt_sites *s, bool *plds_out)
     const int depth = std::max(1, m->max_depth - 1);
     const int nops = (int)s->ops.size();
     const int stack = depth * N * 512;                        // per wave
-    const int ptab = (nops * N * N * 8 + 15) & ~15;
+    const int ptab = ((nops + 1) * N * N * 8 + 15) & ~15;
     // P table in LDS when two 4-wave workgroups still fit on a CU
     const bool plds = ptab + 4 * stack <= 80 * 1024 && !getenv("RAOTEH_LANE_NO_PLDS");
     *plds_out = plds;
@@ -1092,7 +1090,7 @@ static int launch_lane_dma(rt_model *m, rt_sites *s)
     const int depth = s->lane_stack_slots;
     const int nrec = (int)s->ops.size();          // P records = schedule steps
     const int nops = (int)s->lane_nprog;          // program entries (cherries fused)
-    const int ptab = (nrec * N * N * 8 + 15) & ~15;
+    const int ptab = ((nrec + 1) * N * N * 8 + 15) & ~15;
     const int lds = ptab + 4 * (R * 64 * NP * 8 + depth * N * 512);
     if (lds > 160 * 1024) {
         rt_set_error("LDS-DMA lane kernel: %d bytes of LDS needed (tree too large); "
@@ -1120,7 +1118,7 @@ static int launch_lane(rt_model *m, rt_sites *s, const char **name)
         // 3 slots when two workgroups then still fit on a CU, else 2 (measured on
         // C2: 4 slots are slower than 3 even where they fit)
         constexpr int NPv = (N + 1) & ~1;
-        const int ptab = ((int)s->ops.size() * N * N * 8 + 15) & ~15;
+        const int ptab = (((int)s->ops.size() + 1) * N * N * 8 + 15) & ~15;
         for (R = 3; R > 2; --R)
             if (ptab + 4 * (R * 64 * NPv * 8 + s->lane_stack_slots * N * 512) <= 80 * 1024)
                 break;
