@@ -131,6 +131,27 @@ int rt_mcy_esd_get_node_to_pmap(rt_ctx *ctx, int64_t nnodes, int64_t n,
             const int64_t *state_mask, const double *obs_likelihood,
             double *subtree_probability);
 
+/* pyfelscore.mc0_esd_get_node_to_distn (_mc0_dense.py:381, _mcy_dense.py:195;
+ * pure-Python twin _mc0_dense.py:446-486): downward pass, posterior marginal
+ * state distribution of every node given the upward messages.  root_distn
+ * f64[n] or NULL (= ones).  node_to_distn_array f64[nsites][nnodes][n] out.
+ * status (optional) int32[nsites]: 2 where a normalising denominator is zero
+ * (the reference raises NumericalZeroProb, _util.py:164-165).                */
+int rt_mc0_esd_get_node_to_distn(rt_ctx *ctx, int64_t nnodes, int64_t n,
+            int64_t nsites, const int64_t *tree_csr_indices,
+            const int64_t *tree_csr_indptr, const double *esd_transitions,
+            const double *root_distn, const double *subtree_probability,
+            double *node_to_distn_array, int32_t *status);
+
+/* pyfelscore.mc0_esd_get_joint_endpoint_distn (_mcy_dense.py:205; twin
+ * _mc0_dense.py:246-267): joint (parent state, child state) posterior of every
+ * edge, f64[nsites][nnodes][n][n] keyed by the child index (root slot zero). */
+int rt_mc0_esd_get_joint_endpoint_distn(rt_ctx *ctx, int64_t nnodes, int64_t n,
+            int64_t nsites, const int64_t *tree_csr_indices,
+            const int64_t *tree_csr_indptr, const double *esd_transitions,
+            const double *subtree_probability, const double *node_to_distn_array,
+            double *joint_distns);
+
 /* ---- 2. batched, device-resident hot path --------------------------------
  * _mjp_dense.get_likelihood (_mjp_dense.py:362-407) for many sites:
  *   rt_model_create        tree (same CSR as above) -> device, schedule built

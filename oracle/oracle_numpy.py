@@ -312,6 +312,55 @@ def mc0_get_likelihood(root_pmap, root_distn=None):
     return float(root_pmap.sum())
 
 
+def mc0_esd_get_node_to_distn(indices, indptr, esd, root_distn, pmap):
+    """Downward pass: posterior marginal state distribution per node.
+
+    pyfelscore.mc0_esd_get_node_to_distn as called at ``_mc0_dense.py:381`` /
+    ``_mcy_dense.py:195``; pure-Python twin ``_mc0_dense.py:446-486`` (sparse
+    twin ``_mc0.py:382-462``).  Raises NumericalZeroProb where the reference's
+    ``get_normalized_ndarray_distn`` would (``_util.py:164-165``)."""
+    nnodes = len(indptr) - 1
+    n = esd.shape[1]
+    out = np.zeros((nnodes, n), dtype=float)
+    w = pmap[0] * (1.0 if root_distn is None else np.asarray(root_distn, dtype=float))
+    if not w.sum():
+        raise NumericalZeroProb('the denominator is zero')
+    out[0] = w / w.sum()
+    for v in range(nnodes):
+        for c in indices[indptr[v]:indptr[v + 1]]:
+            d = np.zeros(n)
+            for sa in range(n):
+                pa = out[v, sa]
+                if pa:
+                    sb_w = esd[c][sa] * pmap[c]
+                    tot = sb_w.sum()
+                    if not tot:
+                        raise NumericalZeroProb('the denominator is zero')
+                    d += pa * (sb_w / tot)
+            out[c] = d
+    return out
+
+
+def mc0_esd_get_joint_endpoint_distn(indices, indptr, esd, pmap, distn):
+    """Joint (parent state, child state) posterior per edge, keyed by the child
+    index.  pyfelscore.mc0_esd_get_joint_endpoint_distn (``_mcy_dense.py:205``);
+    twin ``_mc0_dense.py:246-267`` (sparse twin ``_mc0.py:255-308``)."""
+    nnodes = len(indptr) - 1
+    n = esd.shape[1]
+    J = np.zeros((nnodes, n, n), dtype=float)
+    for v in range(nnodes):
+        for c in indices[indptr[v]:indptr[v + 1]]:
+            for sa in range(n):
+                pa = distn[v, sa]
+                if pa:
+                    sb_w = esd[c][sa] * pmap[c]
+                    tot = sb_w.sum()
+                    if not tot:
+                        raise NumericalZeroProb('the denominator is zero')
+                    J[c, sa] = pa * (sb_w / tot)
+    return J
+
+
 # ---------------------------------------------------------------------------
 # orchestration (reference: _mcy_dense.py:233-299,302-354,433-493;
 #                _mjp_dense.py:362-407)

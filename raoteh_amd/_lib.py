@@ -68,6 +68,13 @@ SIGNATURES = {
     'rt_mcy_esd_get_node_to_pmap': (c_int, [c_void_p, c_int64, c_int64, c_int64,
                                             _p_i64, _p_i64, _p_f64, _p_i64,
                                             _p_f64, _p_f64]),
+    'rt_mc0_esd_get_node_to_distn': (c_int, [c_void_p, c_int64, c_int64, c_int64,
+                                             _p_i64, _p_i64, _p_f64, _p_f64,
+                                             _p_f64, _p_f64, _p_i32]),
+    'rt_mc0_esd_get_joint_endpoint_distn': (c_int, [c_void_p, c_int64, c_int64,
+                                                    c_int64, _p_i64, _p_i64,
+                                                    _p_f64, _p_f64, _p_f64,
+                                                    _p_f64]),
     'rt_model_create': (c_int, [c_void_p, c_int64, c_int64, _p_i64, _p_i64,
                                 POINTER(c_void_p)]),
     'rt_model_destroy': (c_int, [c_void_p]),

@@ -15,7 +15,7 @@ from ._tree import TreeArrays
 from ._util import StructuralZeroProb
 from .device import get_context
 
-__all__ = ['get_node_to_pmap', 'get_likelihood']
+__all__ = ['get_node_to_pmap', 'get_likelihood', 'kitchen_sink']
 
 
 def _define_state_mask(node_to_allowed_states, preorder_nodes, nstates):
@@ -98,3 +98,29 @@ def get_likelihood(T, root, nstates, node_to_allowed_states=None,
         T, root, nstates, node_to_allowed_states=node_to_allowed_states,
         P_default=P_default)
     return _mc0_dense.get_likelihood(node_to_pmap[root], root_distn=root_distn)
+
+
+def kitchen_sink(T, root, nstates, node_to_allowed_states=None, root_distn=None,
+                 P_default=None):
+    """State mask, upward messages, posterior node marginals and joint endpoint
+    distributions in one go (raoteh/sampler/_mcy_dense.py:57-230).  Returns
+    (state_mask, node_to_pmap, node_to_distn, edge_to_joint_distn)."""
+    from ._util import NumericalZeroProb
+    ta = TreeArrays(T, root)
+    state_mask = _define_state_mask(node_to_allowed_states, ta.preorder_nodes,
+                                    nstates)
+    esd = ta.esd_transitions(nstates, P_default=P_default)
+    pmap = _run_passes(ta, esd, state_mask)
+    ctx = get_context()
+    distn, status = ctx.node_to_distn(ta.indices, ta.indptr, esd, root_distn, pmap)
+    if status[0]:
+        raise NumericalZeroProb('the denominator is zero')
+    J = ctx.joint_endpoint_distn(ta.indices, ta.indptr, esd, pmap, distn)
+    node_to_pmap, node_to_distn, edge_to_joint_distn = {}, {}, {}
+    for i, na in enumerate(ta.preorder_nodes):
+        node_to_pmap[na] = pmap[i]
+        node_to_distn[na] = distn[i]
+        for j in range(ta.indptr[i], ta.indptr[i + 1]):
+            nb_index = ta.indices[j]
+            edge_to_joint_distn[(na, ta.preorder_nodes[nb_index])] = J[nb_index]
+    return state_mask, node_to_pmap, node_to_distn, edge_to_joint_distn

@@ -224,3 +224,155 @@ extern "C" int rt_mcy_esd_get_node_to_pmap(rt_ctx *ctx, int64_t nnodes, int64_t 
     }
     return RT_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Downward pass: posterior marginal state distribution at every node, and the
+// joint (parent state, child state) posterior on every edge.
+//   pyfelscore.mc0_esd_get_node_to_distn        (_mc0_dense.py:381, _mcy_dense.py:195;
+//                                                pure-Python twin _mc0_dense.py:446-486)
+//   pyfelscore.mc0_esd_get_joint_endpoint_distn (_mcy_dense.py:205; twin
+//                                                _mc0_dense.py:246-267)
+// For an edge (a -> b) with upward messages pmap:
+//   den[sa]    = sum_s' P_b[sa,s'] pmap[b,s']
+//   J[sa,sb]   = distn[a,sa] * P_b[sa,sb] * pmap[b,sb] / den[sa]     (0 where distn[a,sa] = 0)
+//   distn[b,sb] = sum_sa J[sa,sb]
+// One 64-lane workgroup per site; lane = state.  status (optional): 2 where a
+// normalising denominator is zero (the reference raises NumericalZeroProb,
+// _util.py:164-165).
+// ---------------------------------------------------------------------------
+
+namespace {
+
+template <bool JOINT>
+__global__ void __launch_bounds__(64)
+distn_kernel(int nnodes, int n, const long *__restrict__ idx, const long *__restrict__ ptr,
+             const double *__restrict__ esd, const double *__restrict__ root_distn,
+             const double *__restrict__ pmap_all, double *__restrict__ distn_all,
+             double *__restrict__ joint_all, int *__restrict__ status)
+{
+    __shared__ double wbuf[64];
+    __shared__ int bad;
+    const int s = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * nnodes * n;
+    const double *pm = pmap_all + base;
+    double *dn = distn_all + base;
+    double *jt = JOINT ? joint_all + base * n : nullptr;
+    if (s == 0) bad = 0;
+    if (!JOINT) {
+        // root: normalised pmap * prior (_mc0_dense.py:458-459)
+        double w = 0.0;
+        if (s < n) w = pm[s] * (root_distn ? root_distn[s] : 1.0);
+        double tot = w;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+        if (!(tot > 0.0) && s == 0) bad = 1;
+        if (s < n) dn[s] = tot > 0.0 ? w / tot : 0.0;
+    } else if (s < n) {
+        for (int sa = 0; sa < n; ++sa) jt[(size_t)sa * n + s] = 0.0;   // root slot
+    }
+    __syncthreads();
+    for (int v = 0; v < nnodes; ++v) {
+        for (long e = ptr[v]; e < ptr[v + 1]; ++e) {
+            const long c = idx[e];
+            const double *Pc = esd + (size_t)c * n * n;
+            const double *Lc = pm + (size_t)c * n;
+            if (s < n) {
+                const double pa = dn[(size_t)v * n + s];
+                double den = 0.0;
+                for (int sp = 0; sp < n; ++sp) den = fma(Pc[(size_t)s * n + sp], Lc[sp], den);
+                double w = 0.0;
+                if (pa != 0.0) {
+                    if (den > 0.0) w = pa / den;
+                    else bad = 1;
+                }
+                wbuf[s] = w;
+            }
+            __syncthreads();
+            if (s < n) {
+                const double lb = Lc[s];
+                if (JOINT) {
+                    for (int sa = 0; sa < n; ++sa)
+                        jt[((size_t)c * n + sa) * n + s] = wbuf[sa] * Pc[(size_t)sa * n + s] * lb;
+                } else {
+                    double acc = 0.0;
+                    for (int sa = 0; sa < n; ++sa) acc = fma(wbuf[sa], Pc[(size_t)sa * n + s], acc);
+                    dn[(size_t)c * n + s] = acc * lb;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (status && s == 0) status[blockIdx.x] = bad ? 2 : 0;
+}
+
+int distn_pass(rt_ctx *ctx, bool joint, int64_t nnodes, int64_t n, int64_t nsites,
+               const int64_t *idx, const int64_t *ptr, const double *esd,
+               const double *root_distn, const double *pmap, double *distn,
+               double *joint_out, int32_t *status)
+{
+    RT_REQUIRE(ctx, "null context");
+    RT_TRY(check_tree(nnodes, n, nsites, idx, ptr, esd));
+    RT_REQUIRE((pmap && distn && (!joint || joint_out)) || nsites == 0, "null array");
+    if (nsites == 0) return RT_OK;
+    RT_HIP(hipSetDevice(ctx->device));
+    dev_tree d;
+    RT_TRY(upload_tree(ctx, d, nnodes, n, idx, ptr, esd));
+    const size_t bytes = (size_t)nsites * nnodes * n * 8;
+    double *dp = nullptr, *dd = nullptr, *dj = nullptr, *dr = nullptr;
+    int *ds = nullptr;
+    hipError_t e = hipMalloc((void **)&dp, bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&dd, bytes);
+    if (e == hipSuccess && joint) e = hipMalloc((void **)&dj, bytes * n);
+    if (e == hipSuccess && root_distn) e = hipMalloc((void **)&dr, n * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&ds, nsites * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(dp, pmap, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && joint)
+        e = hipMemcpyAsync(dd, distn, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && root_distn)
+        e = hipMemcpyAsync(dr, root_distn, n * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        if (joint)
+            hipLaunchKernelGGL(distn_kernel<true>, dim3((unsigned)nsites), dim3(64), 0,
+                               ctx->stream, (int)nnodes, (int)n, d.idx, d.ptr, d.esd, dr, dp,
+                               dd, dj, ds);
+        else
+            hipLaunchKernelGGL(distn_kernel<false>, dim3((unsigned)nsites), dim3(64), 0,
+                               ctx->stream, (int)nnodes, (int)n, d.idx, d.ptr, d.esd, dr, dp,
+                               dd, dj, ds);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && !joint)
+        e = hipMemcpyAsync(distn, dd, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && joint)
+        e = hipMemcpyAsync(joint_out, dj, bytes * n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && status)
+        e = hipMemcpyAsync(status, ds, nsites * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(dp); hipFree(dd); hipFree(dj); hipFree(dr); hipFree(ds);
+    if (e != hipSuccess) {
+        rt_set_error("distn pass failed: %s", hipGetErrorString(e));
+        return RT_ERR_HIP;
+    }
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" int rt_mc0_esd_get_node_to_distn(rt_ctx *ctx, int64_t nnodes, int64_t n,
+        int64_t nsites, const int64_t *idx, const int64_t *ptr, const double *esd,
+        const double *root_distn, const double *subtree_probability,
+        double *node_to_distn_array, int32_t *status)
+{
+    return distn_pass(ctx, false, nnodes, n, nsites, idx, ptr, esd, root_distn,
+                      subtree_probability, node_to_distn_array, nullptr, status);
+}
+
+extern "C" int rt_mc0_esd_get_joint_endpoint_distn(rt_ctx *ctx, int64_t nnodes, int64_t n,
+        int64_t nsites, const int64_t *idx, const int64_t *ptr, const double *esd,
+        const double *subtree_probability, const double *node_to_distn_array,
+        double *joint_distns)
+{
+    return distn_pass(ctx, true, nnodes, n, nsites, idx, ptr, esd, nullptr,
+                      subtree_probability, const_cast<double *>(node_to_distn_array),
+                      joint_distns, nullptr);
+}

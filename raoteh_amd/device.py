@@ -163,6 +163,37 @@ class Context(object):
             _ptr(state_mask, c_int64),
             None if obs is None else _ptr(obs, c_double), _ptr(out, c_double)))
 
+    def node_to_distn(self, indices, indptr, esd, root_distn, pmap):
+        """Downward pass (mc0_esd_get_node_to_distn): returns (distn, status)."""
+        pmap = _f64(pmap)
+        indices, indptr, esd, nnodes, n, nsites = self._pass_args(
+            indices, indptr, esd, pmap)
+        out = np.empty(pmap.shape, dtype=np.float64)
+        status = np.zeros(nsites, dtype=np.int32)
+        rd = None if root_distn is None else _f64(root_distn)
+        if rd is not None and rd.shape != (n,):
+            raise ValueError('inconsistent root distribution')
+        _lib.check(_lib.lib().rt_mc0_esd_get_node_to_distn(
+            self._h, nnodes, n, nsites, _ptr(indices, c_int64), _ptr(indptr, c_int64),
+            _ptr(esd, c_double), None if rd is None else _ptr(rd, c_double),
+            _ptr(pmap, c_double), _ptr(out, c_double), _ptr(status, c_int32)))
+        return out, status
+
+    def joint_endpoint_distn(self, indices, indptr, esd, pmap, distn):
+        """mc0_esd_get_joint_endpoint_distn: f64[..., nnodes, n, n] keyed by
+        the child index."""
+        pmap, distn = _f64(pmap), _f64(distn)
+        indices, indptr, esd, nnodes, n, nsites = self._pass_args(
+            indices, indptr, esd, pmap)
+        if distn.shape != pmap.shape:
+            raise ValueError('shape mismatch')
+        out = np.empty(pmap.shape + (n,), dtype=np.float64)
+        _lib.check(_lib.lib().rt_mc0_esd_get_joint_endpoint_distn(
+            self._h, nnodes, n, nsites, _ptr(indices, c_int64), _ptr(indptr, c_int64),
+            _ptr(esd, c_double), _ptr(pmap, c_double), _ptr(distn, c_double),
+            _ptr(out, c_double)))
+        return out
+
     # ---- multi-GPU ---------------------------------------------------------
 
     @staticmethod

@@ -143,6 +143,27 @@ def test_passes_match_reference_golden(ra):
                                        node_to_allowed_states=allowed,
                                        root_distn=distn)
             assert lk == pytest.approx(c['likelihood'], rel=1e-13)
+        # downward pass + joint endpoint distributions (values from the reference's
+        # _mc0.get_node_to_distn / get_joint_endpoint_distn)
+        if 'distn' in c:
+            from raoteh_amd import _mc0_dense
+            dn = _mc0_dense.get_node_to_distn(T, root, pm, n, root_distn=distn)
+            TJ = _mc0_dense.get_joint_endpoint_distn(T, root, pm, dn, n)
+            for v in pre:
+                np.testing.assert_allclose(dn[v], c['distn'][str(v)], rtol=1e-12,
+                                           atol=1e-300)
+            for na, nb in nx.bfs_edges(T, root):
+                np.testing.assert_allclose(TJ[na][nb]['J'],
+                                           np.array(c['joint'][str(nb)]),
+                                           rtol=1e-12, atol=1e-300)
+            mask2, pm2, dn2, ej = ra.mcy.kitchen_sink(
+                T, root, n, node_to_allowed_states=allowed, root_distn=distn)
+            for v in pre:
+                np.testing.assert_allclose(dn2[v], c['distn'][str(v)], rtol=1e-12,
+                                           atol=1e-300)
+            for (na, nb), Jm in ej.items():
+                np.testing.assert_allclose(Jm, np.array(c['joint'][str(nb)]),
+                                           rtol=1e-12, atol=1e-300)
         # type z (_mcz.py:140-163)
         obs = dict((int(k), dict(enumerate(v))) for k, v in c['obs_lik'].items())
         nset = dict((int(k), set(v)) for k, v in c['set'].items())
@@ -150,6 +171,45 @@ def test_passes_match_reference_golden(ra):
                                      node_to_set=nset)
         for v in pre:
             np.testing.assert_allclose(pz[v], c['pmap_z'][str(v)], rtol=1e-13)
+
+
+def test_downward_pass_batched_and_zero_denominator(ra):
+    rng = np.random.RandomState(8)
+    T, root, leaves = ra.synth.random_tree(17, seed=9)
+    n = 5
+    for na, nb in nx.bfs_edges(T, root):
+        P = rng.exponential(size=(n, n))
+        T[na][nb]['P'] = P / P.sum(axis=1, keepdims=True)
+    pre, idx, ptr, esd = orc.get_esd_transitions(T, root, n)
+    nsites = 21
+    masks = (rng.uniform(size=(nsites, len(pre), n)) > 0.2).astype(np.int64)
+    masks[:, :, 0] = 1
+    pmap = np.empty(masks.shape)
+    ra.ctx.node_to_pmap(idx, ptr, esd, masks, pmap)
+    w = rng.uniform(0.1, 1, size=n)
+    dn, st = ra.ctx.node_to_distn(idx, ptr, esd, w, pmap)
+    J = ra.ctx.joint_endpoint_distn(idx, ptr, esd, pmap, dn)
+    assert not st.any()
+    for s in range(nsites):
+        want = orc.mc0_esd_get_node_to_distn(idx, ptr, esd, w, pmap[s])
+        np.testing.assert_allclose(dn[s], want, rtol=1e-12, atol=1e-300)
+        np.testing.assert_allclose(
+            J[s], orc.mc0_esd_get_joint_endpoint_distn(idx, ptr, esd, pmap[s], want),
+            rtol=1e-12, atol=1e-300)
+        np.testing.assert_allclose(dn[s].sum(axis=1), 1.0, rtol=1e-12)
+        # the joint of an edge marginalises to the two node distributions
+        for v in range(len(pre)):
+            for c in idx[ptr[v]:ptr[v + 1]]:
+                np.testing.assert_allclose(J[s, c].sum(axis=1), dn[s, v], rtol=1e-11,
+                                           atol=1e-15)
+                np.testing.assert_allclose(J[s, c].sum(axis=0), dn[s, c], rtol=1e-11,
+                                           atol=1e-15)
+    # a site whose root pmap is all zero: status 2 <-> NumericalZeroProb
+    pmap[3, 0, :] = 0.0
+    dn, st = ra.ctx.node_to_distn(idx, ptr, esd, w, pmap)
+    assert st[3] == 2 and not st[[0, 1, 2, 4]].any()
+    with pytest.raises(orc.NumericalZeroProb):
+        orc.mc0_esd_get_node_to_distn(idx, ptr, esd, w, pmap[3])
 
 
 def test_passes_batched_over_sites(ra):

@@ -109,6 +109,18 @@ def test_random_sparse_trees_type_y_and_z():
         else:
             lk = orc.mc0_get_likelihood(pmap[0], root_distn=distn)
             assert lk == pytest.approx(c['likelihood'], rel=RTOL)
+        # downward pass + joint endpoint distributions (reference _mc0.py:255-308,
+        # 382-462 / _mc0_dense.py:217-270,400-489)
+        if 'distn' in c:
+            dn = orc.mc0_esd_get_node_to_distn(idx, ptr, esd, distn, pmap)
+            J = orc.mc0_esd_get_joint_endpoint_distn(idx, ptr, esd, pmap, dn)
+            for i, v in enumerate(pre):
+                np.testing.assert_allclose(dn[i], c['distn'][str(v)], rtol=1e-12,
+                                           atol=1e-300)
+                assert dn[i].sum() == pytest.approx(1.0, rel=1e-12)
+                if str(v) in c['joint']:
+                    np.testing.assert_allclose(J[i], np.array(c['joint'][str(v)]),
+                                               rtol=1e-12, atol=1e-300)
         # type-z (reference _mcz.py:140-163)
         obs = np.array([c['obs_lik'][str(v)] for v in pre])
         pz = orc.mcy_esd_get_node_to_pmap(idx, ptr, esd, m2, obs_lik=obs)

@@ -291,6 +291,18 @@ def fixture_random_sparse(mods, ncases=24):
         except _util.StructuralZeroProb:
             rec['likelihood'] = 0.0
             rec['zero'] = True
+        # downward pass + joint endpoint distributions (_mc0.py:255-308,382-462)
+        if not rec['zero']:
+            nd = _mc0.get_node_to_distn(T_aug, root, pmap, root_distn=distn_dict)
+            rec['distn'] = pmap_json(nd, n)
+            TJ = _mc0.get_joint_endpoint_distn(T_aug, root, pmap, nd)
+            joint = {}
+            for na, nb in nx.bfs_edges(T, root):
+                Jm = np.zeros((n, n))
+                for sa, sb, dat in TJ[na][nb]['J'].edges(data=True):
+                    Jm[sa, sb] = dat['weight']
+                joint[str(int(nb))] = Jm.tolist()
+            rec['joint'] = joint
         # type-z: random likelihood for every (node, state)
         obs = dict((v, dict((s, float(rng.uniform(0.1, 1.0)))
                             for s in range(n))) for v in T)
