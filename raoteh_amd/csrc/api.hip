@@ -648,7 +648,8 @@ static int sites_alloc(rt_sites *s, bool generic)
         const int64_t nt = (n + 15) / 16;
         const int64_t waves = nt == 3 ? 3 : 4;
         const int64_t tiles = waves / nt;
-        s->npartials = (s->nblocks + tiles - 1) / tiles * waves;
+        s->npartials = s->mfma_solo ? (s->nblocks + 3) / 4 * 4
+                                    : (s->nblocks + tiles - 1) / tiles * waves;
     }
     hipError_t e = hipMalloc((void **)&s->d_ops, s->ops.size() * sizeof(rt_op));
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_obs, std::max<int64_t>(s->obs_bytes, 1024));
@@ -671,11 +672,13 @@ static int sites_alloc(rt_sites *s, bool generic)
         const bool fuse = s->layout == RT_LAYOUT_LANE && s->lane_dma &&
                           (s->lane_ring == 0 || s->lane_ring >= 2) &&
                           !getenv("RAOTEH_LANE_NO_FUSE");
-        const std::vector<int32_t> prog =
-            lane_program(s, s->layout == RT_LAYOUT_LANE ? n * 512 : 2048, fuse);
+        // bytes of one accumulator slot of one wave: lane family n doubles per lane,
+        // MFMA split-M 4 (own rows), MFMA solo the whole message (NT*4)
+        const int64_t slot_bytes = s->layout == RT_LAYOUT_LANE ? n * 512
+                                 : s->mfma_solo ? ((n + 15) / 16) * 4 * 512 : 2048;
+        const std::vector<int32_t> prog = lane_program(s, slot_bytes, fuse);
         s->lane_nprog = (int64_t)(prog.size() / 4) - 1;     // without the sentinel
-        s->lane_stack_slots =
-            program_stack_slots(prog, s->layout == RT_LAYOUT_LANE ? n * 512 : 2048);
+        s->lane_stack_slots = program_stack_slots(prog, slot_bytes);
         e = hipMalloc((void **)&s->d_lane_ops, prog.size() * 4);
         if (e == hipSuccess)
             e = hipMemcpy(s->d_lane_ops, prog.data(), prog.size() * 4, hipMemcpyHostToDevice);
@@ -738,6 +741,7 @@ extern "C" int rt_sites_create(rt_model *m, int64_t nsites, int kind, int64_t no
         const int64_t ptab = ((int64_t)(m->ops.size() + 1) * m->n * m->n * 8 + 15) & ~15ll;
         s->lane_dma = ptab + 4 * (3 * 64 * np * 8 + stack) <= 80 * 1024;
     }
+    s->mfma_solo = s->layout == RT_LAYOUT_MFMA && m->n <= 32 && !getenv("RAOTEH_MFMA_NO_SOLO");
     if (const char *v = getenv("RAOTEH_LANE_VARIANT")) s->lane_dma = strcmp(v, "dma") == 0;
     if (const char *r = getenv("RAOTEH_LANE_RING")) s->lane_ring = atoi(r);
     else s->lane_ring = s->lane_dma ? 0 : 8;      // 0: rt_launch_prune picks what fits
@@ -763,6 +767,7 @@ extern "C" int rt_sites_clone(rt_sites *src, rt_sites **out)
     s->nobs = src->nobs;
     s->layout = src->layout;
     s->lane_dma = src->lane_dma;
+    s->mfma_solo = src->mfma_solo;
     s->lane_ring = src->lane_ring;
     s->node_obs = src->node_obs;
     s->ops = src->ops;

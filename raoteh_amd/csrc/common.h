@@ -113,6 +113,7 @@ struct rt_sites {
     int layout = RT_LAYOUT_LANE;
     bool lane_dma = false;          // lane family: LDS-DMA ring instead of VGPR ring
     int lane_ring = 8;              // ring depth of the lane kernel
+    bool mfma_solo = false;         // MFMA family, n <= 32: one wave owns a tile outright
     int64_t nblocks = 0;            // site blocks (64 or 16 sites each)
     int64_t obs_bytes = 0;
     std::vector<int32_t> node_obs;  // per node: stream position or -1

@@ -771,6 +771,184 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
 }
 
 // ---------------------------------------------------------------------------
+// 4 < n <= 32: v_mfma_f64_16x16x4_f64, ONE wave owns a 16-site tile outright
+// ---------------------------------------------------------------------------
+//
+// With at most two row tiles the whole message (NT*4 doubles per lane) and the
+// A fragments of an edge (NT*KS doubles per lane) fit comfortably in registers,
+// so a wave computes all rows itself: the D registers ARE the next B operand
+// (same lane, same register), nothing is exchanged between waves, there is no
+// barrier anywhere, and four independent waves share a workgroup only to share
+// the launch.  Stack: [slot][NT*4][lane] doubles per wave in LDS, top cached in
+// registers (same LOP_* program as the other kernels).
+
+template <int NT, int KS>
+__global__ void __launch_bounds__(256)
+prune_mfma_solo_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
+                       const int4_t *__restrict__ prog, int nops,
+                       const double *__restrict__ obs, int K,  // [blk16][K][KP][64][2]
+                       const double *__restrict__ root_w, int n, int lds_slots,
+                       double *__restrict__ loglik, int *__restrict__ status,
+                       double *__restrict__ partial, long nsites, long nblocks16)
+{
+    constexpr int MW = NT * 4;                 // message doubles per lane
+    constexpr int KP = (KS + 1) / 2;           // k-step pairs
+    constexpr int NA = NT * 2 * KP;            // A-fragment doubles per lane and step
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long gw = (long)blockIdx.x * 4 + wave;           // site tile of this wave
+    if (gw >= nblocks16) {                                  // wave-uniform; no barriers
+        if (lane == 0) { partial[gw * 2] = 0.0; partial[gw * 2 + 1] = 0.0; }
+        return;
+    }
+    unsigned char *stack = smem + (size_t)wave * lds_slots * (MW * 512) + lane * 8;
+    const RT_CONST_AS int4_t *prog_c = (const RT_CONST_AS int4_t *)prog;
+    const double *ag = Pfrag + lane * 2;                    // [op][m][q][lane][2]
+    constexpr size_t ASTRIDE = (size_t)NT * KP * 128;
+    const double *og = obs + (size_t)gw * K * (KP * 128) + lane * 2;
+
+    double an[NA];                // A fragments of the NEXT step
+    double on[2 * KP];            // next observation of the stream (B-operand order)
+#pragma unroll
+    for (int j = 0; j < 2 * KP; ++j) on[j] = 1.0;
+    int4_t op = prog_c[0];
+    int knext = 0;
+#pragma unroll
+    for (int q = 0; q < NT * KP; ++q) {
+        const double2 v = *(const double2 *)(ag + q * 128);
+        an[2 * q] = v.x;
+        an[2 * q + 1] = v.y;
+    }
+    if (K > 0) {
+#pragma unroll
+        for (int q = 0; q < KP; ++q) {
+            const double2 v = *(const double2 *)(og + (size_t)q * 128);
+            on[2 * q] = v.x;
+            on[2 * q + 1] = v.y;
+        }
+    }
+
+    double lik = 0.0;
+    bool negative = false;
+    double cur[MW];
+#pragma unroll
+    for (int j = 0; j < MW; ++j) cur[j] = 1.0;
+
+    for (int i = 0; i < nops; ++i) {
+        const int flags = op.x;
+        double x[MW];
+        if (flags & LOP_INTERNAL) {
+            if (flags & LOP_X_CUR) {
+#pragma unroll
+                for (int j = 0; j < MW; ++j) x[j] = cur[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < MW; ++j) x[j] = *(const double *)(stack + op.y + j * 512);
+            }
+            if (flags & LOP_OBS) {
+#pragma unroll
+                for (int j = 0; j < KS; ++j) x[j] *= on[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < MW; ++j)
+                x[j] = (flags & LOP_OBS) ? (j < 2 * KP ? on[j] : 0.0) : 1.0;
+        }
+        if (flags & LOP_OBS) knext += 1;
+        if (flags & LOP_ROOT) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                const int row = 4 * j + (lane >> 4);
+                const double w = row < n ? root_w[row] : 0.0;
+                negative |= (row < n) && (x[j] < 0.0);
+                sacc += w * fmax(x[j], 0.0);
+            }
+            sacc += __shfl_xor(sacc, 16, 64);
+            sacc += __shfl_xor(sacc, 32, 64);
+            lik = sacc;
+            break;
+        }
+        double a[NA];
+#pragma unroll
+        for (int j = 0; j < NA; ++j) a[j] = an[j];
+
+        // start everything the next step needs
+        const int inext = (i + 1 < nops) ? i + 1 : i;
+        const int4_t opn = prog_c[inext];
+        if (!(opn.x & LOP_ROOT)) {
+#pragma unroll
+            for (int q = 0; q < NT * KP; ++q) {
+                const double2 v = *(const double2 *)(ag + (size_t)inext * ASTRIDE + q * 128);
+                an[2 * q] = v.x;
+                an[2 * q + 1] = v.y;
+            }
+        }
+        if ((flags & LOP_OBS) && knext < K) {
+#pragma unroll
+            for (int q = 0; q < KP; ++q) {
+                const double2 v = *(const double2 *)(og + ((size_t)knext * KP + q) * 128);
+                on[2 * q] = v.x;
+                on[2 * q + 1] = v.y;
+            }
+        }
+
+        double4_t acc[NT];
+#pragma unroll
+        for (int m = 0; m < NT; ++m) acc[m] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+#pragma unroll
+            for (int m = 0; m < NT; ++m)
+                acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m * 2 * KP + kk], x[kk],
+                                                              acc[m], 0, 0, 0);
+        }
+        double t[MW];
+#pragma unroll
+        for (int m = 0; m < NT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[m * 4 + r] = acc[m][r];
+
+        if (flags & LOP_FIRST) {
+            if (flags & LOP_SPILL) {
+#pragma unroll
+                for (int j = 0; j < MW; ++j) *(double *)(stack + op.w + j * 512) = cur[j];
+            }
+#pragma unroll
+            for (int j = 0; j < MW; ++j) cur[j] = t[j];
+        } else if (flags & LOP_DST_CUR) {
+#pragma unroll
+            for (int j = 0; j < MW; ++j) cur[j] *= t[j];
+        } else if (flags & LOP_FAST) {     // un-spill: the parent's step is next
+#pragma unroll
+            for (int j = 0; j < MW; ++j)
+                cur[j] = *(const double *)(stack + op.z + j * 512) * t[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < MW; ++j) {
+                double *d = (double *)(stack + op.z + j * 512);
+                *d = *d * t[j];
+            }
+        }
+        op = opn;
+    }
+
+    // lanes 0..15 own the 16 sites of the tile
+    const long site = gw * 16 + (lane & 15);
+    const bool valid = lane < 16 && site < nsites;
+    double sum, nzero;
+    finish_site(lik, negative, valid, loglik, status, site, sum, nzero);
+    sum = wave_sum(sum);
+    nzero = wave_sum(nzero);
+    if (lane == 0) {
+        partial[gw * 2] = sum;
+        partial[gw * 2 + 1] = nzero;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // generic fallback: lane per site, accumulator stack in global scratch
 // ---------------------------------------------------------------------------
 
@@ -1148,11 +1326,23 @@ static int launch_lane(rt_model *m, rt_sites *s, const char **name)
 template <int NT, int KS>
 static int launch_mfma_inst(rt_model *m, rt_sites *s)
 {
+    const int lds_slots = std::max(1, s->lane_stack_slots);
+    if (s->mfma_solo) {
+        if constexpr (NT <= 2) {
+            const int lds = 4 * lds_slots * (NT * 4 * 512);
+            const unsigned grid = (unsigned)((s->nblocks + 3) / 4);
+            auto kern = prune_mfma_solo_kernel<NT, KS>;
+            RT_HIP(hipFuncSetAttribute((const void *)kern,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, m->ctx->stream, m->d_Pfrag,
+                               (const int4_t *)s->d_lane_ops, (int)s->ops.size(), s->d_obs,
+                               (int)s->nobs, m->d_root, (int)m->n, lds_slots, s->d_loglik,
+                               s->d_status, s->d_partial, (long)s->nsites, (long)s->nblocks);
+            return RT_OK;
+        }
+    }
     constexpr int WAVES = (NT == 3) ? 3 : 4;
     constexpr int TILES = WAVES / NT;
-    // the deepest accumulator never leaves the register cache
-    const int lds_slots = std::max(1, m->max_depth - 1);
-
     const int lds = (TILES * NT * 4 * 64 + TILES * NT * 16) * 8 + WAVES * lds_slots * 2048;
     const unsigned grid = (unsigned)((s->nblocks + TILES - 1) / TILES);
     auto kern = prune_mfma_kernel<NT, KS>;
@@ -1170,7 +1360,8 @@ static int launch_mfma(rt_model *m, rt_sites *s, const char **name)
 {
     static char buf[17][32];
     const int ks = ks_of(m->n);
-    snprintf(buf[ks], sizeof(buf[ks]), "prune_mfma<%d,%d>", nt_of(m->n), ks);
+    snprintf(buf[ks], sizeof(buf[ks]), "prune_mfma%s<%d,%d>", s->mfma_solo ? "_solo" : "",
+             nt_of(m->n), ks);
     *name = buf[ks];
     switch (ks) {
     case 2: return launch_mfma_inst<1, 2>(m, s);
