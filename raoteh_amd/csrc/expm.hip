@@ -49,6 +49,24 @@ __constant__ double c_b13[14] = {64764752532480000., 32382376266240000.,
 constexpr int TPB = 256;
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+// Wave-wide unsigned max in registers (DPP scan: row_shr 1/2/4/8, row_bcast 15/31;
+// the total lands in lane 63).  Checked against a shuffle reduction by
+// tools/micro/dpp_umax_test.hip.  Six dependent ds_bpermute round trips (what
+// __shfl_xor compiles to) would cost ~10x more per pivot step.
+__device__ __forceinline__ unsigned wave_umax_dpp(unsigned v)
+{
+#define RT_DPP(ctrl, rmask) (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, false)
+    unsigned t;
+    t = RT_DPP(0x111, 0xf); v = v > t ? v : t;   // row_shr:1
+    t = RT_DPP(0x112, 0xf); v = v > t ? v : t;   // row_shr:2
+    t = RT_DPP(0x114, 0xf); v = v > t ? v : t;   // row_shr:4
+    t = RT_DPP(0x118, 0xf); v = v > t ? v : t;   // row_shr:8
+    t = RT_DPP(0x142, 0xa); v = v > t ? v : t;   // row_bcast:15
+    t = RT_DPP(0x143, 0xc); v = v > t ? v : t;   // row_bcast:31
+#undef RT_DPP
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // C = A * B (n x n, leading dimension ld, in LDS) on the f64 matrix pipe.
 // A lane l: A[16m + (l&15)][4kk + (l>>4)], B lane l: B[4kk + (l>>4)][16j + (l&15)],
 // D lane l reg r: C[16m + 4r + (l>>4)][16j + (l&15)].  Elements outside n x n
@@ -97,6 +115,12 @@ __device__ __forceinline__ void lds_matmul(const double *A, const double *B, dou
     __syncthreads();
 }
 
+// all n x n elements, four rows per pass, no integer division: thread (tid>>6, tid&63)
+#define RT_FOR_EACH_ELEMENT(I, J, O)                                              \
+    for (int I = tid >> 6, J = tid & 63, O = (tid >> 6) * ld + (tid & 63); I < n; \
+         I += 4, O += 4 * ld)                                                      \
+        if (J < n)
+
 __global__ void __launch_bounds__(TPB)
 expm_kernel(int n, const double *__restrict__ Q, const int *__restrict__ qidx,
             const double *__restrict__ tt, double *__restrict__ P,
@@ -143,8 +167,8 @@ expm_kernel(int n, const double *__restrict__ Q, const int *__restrict__ qidx,
     const double t = tt[b];
 
     // A = Q * t
-    for (int e = tid; e < nn; e += TPB) {
-        const int i = e / n, j = e - i * n;
+    RT_FOR_EACH_ELEMENT(i, j, o_unused_) {
+        const int e = i * n + j;
         B0[i * ld + j] = Qb[e] * t;
     }
     __syncthreads();
@@ -176,9 +200,8 @@ expm_kernel(int n, const double *__restrict__ Q, const int *__restrict__ qidx,
     if (s > 0) {
         __syncthreads();
         const double sc = ldexp(1.0, -s);
-        for (int e = tid; e < nn; e += TPB) {
-            const int i = e / n, j = e - i * n;
-            B0[i * ld + j] *= sc;
+        RT_FOR_EACH_ELEMENT(i, j, o) {
+            B0[o] *= sc;
         }
         __syncthreads();
     }
@@ -188,27 +211,23 @@ expm_kernel(int n, const double *__restrict__ Q, const int *__restrict__ qidx,
         lds_matmul(B0, B0, B1, n, ld, NT, KS);         // A2
         lds_matmul(B1, B1, B2, n, ld, NT, KS);         // A4
         lds_matmul(B2, B1, B3, n, ld, NT, KS);         // A6
-        for (int e = tid; e < nn; e += TPB) {
-            const int i = e / n, j = e - i * n, o = i * ld + j;
+        RT_FOR_EACH_ELEMENT(i, j, o) {
             B4[o] = c_b13[13] * B3[o] + c_b13[11] * B2[o] + c_b13[9] * B1[o];
         }
         __syncthreads();
         lds_matmul(B3, B4, B4, n, ld, NT, KS);         // A6 * (...)
-        for (int e = tid; e < nn; e += TPB) {
-            const int i = e / n, j = e - i * n, o = i * ld + j;
+        RT_FOR_EACH_ELEMENT(i, j, o) {
             B4[o] += c_b13[7] * B3[o] + c_b13[5] * B2[o] + c_b13[3] * B1[o] +
                      (i == j ? c_b13[1] : 0.0);
         }
         __syncthreads();
         lds_matmul(B0, B4, B4, n, ld, NT, KS);         // U = A * W
-        for (int e = tid; e < nn; e += TPB) {          // A is dead: reuse B0
-            const int i = e / n, j = e - i * n, o = i * ld + j;
+        RT_FOR_EACH_ELEMENT(i, j, o) {                 // A is dead: reuse B0
             B0[o] = c_b13[12] * B3[o] + c_b13[10] * B2[o] + c_b13[8] * B1[o];
         }
         __syncthreads();
         lds_matmul(B3, B0, B0, n, ld, NT, KS);
-        for (int e = tid; e < nn; e += TPB) {
-            const int i = e / n, j = e - i * n, o = i * ld + j;
+        RT_FOR_EACH_ELEMENT(i, j, o) {
             B0[o] += c_b13[6] * B3[o] + c_b13[4] * B2[o] + c_b13[2] * B1[o] +
                      (i == j ? c_b13[0] : 0.0);
         }
@@ -221,8 +240,7 @@ expm_kernel(int n, const double *__restrict__ Q, const int *__restrict__ qidx,
         if (m >= 7) lds_matmul(B2, B1, B3, n, ld, NT, KS);           // A6
         if (m >= 9) lds_matmul(B3, B1, B4, n, ld, NT, KS);           // A8
         // W (odd coefficients) -> B4, V (even coefficients) -> B3, elementwise
-        for (int e = tid; e < nn; e += TPB) {
-            const int i = e / n, j = e - i * n, o = i * ld + j;
+        RT_FOR_EACH_ELEMENT(i, j, o) {
             const double a2 = B1[o];
             const double a4 = (m >= 5) ? B2[o] : 0.0;
             const double a6 = (m >= 7) ? B3[o] : 0.0;
@@ -269,31 +287,43 @@ expm_kernel(int n, const double *__restrict__ Q, const int *__restrict__ qidx,
     bool used = lane >= n;              // replicated in every wave: row = lane
     for (int k = 0; k < n; ++k) {
         const double *cb = colbuf + (k & 1) * 64;
-        // every wave finds the pivot row itself
-        double pv = used ? -1.0 : fabs(cb[lane]);
-        int pr = lane;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const double ov = __shfl_xor(pv, o, 64);
-            const int orow = __shfl_xor(pr, o, 64);
-            if (ov > pv || (ov == pv && orow < pr)) { pv = ov; pr = orow; }
-        }
-        pr = __builtin_amdgcn_readfirstlane(pr);
-        if (!(pv > 0.0)) {                       // singular (or NaN): wave-uniform
+        // Every wave finds the pivot row itself.  Key = the top 26 bits of |value|
+        // (exponent + 15 mantissa bits: partial pivoting does not need more) with
+        // 63 - lane in the low 6 bits, so one unsigned max yields the row too
+        // (ties -> lowest row).
+        const unsigned hi = (unsigned)(__double_as_longlong(fabs(cb[lane])) >> 32);
+        unsigned key = used ? 0u : ((hi & ~63u) | (63u - (unsigned)lane));
+        key = wave_umax_dpp(key);
+        const int pr = 63 - (int)(key & 63u);
+        const double pvt = cb[pr];
+        if ((key & ~63u) == 0u || !(fabs(pvt) > 0.0) || !(fabs(pvt) < 1e308 * 10.0)) {
+            // zero / denormal column, or inf / NaN: wave-uniform
             if (tid == 0) ibuf[2] = 1;
             break;
         }
         if (lane == pr) used = true;
-        const double rinv = 1.0 / cb[pr];
+        const double rinv = 1.0 / pvt;
         if (tid == 0) { dinv[pr] = rinv; kof[pr] = k; }
         // pivot-row owners publish their 8 columns
         if (ri == (pr & 15)) {
-            const int a0 = pr >> 4;
+            double *rb = rowbuf + ci;
+            switch (pr >> 4) {                  // wave-uniform
+            case 0:
 #pragma unroll
-            for (int bb = 0; bb < 8; ++bb) {
-                const double v = a0 == 0 ? g[0][bb] : a0 == 1 ? g[1][bb]
-                               : a0 == 2 ? g[2][bb] : g[3][bb];
-                rowbuf[ci + 16 * bb] = v;
+                for (int bb = 0; bb < 8; ++bb) rb[16 * bb] = g[0][bb];
+                break;
+            case 1:
+#pragma unroll
+                for (int bb = 0; bb < 8; ++bb) rb[16 * bb] = g[1][bb];
+                break;
+            case 2:
+#pragma unroll
+                for (int bb = 0; bb < 8; ++bb) rb[16 * bb] = g[2][bb];
+                break;
+            default:
+#pragma unroll
+                for (int bb = 0; bb < 8; ++bb) rb[16 * bb] = g[3][bb];
+                break;
             }
         }
         __syncthreads();
@@ -313,13 +343,24 @@ expm_kernel(int n, const double *__restrict__ Q, const int *__restrict__ qidx,
         }
         // owners of column k+1 publish it for the next step (other colbuf half)
         if (k + 1 < n && ci == ((k + 1) & 15)) {
-            const int b1 = (k + 1) >> 4;
-            double *nb = colbuf + ((k + 1) & 1) * 64;
+            double *nb = colbuf + ((k + 1) & 1) * 64 + ri;
+            switch ((k + 1) >> 4) {             // wave-uniform
+            case 0:
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const double v = b1 == 0 ? g[a][0] : b1 == 1 ? g[a][1]
-                               : b1 == 2 ? g[a][2] : g[a][3];
-                nb[ri + 16 * a] = v;
+                for (int a = 0; a < 4; ++a) nb[16 * a] = g[a][0];
+                break;
+            case 1:
+#pragma unroll
+                for (int a = 0; a < 4; ++a) nb[16 * a] = g[a][1];
+                break;
+            case 2:
+#pragma unroll
+                for (int a = 0; a < 4; ++a) nb[16 * a] = g[a][2];
+                break;
+            default:
+#pragma unroll
+                for (int a = 0; a < 4; ++a) nb[16 * a] = g[a][3];
+                break;
             }
         }
         __syncthreads();
@@ -347,13 +388,13 @@ expm_kernel(int n, const double *__restrict__ Q, const int *__restrict__ qidx,
     __syncthreads();
     for (int q = 0; q < s; ++q) lds_matmul(Xb, Xb, Xb, n, ld, NT, KS);
 
-    for (int e = tid; e < nn; e += TPB) {
-        const int i = e / n, j = e - i * n;
+    RT_FOR_EACH_ELEMENT(i, j, o_unused_) {
+        const int e = i * n + j;
         Pb[e] = Xb[i * ld + j];
     }
     if (step >= 0 && frag_kind == 0) {
-        for (int e = tid; e < nn; e += TPB) {
-            const int i = e / n, j = e - i * n;
+        RT_FOR_EACH_ELEMENT(i, j, o_unused_) {
+            const int e = i * n + j;
             Pfrag[(long)step * nn + e] = Xb[i * ld + j];
         }
     } else if (step >= 0 && frag_kind == 1) {
