@@ -198,8 +198,17 @@ int rt_build_schedule(int64_t nnodes, const int64_t *tree_csr_indices,
             const int64_t *tree_csr_indptr, int32_t *ops /*[nnodes][4]*/,
             int32_t *depth);
 /* Process-wide options: "force_generic" (0/1) routes every later
- * rt_sites_create to the generic fallback kernel.                           */
+ * rt_sites_create to the generic fallback kernel.  "jit" (-1 automatic, 0
+ * never, 1 always): rt_sites_create compiles (hiprtc, once per distinct tree
+ * and set of observed nodes) a pruning kernel specialised for the tree when
+ * n <= 4; automatic = batches of at least 16 384 sites.  Results are
+ * bit-identical with and without it.                                         */
 int rt_set_option(const char *key, int64_t value);
+/* Diagnostics, host only: the HIP source rt_sites_create would compile for this
+ * tree (n <= 4), observation stream obs_nodes and prefetch distance.         */
+int rt_jit_source(int64_t nnodes, const int64_t *tree_csr_indices,
+            const int64_t *tree_csr_indptr, int64_t n, int64_t nobs,
+            const int64_t *obs_nodes, int64_t prefetch, char *buf, int64_t capacity);
 
 /* obs_nodes int64[nobs]: preorder indices of the nodes that carry per-site
  * data (all other nodes are unrestricted).  data layout per `kind` above.   */

@@ -88,6 +88,8 @@ SIGNATURES = {
     'rt_model_get_schedule': (c_int, [c_void_p, _p_i32, c_int64, _p_i64]),
     'rt_build_schedule': (c_int, [c_int64, _p_i64, _p_i64, _p_i32, _p_i32]),
     'rt_set_option': (c_int, [c_char_p, c_int64]),
+    'rt_jit_source': (c_int, [c_int64, _p_i64, _p_i64, c_int64, c_int64, _p_i64, c_int64,
+                              c_char_p, c_int64]),
     'rt_sites_create': (c_int, [c_void_p, c_int64, c_int, c_int64, _p_i64,
                                 c_void_p, POINTER(c_void_p)]),
     'rt_sites_clone': (c_int, [c_void_p, POINTER(c_void_p)]),

@@ -102,6 +102,7 @@ extern "C" int rt_ctx_destroy(rt_ctx *ctx)
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     rt_comm_destroy(ctx);
+    rt_jit_release(ctx);
     for (auto &s : ctx->slots) {
         drain_slot(s, true);
         for (auto ev : s.pool) hipEventDestroy(ev);
@@ -517,11 +518,16 @@ extern "C" int rt_model_schedule_depth(const rt_model *m)
 
 static const int RT_FAST_MAX_DEPTH = 16;   // LDS accumulator stack of the fast kernels
 static int g_force_generic = 0;
+// tree-specialised kernels (jit.hip): -1 = automatic (batches of at least
+// RT_JIT_MIN_SITES sites), 0 = never, 1 = always (lane family only)
+static int g_jit = -1;
+static const int64_t RT_JIT_MIN_SITES = 16384;
 
 extern "C" int rt_set_option(const char *key, int64_t value)
 {
     RT_REQUIRE(key, "null key");
     if (strcmp(key, "force_generic") == 0) { g_force_generic = value != 0; return RT_OK; }
+    if (strcmp(key, "jit") == 0) { g_jit = value < 0 ? -1 : value != 0; return RT_OK; }
     rt_set_error("unknown option %s", key);
     return RT_ERR_INVALID;
 }
@@ -635,7 +641,8 @@ static int sites_alloc(rt_sites *s, bool generic)
     const int64_t K = s->nobs;
     int64_t padded;
     if (s->layout == RT_LAYOUT_LANE) {
-        s->nblocks = std::max<int64_t>(1, (s->nsites + 63) / 64);
+        // an even number of blocks: the LDS-DMA kernel may give a wave two
+        s->nblocks = (std::max<int64_t>(1, (s->nsites + 63) / 64) + 1) & ~1ll;
         const int64_t np = (n + 1) & ~1ll;
         s->obs_bytes = s->nblocks * K * 64 * np * 8;
         padded = s->nblocks * 64;
@@ -687,6 +694,53 @@ static int sites_alloc(rt_sites *s, bool generic)
         rt_set_error("rt_sites: %s", hipGetErrorString(e));
         return e == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_HIP;
     }
+    return RT_OK;
+}
+
+// Tree-specialised kernel for this batch (lane family): source from the
+// schedule, compiled once per distinct (tree, observed nodes) and device.
+static int sites_jit(rt_sites *s, bool generic)
+{
+    int want = g_jit;
+    if (const char *v = getenv("RAOTEH_JIT")) want = atoi(v);
+    if (want < 0) want = s->nsites >= RT_JIT_MIN_SITES;
+    if (!want || generic || s->layout != RT_LAYOUT_LANE) return RT_OK;
+    // straight-line code: keep it inside the instruction cache's reach
+    if (s->ops.size() > 1024) return RT_OK;
+    int D = 6;
+    if (const char *v = getenv("RAOTEH_JIT_PREFETCH")) D = std::max(1, atoi(v));
+    int LA = 2;
+    if (const char *v = getenv("RAOTEH_JIT_LOOKAHEAD")) LA = std::max(1, atoi(v));
+    const std::string src = rt_jit_lane_source(s->ops, (int)s->model->n, (int)s->nobs, D, LA);
+    s->jit_prefetch = D;
+    return rt_jit_get(s->model->ctx, src, &s->jit_fn);
+}
+
+extern "C" int rt_jit_source(int64_t nnodes, const int64_t *idx, const int64_t *ptr,
+                             int64_t n, int64_t nobs, const int64_t *obs_nodes,
+                             int64_t prefetch, char *buf, int64_t capacity)
+{
+    RT_REQUIRE(nnodes >= 1 && ptr && (idx || nnodes == 1) && buf && capacity > 0,
+               "bad arguments");
+    RT_REQUIRE(n >= 1 && n <= 4, "tree-specialised kernels exist for n <= 4");
+    rt_model m;
+    m.nnodes = nnodes;
+    if (nnodes > 1) m.indices.assign(idx, idx + (nnodes - 1));
+    m.indptr.assign(ptr, ptr + nnodes + 1);
+    build_schedule(&m);
+    std::vector<int32_t> node_obs((size_t)nnodes, -1);
+    for (int64_t j = 0; j < nobs; ++j) {
+        RT_REQUIRE(obs_nodes[j] >= 0 && obs_nodes[j] < nnodes, "obs_nodes out of range");
+        node_obs[(size_t)obs_nodes[j]] = (int32_t)j;
+    }
+    int32_t k = 0;
+    for (auto &op : m.ops)
+        if (node_obs[(size_t)op.node] >= 0) op.obs = k++;
+    const int LA = getenv("RAOTEH_JIT_LOOKAHEAD") ? std::max(1, atoi(getenv("RAOTEH_JIT_LOOKAHEAD"))) : 2;
+    const std::string src = rt_jit_lane_source(m.ops, (int)n, (int)nobs, (int)prefetch, LA);
+    RT_REQUIRE((int64_t)src.size() + 1 <= capacity, "buffer too small: %lld bytes needed",
+               (long long)src.size() + 1);
+    memcpy(buf, src.c_str(), src.size() + 1);
     return RT_OK;
 }
 
@@ -747,6 +801,7 @@ extern "C" int rt_sites_create(rt_model *m, int64_t nsites, int kind, int64_t no
     else s->lane_ring = s->lane_dma ? 0 : 8;      // 0: rt_launch_prune picks what fits
     int rc = sites_alloc(s, generic);
     if (rc == RT_OK) rc = rt_sites_pack(s, kind, src_of_k.data(), data);
+    if (rc == RT_OK) rc = sites_jit(s, generic);
     if (rc != RT_OK) {
         rt_sites_destroy(s);
         return rc;
@@ -769,6 +824,8 @@ extern "C" int rt_sites_clone(rt_sites *src, rt_sites **out)
     s->lane_dma = src->lane_dma;
     s->mfma_solo = src->mfma_solo;
     s->lane_ring = src->lane_ring;
+    s->jit_fn = src->jit_fn;
+    s->jit_prefetch = src->jit_prefetch;
     s->node_obs = src->node_obs;
     s->ops = src->ops;
     int rc = sites_alloc(s, src->d_scratch != nullptr);

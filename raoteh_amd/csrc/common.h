@@ -131,6 +131,8 @@ struct rt_sites {
     hipEvent_t ev_reduced = nullptr;    // totals written (compute stream)
     hipEvent_t ev_comm_done = nullptr;  // all-reduce of the totals finished (comm stream)
     bool comm_pending = false;
+    void *jit_fn = nullptr;         // hipFunction_t of the tree-specialised kernel (jit.hip)
+    int jit_prefetch = 0;           // its prefetch distance (stream positions)
     double *d_scratch = nullptr;    // generic kernel message stack
     int64_t scratch_bytes = 0;
 };
@@ -146,6 +148,11 @@ int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
                    double *d_Pfrag);
 int rt_launch_pfrag(rt_model *m);
 int rt_launch_prune(rt_model *m, rt_sites *s);
+// jit.hip
+std::string rt_jit_lane_source(const std::vector<rt_op> &ops, int n, int K, int D, int LA);
+int rt_jit_get(rt_ctx *ctx, const std::string &src, void **fn);
+void rt_jit_release(const rt_ctx *ctx);
+int rt_launch_prune_jit(rt_model *m, rt_sites *s);
 int rt_sites_pack(rt_sites *s, int kind, const int64_t *obs_order,
                   const void *data);
 

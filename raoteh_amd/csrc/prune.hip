@@ -128,22 +128,38 @@ enum {
     LOP_STOP = 512      // sentinel entry after the last step (lane kernels)
 };
 
-template <int N, bool PLDS>
+// B = site blocks per wave: B = 2 gives every lane two independent sites, which
+// (i) halves the scalar work, the schedule fetches and the P reads per site and
+// (ii) gives the scheduler two independent dependency chains to interleave.
+template <int N, bool PLDS, int B = 1>
 struct LaneCtx {
     const RT_CONST_AS int4_t *ops_c;
     const RT_CONST_AS double *P_c;       // step-ordered P through the scalar cache
     const double *P_l;                   // ... or the copy of it in LDS (PLDS)
     const RT_CONST_AS double *w_c;
-    unsigned char *stack;          // LDS, + lane * 8 bytes
+    unsigned char *stack[B];       // LDS, + lane * 8 bytes
     int nops;                      // program entries
     int nrec;                      // P records (>= nops: a fused entry spans 3)
     int pidx;                      // P record of the current step
     int i;                         // index of the current program entry
     int4_t op;                     // current step: {flags, pop_off, dst_off, spill_off}
     double p[N * N];               // transition matrix of the current step
-    double cur[N];                 // register-cached top accumulator
-    double lik;
-    bool negative;
+    double cur[B][N];              // register-cached top accumulator
+    double lik[B];
+    bool negative[B];
+
+    __device__ __forceinline__ void init()
+    {
+        pidx = 0;
+        i = 0;
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            lik[b] = 0.0;
+            negative[b] = false;
+#pragma unroll
+            for (int j = 0; j < N; ++j) cur[b][j] = 1.0;
+        }
+    }
 
     __device__ __forceinline__ void load_p(int ii)
     {
@@ -166,104 +182,125 @@ struct LaneCtx {
         load_p(pidx);
     }
 
-    __device__ __forceinline__ double lds_get(int off, int j) const
+    __device__ __forceinline__ double lds_get(int b, int off, int j) const
     {
-        return *(const double *)(stack + off + j * 512);
+        return *(const double *)(stack[b] + off + j * 512);
     }
-    __device__ __forceinline__ void lds_put(int off, int j, double v)
+    __device__ __forceinline__ void lds_put(int b, int off, int j, double v)
     {
-        *(double *)(stack + off + j * 512) = v;
+        *(double *)(stack[b] + off + j * 512) = v;
+    }
+
+    // t = P * x for every block
+    __device__ __forceinline__ void matvec(const double (&q)[N * N],
+                                           const double (&x)[B][N], double (&t)[B][N])
+    {
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                double sacc = q[r * N] * x[b][0];
+#pragma unroll
+                for (int j = 1; j < N; ++j) sacc = fma(q[r * N + j], x[b][j], sacc);
+                t[b][r] = sacc;
+            }
+        }
+    }
+
+    // where the result of a step goes (flags are wave-uniform)
+    __device__ __forceinline__ void deposit(int flags, const double (&t)[B][N],
+                                            bool unspill_is_fast)
+    {
+        if (flags & LOP_FIRST) {
+#pragma unroll
+            for (int b = 0; b < B; ++b)
+#pragma unroll
+                for (int r = 0; r < N; ++r) cur[b][r] = t[b][r];
+        } else if (flags & LOP_DST_CUR) {
+#pragma unroll
+            for (int b = 0; b < B; ++b)
+#pragma unroll
+                for (int r = 0; r < N; ++r) cur[b][r] *= t[b][r];
+        } else if (unspill_is_fast) {      // un-spill: the parent's step is next
+#pragma unroll
+            for (int b = 0; b < B; ++b)
+#pragma unroll
+                for (int r = 0; r < N; ++r) cur[b][r] = lds_get(b, op.z, r) * t[b][r];
+        } else {
+#pragma unroll
+            for (int b = 0; b < B; ++b)
+#pragma unroll
+                for (int r = 0; r < N; ++r)
+                    lds_put(b, op.z, r, lds_get(b, op.z, r) * t[b][r]);
+        }
+    }
+
+    __device__ __forceinline__ void spill()
+    {
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+#pragma unroll
+            for (int r = 0; r < N; ++r) lds_put(b, op.w, r, cur[b][r]);
     }
 
     // Execute the current step with observation vector o (ignored unless
     // HAS_OBS) and move to the next step.
     template <bool HAS_OBS>
-    __device__ __forceinline__ void compute(const double (&o)[N])
+    __device__ __forceinline__ void compute(const double (&o)[B][N])
     {
         const int flags = op.x;
+        double t[B][N];
         if (flags & LOP_FAST) {
-            if (flags & LOP_SPILL) {
-#pragma unroll
-                for (int r = 0; r < N; ++r) lds_put(op.w, r, cur[r]);
-            }
-            double t[N];
-#pragma unroll
-            for (int r = 0; r < N; ++r) {
-                double sacc = p[r * N] * (HAS_OBS ? o[0] : cur[0]);
-#pragma unroll
-                for (int j = 1; j < N; ++j)
-                    sacc = fma(p[r * N + j], HAS_OBS ? o[j] : cur[j], sacc);
-                t[r] = sacc;
-            }
-            if (flags & LOP_FIRST) {
-#pragma unroll
-                for (int r = 0; r < N; ++r) cur[r] = t[r];
-            } else if (flags & LOP_DST_CUR) {
-#pragma unroll
-                for (int r = 0; r < N; ++r) cur[r] *= t[r];
-            } else {                       // un-spill: the parent's step is next
-#pragma unroll
-                for (int r = 0; r < N; ++r) cur[r] = lds_get(op.z, r) * t[r];
-            }
+            if (flags & LOP_SPILL) spill();
+            if constexpr (HAS_OBS) matvec(p, o, t);
+            else matvec(p, cur, t);
+            deposit(flags, t, true);
             return;
         }
-        double x[N];
+        double x[B][N];
         if (flags & LOP_INTERNAL) {
-            if (flags & LOP_X_CUR) {
 #pragma unroll
-                for (int j = 0; j < N; ++j) x[j] = cur[j];
-            } else {
+            for (int b = 0; b < B; ++b) {
+                if (flags & LOP_X_CUR) {
 #pragma unroll
-                for (int j = 0; j < N; ++j) x[j] = lds_get(op.y, j);
-            }
-            if (HAS_OBS) {
+                    for (int j = 0; j < N; ++j) x[b][j] = cur[b][j];
+                } else {
 #pragma unroll
-                for (int j = 0; j < N; ++j) x[j] *= o[j];
+                    for (int j = 0; j < N; ++j) x[b][j] = lds_get(b, op.y, j);
+                }
+                if (HAS_OBS) {
+#pragma unroll
+                    for (int j = 0; j < N; ++j) x[b][j] *= o[b][j];
+                }
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < N; ++j) x[j] = HAS_OBS ? o[j] : 1.0;
+            for (int b = 0; b < B; ++b)
+#pragma unroll
+                for (int j = 0; j < N; ++j) x[b][j] = HAS_OBS ? o[b][j] : 1.0;
         }
         if (flags & LOP_ROOT) {
             // root reduction (_mc0_dense.py:184-209)
-            double sacc = 0.0;
 #pragma unroll
-            for (int j = 0; j < N; ++j) {
-                negative |= x[j] < 0.0;
-                sacc += w_c[j] * fmax(x[j], 0.0);
-            }
-            lik = sacc;
-        } else {
-            double t[N];
+            for (int b = 0; b < B; ++b) {
+                double sacc = 0.0;
 #pragma unroll
-            for (int r = 0; r < N; ++r) {
-                double sacc = p[r * N] * x[0];
-#pragma unroll
-                for (int j = 1; j < N; ++j) sacc = fma(p[r * N + j], x[j], sacc);
-                t[r] = sacc;
-            }
-            if (flags & LOP_FIRST) {
-                if (flags & LOP_SPILL) {
-#pragma unroll
-                    for (int r = 0; r < N; ++r) lds_put(op.w, r, cur[r]);
+                for (int j = 0; j < N; ++j) {
+                    negative[b] |= x[b][j] < 0.0;
+                    sacc += w_c[j] * fmax(x[b][j], 0.0);
                 }
-#pragma unroll
-                for (int r = 0; r < N; ++r) cur[r] = t[r];
-            } else if (flags & LOP_DST_CUR) {
-#pragma unroll
-                for (int r = 0; r < N; ++r) cur[r] *= t[r];
-            } else {
-#pragma unroll
-                for (int r = 0; r < N; ++r) lds_put(op.z, r, lds_get(op.z, r) * t[r]);
+                lik[b] = sacc;
             }
+        } else {
+            matvec(p, x, t);
+            if ((flags & LOP_FIRST) && (flags & LOP_SPILL)) spill();
+            deposit(flags, t, false);
         }
     }
 
     // Fetch ahead (call after compute() and after anything that must not wait
     // for these requests, e.g. the ring refill).  p is a single buffer: the FMAs
-    // of compute() have read it, so the next step's matrix can be requested now;
-    // the schedule entry is fetched TWO steps ahead so that the branchy head of
-    // the next step never waits for the scalar cache.
+    // of compute() have read it, so the next step's matrix can be requested now.
     __device__ __forceinline__ void advance(int records = 1)
     {
         i += 1;
@@ -273,8 +310,8 @@ struct LaneCtx {
     }
 
     // Fused cherry (LOP_CHERRY, PLDS only): p already holds P_a.
-    __device__ __forceinline__ void compute_cherry(const double (&oa)[N],
-                                                   const double (&ob)[N])
+    __device__ __forceinline__ void compute_cherry(const double (&oa)[B][N],
+                                                   const double (&ob)[B][N])
     {
         const int flags = op.x;
         double pb[N * N], pp[N * N];
@@ -283,47 +320,20 @@ struct LaneCtx {
         for (int j = 0; j < N * N; ++j) pb[j] = rec[j];
 #pragma unroll
         for (int j = 0; j < N * N; ++j) pp[j] = rec[N * N + j];
-        if (flags & LOP_SPILL) {
+        if (flags & LOP_SPILL) spill();
+        double ya[B][N], yb[B][N], t[B][N];
+        matvec(p, oa, ya);
+        matvec(pb, ob, yb);
 #pragma unroll
-            for (int r = 0; r < N; ++r) lds_put(op.w, r, cur[r]);
-        }
-        double y[N];
+        for (int b = 0; b < B; ++b)
 #pragma unroll
-        for (int r = 0; r < N; ++r) {
-            double sa = p[r * N] * oa[0];
-            double sb = pb[r * N] * ob[0];
-#pragma unroll
-            for (int j = 1; j < N; ++j) {
-                sa = fma(p[r * N + j], oa[j], sa);
-                sb = fma(pb[r * N + j], ob[j], sb);
-            }
-            y[r] = sa * sb;
-        }
-        double t[N];
-#pragma unroll
-        for (int r = 0; r < N; ++r) {
-            double sacc = pp[r * N] * y[0];
-#pragma unroll
-            for (int j = 1; j < N; ++j) sacc = fma(pp[r * N + j], y[j], sacc);
-            t[r] = sacc;
-        }
-        if (flags & LOP_FIRST) {
-#pragma unroll
-            for (int r = 0; r < N; ++r) cur[r] = t[r];
-        } else if (flags & LOP_DST_CUR) {
-#pragma unroll
-            for (int r = 0; r < N; ++r) cur[r] *= t[r];
-        } else if (flags & LOP_FAST) {          // un-spill
-#pragma unroll
-            for (int r = 0; r < N; ++r) cur[r] = lds_get(op.z, r) * t[r];
-        } else {
-#pragma unroll
-            for (int r = 0; r < N; ++r) lds_put(op.z, r, lds_get(op.z, r) * t[r]);
-        }
+            for (int r = 0; r < N; ++r) ya[b][r] *= yb[b][r];
+        matvec(pp, ya, t);
+        deposit(flags, t, (flags & LOP_FAST) != 0);
     }
 
     template <bool HAS_OBS>
-    __device__ __forceinline__ void step(const double (&o)[N])
+    __device__ __forceinline__ void step(const double (&o)[B][N])
     {
         compute<HAS_OBS>(o);
         advance();
@@ -332,7 +342,7 @@ struct LaneCtx {
     // run the steps that carry no observation
     __device__ __forceinline__ void run_plain()
     {
-        const double none[N] = {};
+        const double none[B][N] = {};
         while (!(op.x & (LOP_OBS | LOP_STOP))) step<false>(none);
     }
 };
@@ -379,15 +389,10 @@ prune_lane_kernel(const double *__restrict__ Pord,   // [nops][N][N]
     C.ops_c = (const RT_CONST_AS int4_t *)ops;
     C.P_c = (const RT_CONST_AS double *)Pord;
     C.w_c = (const RT_CONST_AS double *)root_w;
-    C.stack = stack_base + (size_t)wave * depth * N * 512 + lane * 8;
+    C.stack[0] = stack_base + (size_t)wave * depth * N * 512 + lane * 8;
     C.nops = nops;
     C.nrec = nops;
-    C.pidx = 0;
-    C.i = 0;
-    C.lik = 0.0;
-    C.negative = false;
-#pragma unroll
-    for (int j = 0; j < N; ++j) C.cur[j] = 1.0;
+    C.init();
 
     // prologue: R slots in flight
     double2 ring[R][HP];
@@ -408,10 +413,10 @@ prune_lane_kernel(const double *__restrict__ Pord,   // [nops][N][N]
         for (int j = 0; j < R; ++j) {
             const int k = k0 + j;
             if (k < K) {              // wave-uniform; the current step consumes slot k
-                double o[N];
+                double o[1][N];
 #pragma unroll
                 for (int q = 0; q < N; ++q)
-                    o[q] = (q & 1) ? ring[j][q >> 1].y : ring[j][q >> 1].x;
+                    o[0][q] = (q & 1) ? ring[j][q >> 1].y : ring[j][q >> 1].x;
                 C.template step<true>(o);
                 if (k + R < K && !noload) {
 #pragma unroll
@@ -425,7 +430,7 @@ prune_lane_kernel(const double *__restrict__ Pord,   // [nops][N][N]
 
     const long site = gw * 64 + lane;
     double sum, nzero;
-    finish_site(C.lik, C.negative, site < nsites, loglik, status, site, sum, nzero);
+    finish_site(C.lik[0], C.negative[0], site < nsites, loglik, status, site, sum, nzero);
     sum = wave_sum(sum);
     nzero = wave_sum(nzero);
     if (lane == 0) {
@@ -437,64 +442,66 @@ prune_lane_kernel(const double *__restrict__ Pord,   // [nops][N][N]
 // ---------------------------------------------------------------------------
 // n <= 4, variant B: the same walk (LaneCtx) with the leaf vectors landing in an
 // LDS ring by LDS-DMA (global_load_lds, 1 KiB per wave-instruction, data layout
-// [block][slot][lane][np]).  Data in flight lives in LDS, not in VGPRs, so the
+// [block][slot][pair][lane][2], the same as the VGPR-ring variant).  Data in flight lives in LDS, not in VGPRs, so the
 // kernel owns its vmcnt waits: exactly the slots younger than the one being
 // consumed stay outstanding ((R-1)*IPS instructions), nothing is ever drained.
 // ---------------------------------------------------------------------------
 
-template <int N, int R>
-__global__ void __launch_bounds__(256)
+// B site blocks per wave (see LaneCtx), WPB waves per workgroup.
+template <int N, int R, int B, int WPB>
+__global__ void __launch_bounds__(64 * WPB)
 prune_lanedma_kernel(const double *__restrict__ Pord,   // [nrec][N][N]
                      const int4_t *__restrict__ ops, int nops, int nrec,   // program
-                     const double *__restrict__ obs, int K,  // [blk][K][64][NP]
+                     const double *__restrict__ obs, int K,  // [blk][K][NP/2][64][2]
                      const double *__restrict__ root_w, int depth,
                      double *__restrict__ loglik, int *__restrict__ status,
-                     double *__restrict__ partial, long nsites, long nblocks)
+                     double *__restrict__ partial, long nsites, long nwaves)
 {
     constexpr int NP = (N + 1) & ~1;
-    constexpr int SLOT = 64 * NP * 8;         // bytes of one obs slot of one wave
+    constexpr int SLOT = 64 * NP * 8;         // bytes of one obs slot of one block
     constexpr int IPS = SLOT / 1024;          // LDS-DMA instructions per slot
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long gw = (long)blockIdx.x * 4 + wave;      // site block of this wave
+    const long gw = (long)blockIdx.x * WPB + wave;    // wave = B consecutive site blocks
 
-    LaneCtx<N, true> C;
+    LaneCtx<N, true, B> C;
     double *pl = (double *)smem;
-    for (int e = threadIdx.x; e < (nrec + 1) * N * N; e += 256) pl[e] = Pord[e];
-    unsigned char *wbase = smem + (((size_t)(nrec + 1) * N * N * 8 + 15) & ~(size_t)15) +
-                           (size_t)wave * (R * SLOT + depth * N * 512);
+    for (int e = threadIdx.x; e < (nrec + 1) * N * N; e += 64 * WPB) pl[e] = Pord[e];
+    const int stack_bytes = depth * N * 512;
+    // per wave: [B][R] observation slots, then [B] accumulator stacks
+    unsigned char *ring = smem + (((size_t)(nrec + 1) * N * N * 8 + 15) & ~(size_t)15) +
+                          (size_t)wave * B * (R * SLOT + stack_bytes);
     __syncthreads();
-    if (gw >= nblocks) return;                // wave-uniform, after the only barrier
-    unsigned char *ring = wbase;
+    if (gw >= nwaves) return;                 // wave-uniform, after the only barrier
     C.P_l = pl;
     C.ops_c = (const RT_CONST_AS int4_t *)ops;
     C.P_c = (const RT_CONST_AS double *)Pord;
     C.w_c = (const RT_CONST_AS double *)root_w;
-    C.stack = wbase + R * SLOT + lane * 8;
+#pragma unroll
+    for (int b = 0; b < B; ++b) C.stack[b] = ring + B * R * SLOT + b * stack_bytes + lane * 8;
     C.nops = nops;
     C.nrec = nrec;
-    C.pidx = 0;
-    C.i = 0;
-    C.lik = 0.0;
-    C.negative = false;
-#pragma unroll
-    for (int j = 0; j < N; ++j) C.cur[j] = 1.0;
+    C.init();
 
+    const size_t bstride = (size_t)K * SLOT;  // bytes between consecutive blocks
     const unsigned char *g =
-        (const unsigned char *)obs + (size_t)gw * K * SLOT + lane * 16;
-    // prologue: fill the ring
+        (const unsigned char *)obs + (size_t)gw * B * bstride + lane * 16;
+    // stream position kk of every block -> ring slot r
+    auto fetch = [&](int kk, int r) {
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-        if (k < K) {
+        for (int b = 0; b < B; ++b)
 #pragma unroll
             for (int j = 0; j < IPS; ++j)
                 __builtin_amdgcn_global_load_lds(
-                    (glb_void *)(g + (size_t)k * SLOT + j * 1024),
-                    (lds_void *)(ring + k * SLOT + j * 1024), 16, 0, 0);
-        }
-    }
+                    (glb_void *)(g + b * bstride + (size_t)kk * SLOT + j * 1024),
+                    (lds_void *)(ring + (b * R + r) * SLOT + j * 1024), 16, 0, 0);
+    };
+    // prologue: fill the ring
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+        if (k < K) fetch(k, k);
 
     C.load_current();
     C.run_plain();
@@ -504,53 +511,45 @@ prune_lanedma_kernel(const double *__restrict__ Pord,   // [nrec][N][N]
         if ((C.op.x & LOP_CHERRY) && R >= 2) {
             // two leaves + parent: stream positions k, k+1
             if (k + 1 + R <= K)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R >= 2 ? R - 2 : 0) * IPS) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R >= 2 ? R - 2 : 0) * IPS * B) : "memory");
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int rs1 = (rs + 1 == R) ? 0 : rs + 1;
-            const double *oa_l = (const double *)(ring + rs * SLOT) + lane * NP;
-            const double *ob_l = (const double *)(ring + rs1 * SLOT) + lane * NP;
-            double oa[N], ob[N];
+            double oa[B][N], ob[B][N];
 #pragma unroll
-            for (int j = 0; j < N; ++j) { oa[j] = oa_l[j]; ob[j] = ob_l[j]; }
+            for (int b = 0; b < B; ++b) {
+                // slot image [pair][lane][2]: conflict-free ds_read_b128
+                const double *oa_l = (const double *)(ring + (b * R + rs) * SLOT) + lane * 2;
+                const double *ob_l = (const double *)(ring + (b * R + rs1) * SLOT) + lane * 2;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    oa[b][j] = oa_l[(j >> 1) * 128 + (j & 1)];
+                    ob[b][j] = ob_l[(j >> 1) * 128 + (j & 1)];
+                }
+            }
             C.compute_cherry(oa, ob);
-            if (k + R < K) {
-#pragma unroll
-                for (int j = 0; j < IPS; ++j)
-                    __builtin_amdgcn_global_load_lds(
-                        (glb_void *)(g + (size_t)(k + R) * SLOT + j * 1024),
-                        (lds_void *)(ring + rs * SLOT + j * 1024), 16, 0, 0);
-            }
-            if (k + 1 + R < K) {
-#pragma unroll
-                for (int j = 0; j < IPS; ++j)
-                    __builtin_amdgcn_global_load_lds(
-                        (glb_void *)(g + (size_t)(k + 1 + R) * SLOT + j * 1024),
-                        (lds_void *)(ring + rs1 * SLOT + j * 1024), 16, 0, 0);
-            }
+            if (k + R < K) fetch(k + R, rs);
+            if (k + 1 + R < K) fetch(k + 1 + R, rs1);
             C.advance(3);
             rs = (rs1 + 1 == R) ? 0 : rs1 + 1;
             k += 2;
         } else {
             if (k + R <= K)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 1) * IPS) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 1) * IPS * B) : "memory");
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const double *o_l = (const double *)(ring + rs * SLOT) + lane * NP;
-            double o[N];
+            double o[B][N];
 #pragma unroll
-            for (int j = 0; j < N; ++j) o[j] = o_l[j];
+            for (int b = 0; b < B; ++b) {
+                const double *o_l = (const double *)(ring + (b * R + rs) * SLOT) + lane * 2;
+#pragma unroll
+                for (int j = 0; j < N; ++j) o[b][j] = o_l[(j >> 1) * 128 + (j & 1)];
+            }
             C.template compute<true>(o);
             // refill BEFORE the fetch-ahead: the LDS-DMA must wait for the reads
             // of the slot it overwrites (lgkmcnt(0)), which are long done here,
             // and must not wait for the P / schedule requests advance() issues
-            if (k + R < K) {
-#pragma unroll
-                for (int j = 0; j < IPS; ++j)
-                    __builtin_amdgcn_global_load_lds(
-                        (glb_void *)(g + (size_t)(k + R) * SLOT + j * 1024),
-                        (lds_void *)(ring + rs * SLOT + j * 1024), 16, 0, 0);
-            }
+            if (k + R < K) fetch(k + R, rs);
             C.advance();
             rs = (rs + 1 == R) ? 0 : rs + 1;
             k += 1;
@@ -558,14 +557,18 @@ prune_lanedma_kernel(const double *__restrict__ Pord,   // [nrec][N][N]
         C.run_plain();
     }
 
-    const long site = gw * 64 + lane;
-    double sum, nzero;
-    finish_site(C.lik, C.negative, site < nsites, loglik, status, site, sum, nzero);
-    sum = wave_sum(sum);
-    nzero = wave_sum(nzero);
-    if (lane == 0) {
-        partial[gw * 2] = sum;
-        partial[gw * 2 + 1] = nzero;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        const long blk = gw * B + b;
+        const long site = blk * 64 + lane;
+        double sum, nzero;
+        finish_site(C.lik[b], C.negative[b], site < nsites, loglik, status, site, sum, nzero);
+        sum = wave_sum(sum);
+        nzero = wave_sum(nzero);
+        if (lane == 0) {
+            partial[blk * 2] = sum;
+            partial[blk * 2 + 1] = nzero;
+        }
     }
 }
 
@@ -1210,7 +1213,7 @@ int rt_sites_pack(rt_sites *s, int kind, const int64_t *src_of_k, const void *da
         if (blocks > 65536) blocks = 65536;
         if (s->layout == RT_LAYOUT_LANE) {
             const int np = (n + 1) & ~1;
-            const int paired = s->d_scratch == nullptr && !s->lane_dma;
+            const int paired = s->d_scratch == nullptr;
             hipLaunchKernelGGL(pack_sites_lane_kernel, dim3((unsigned)blocks), dim3(256),
                                0, st, kind, d_in, d_src, (long)s->nsites, (long)K, K, n,
                                np, paired, s->d_obs, total);
@@ -1261,54 +1264,71 @@ static int launch_lane_reg(rt_model *m, rt_sites *s, bool *plds_out)
     return RT_OK;
 }
 
-template <int N, int R>
+static int lane_dma_lds(int n, int R, int B, int wpb, int nrec, int slots)
+{
+    const int np = (n + 1) & ~1;
+    const int ptab = ((nrec + 1) * n * n * 8 + 15) & ~15;
+    return ptab + wpb * B * (R * 64 * np * 8 + slots * n * 512);
+}
+
+template <int N, int R, int B, int WPB>
 static int launch_lane_dma(rt_model *m, rt_sites *s)
 {
-    constexpr int NP = (N + 1) & ~1;
     const int depth = s->lane_stack_slots;
     const int nrec = (int)s->ops.size();          // P records = schedule steps
     const int nops = (int)s->lane_nprog;          // program entries (cherries fused)
-    const int ptab = ((nrec + 1) * N * N * 8 + 15) & ~15;
-    const int lds = ptab + 4 * (R * 64 * NP * 8 + depth * N * 512);
+    const int lds = lane_dma_lds(N, R, B, WPB, nrec, depth);
     if (lds > 160 * 1024) {
         rt_set_error("LDS-DMA lane kernel: %d bytes of LDS needed (tree too large); "
                      "unset RAOTEH_LANE_VARIANT", lds);
         return RT_ERR_UNSUPPORTED;
     }
-    auto kern = prune_lanedma_kernel<N, R>;
+    // rt_sites pads the lane layout to an even number of blocks
+    const long nwaves = (s->nblocks + B - 1) / B;
+    auto kern = prune_lanedma_kernel<N, R, B, WPB>;
     RT_HIP(hipFuncSetAttribute((const void *)kern,
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)((s->nblocks + 3) / 4)), dim3(256), lds,
+    hipLaunchKernelGGL(kern, dim3((unsigned)((nwaves + WPB - 1) / WPB)), dim3(64 * WPB), lds,
                        m->ctx->stream, m->d_Pfrag, (const int4_t *)s->d_lane_ops, nops, nrec,
                        s->d_obs, (int)s->nobs, m->d_root, depth, s->d_loglik, s->d_status,
-                       s->d_partial, (long)s->nsites, (long)s->nblocks);
+                       s->d_partial, (long)s->nsites, nwaves);
     return RT_OK;
 }
 
 template <int N>
 static int launch_lane(rt_model *m, rt_sites *s, const char **name)
 {
-    static char buf[5][48];
+    static char buf[5][64];
     int R = s->lane_ring;
+    int B = 1, W = 4;
     int rc;
     bool plds = false;
-    if (s->lane_dma && R == 0) {
-        // 3 slots when two workgroups then still fit on a CU, else 2 (measured on
-        // C2: 4 slots are slower than 3 even where they fit)
-        constexpr int NPv = (N + 1) & ~1;
-        const int ptab = (((int)s->ops.size() + 1) * N * N * 8 + 15) & ~15;
-        for (R = 3; R > 2; --R)
-            if (ptab + 4 * (R * 64 * NPv * 8 + s->lane_stack_slots * N * 512) <= 80 * 1024)
-                break;
+    if (s->lane_dma) {
+        const int nrec = (int)s->ops.size();
+        const int slots = s->lane_stack_slots;
+        // ring: 3 slots (measured on C2: 4 are slower than 3 even where they fit)
+        if (R == 0) R = 3;
+        // two site blocks per wave (RAOTEH_LANE_BLOCKS=2) halve the scalar / P-read
+        // work per site, but one wave with two blocks hides latency worse than two
+        // waves with one: measured 60 us against 48 us on C2, so one is the default
+        B = 1;
+        if (const char *v = getenv("RAOTEH_LANE_BLOCKS")) B = atoi(v) == 2 ? 2 : 1;
+        if (B == 2 && lane_dma_lds(N, R, 2, 4, nrec, slots) > 160 * 1024) W = 2;
+        if (B == 2 && lane_dma_lds(N, R, 2, W, nrec, slots) > 160 * 1024) B = 1, W = 4;
+        if (const char *v = getenv("RAOTEH_LANE_WPB")) W = atoi(v) == 2 ? 2 : 4;
+        if (B == 1) W = 4;
     }
     if (s->lane_dma) {
+#define RT_DMA_CASE(r) \
+        rc = B == 2 ? (W == 2 ? launch_lane_dma<N, r, 2, 2>(m, s)               \
+                              : launch_lane_dma<N, r, 2, 4>(m, s))              \
+                    : launch_lane_dma<N, r, 1, 4>(m, s)
         switch (R) {
-        case 2: rc = launch_lane_dma<N, 2>(m, s); break;
-        case 4: rc = launch_lane_dma<N, 4>(m, s); break;
-        case 5: rc = launch_lane_dma<N, 5>(m, s); break;
-        case 6: rc = launch_lane_dma<N, 6>(m, s); break;
-        default: rc = launch_lane_dma<N, 3>(m, s); break;
+        case 2: RT_DMA_CASE(2); break;
+        case 4: RT_DMA_CASE(4); break;
+        default: R = 3; RT_DMA_CASE(3); break;
         }
+#undef RT_DMA_CASE
     } else {
         switch (R) {
         case 4: rc = launch_lane_reg<N, 4>(m, s, &plds); break;
@@ -1317,8 +1337,11 @@ static int launch_lane(rt_model *m, rt_sites *s, const char **name)
         default: rc = launch_lane_reg<N, 8>(m, s, &plds); break;
         }
     }
-    snprintf(buf[N], sizeof(buf[N]), "prune_lane<%d,%s,R%d>", N,
-             s->lane_dma ? "dma" : (plds ? "reg+ldsP" : "reg"), R);
+    if (s->lane_dma)
+        snprintf(buf[N], sizeof(buf[N]), "prune_lane<%d,dma,R%d,B%d,W%d>", N, R, B, W);
+    else
+        snprintf(buf[N], sizeof(buf[N]), "prune_lane<%d,%s,R%d>", N,
+                 plds ? "reg+ldsP" : "reg", R);
     *name = buf[N];
     return rc;
 }
@@ -1415,8 +1438,14 @@ int rt_launch_prune(rt_model *m, rt_sites *s)
     if (!generic) RT_TRY(rt_launch_pfrag(m));
     rt_time_begin(ctx, RT_K_PRUNE, "", &ev);
     int rc;
+    static char jit_name[48];
     if (generic) rc = launch_generic(m, s, &name);
-    else if (s->layout == RT_LAYOUT_LANE) {
+    else if (s->jit_fn) {
+        rc = rt_launch_prune_jit(m, s);
+        snprintf(jit_name, sizeof(jit_name), "prune_tree_jit<%d,D%d>", (int)m->n,
+                 s->jit_prefetch);
+        name = jit_name;
+    } else if (s->layout == RT_LAYOUT_LANE) {
         switch ((int)m->n) {
         case 1: rc = launch_lane<1>(m, s, &name); break;
         case 2: rc = launch_lane<2>(m, s, &name); break;
