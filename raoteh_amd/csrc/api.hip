@@ -703,17 +703,26 @@ static int sites_jit(rt_sites *s, bool generic)
 {
     int want = g_jit;
     if (const char *v = getenv("RAOTEH_JIT")) want = atoi(v);
+    const bool forced = want > 0;
     if (want < 0) want = s->nsites >= RT_JIT_MIN_SITES;
     if (!want || generic || s->layout != RT_LAYOUT_LANE) return RT_OK;
     // straight-line code: keep it inside the instruction cache's reach
     if (s->ops.size() > 1024) return RT_OK;
+    // measured on C2: 6 stream positions and 2 P records ahead (tools/ab_jit.sh)
     int D = 6;
     if (const char *v = getenv("RAOTEH_JIT_PREFETCH")) D = std::max(1, atoi(v));
     int LA = 2;
     if (const char *v = getenv("RAOTEH_JIT_LOOKAHEAD")) LA = std::max(1, atoi(v));
     const std::string src = rt_jit_lane_source(s->ops, (int)s->model->n, (int)s->nobs, D, LA);
     s->jit_prefetch = D;
-    return rt_jit_get(s->model->ctx, src, &s->jit_fn);
+    const int rc = rt_jit_get(s->model->ctx, src, &s->jit_fn);
+    if (rc != RT_OK && !forced) {
+        // automatic mode: the interpreter kernel (prune.hip) computes the same
+        // numbers; rt_last_error() keeps the compiler's message
+        s->jit_fn = nullptr;
+        return RT_OK;
+    }
+    return rc;
 }
 
 extern "C" int rt_jit_source(int64_t nnodes, const int64_t *idx, const int64_t *ptr,

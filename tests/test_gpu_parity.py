@@ -463,6 +463,42 @@ def test_generic_kernel_agrees(ra, n):
     np.testing.assert_allclose(fast, want, rtol=RTOL_LL)
 
 
+@pytest.mark.parametrize('n', [1, 2, 3, 4])
+def test_tree_specialised_kernel_is_bit_identical(ra, n):
+    """jit.hip: the hiprtc-compiled straight-line kernel for one tree performs
+    the interpreter kernel's arithmetic in the interpreter's order."""
+    rng = np.random.RandomState(900 + n)
+    set_option = ra.lib.lib().rt_set_option
+    for nnodes, nsites in ((2, 70), (9, 129), (34, 4000)):
+        T, root, obs_nodes, w = _random_case(ra, rng, n, nnodes, nsites,
+                                             sparse=(nnodes == 9))
+        pre, idx, ptr, esd = orc.get_esd_transitions(T, root, n)
+        oidx = [pre.index(v) for v in obs_nodes]
+        dense = rng.uniform(0.05, 1.0, size=(nsites, len(obs_nodes), n))
+        dense[rng.uniform(size=dense.shape) < 0.1] = 0.0
+        want, wst = orc.batch_log_likelihoods(idx, ptr, esd, oidx, dense, w)
+        model = ra.device.TreeModel(T, root, n)
+        model.set_transitions(esd)
+        model.set_root_distn(w)
+        out = {}
+        for jit in (0, 1):
+            ra.lib.check(set_option(b'jit', jit))
+            try:
+                batch = model.upload_sites(obs_nodes, dense, kind='dense')
+                ll, st = model.log_likelihoods(batch)
+                name = ra.ctx.kernel_time(1)[2]
+                out[jit] = (ll, st, model.fetch_totals(batch), name)
+            finally:
+                ra.lib.check(set_option(b'jit', -1))
+        assert out[0][3].startswith('prune_lane'), out[0][3]
+        assert out[1][3].startswith('prune_tree_jit'), out[1][3]
+        np.testing.assert_array_equal(out[0][0], out[1][0])
+        np.testing.assert_array_equal(out[0][1], out[1][1])
+        np.testing.assert_array_equal(out[0][2], out[1][2])
+        np.testing.assert_array_equal(out[1][1] & 1, wst)
+        np.testing.assert_allclose(out[1][0][wst == 0], want[wst == 0], rtol=RTOL_LL)
+
+
 def test_deep_caterpillar_and_wide_star(ra):
     rng = np.random.RandomState(11)
     n = 4

@@ -161,3 +161,35 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle', text, re.M), f
                 assert 'oracle_numpy' not in text, f
+
+
+def test_tree_specialised_source_is_generated_on_the_host():
+    """rt_jit_source (csrc/jit.hip) needs no device: one arithmetic block per
+    schedule step, one load pair per observed node, every P element referenced
+    at its step-ordered offset."""
+    import ctypes
+    import re
+    from raoteh_amd import _lib, synth
+    from raoteh_amd._tree import TreeArrays
+    T, root, leaves = synth.balanced_tree(8, seed=0)
+    ta = TreeArrays(T, root)
+    obs = np.array([ta.node_to_index[v] for v in leaves], dtype=np.int64)
+    p64 = ctypes.POINTER(ctypes.c_int64)
+    buf = ctypes.create_string_buffer(1 << 20)
+    for n in (2, 3, 4):
+        _lib.check(_lib.lib().rt_jit_source(
+            ta.nnodes, ta.indices.ctypes.data_as(p64), ta.indptr.ctypes.data_as(p64),
+            n, len(obs), obs.ctypes.data_as(p64), 3, buf, len(buf)))
+        src = buf.value.decode()
+        assert src.count('// step ') == ta.nnodes
+        assert 'extern "C" __global__' in src and 'rt_jit_prune' in src
+        hp = (n + 1) // 2
+        assert len(re.findall(r'const rt_d2 o\d+_\d+ = g\[', src)) == len(obs) * hp
+        # P records of the 14 non-root steps, n*n registers each
+        assert len(set(re.findall(r'\bp(\d+)_0\b', src))) == ta.nnodes - 1
+    # too small a buffer is an error, not a truncation
+    small = ctypes.create_string_buffer(64)
+    rc = _lib.lib().rt_jit_source(
+        ta.nnodes, ta.indices.ctypes.data_as(p64), ta.indptr.ctypes.data_as(p64),
+        4, len(obs), obs.ctypes.data_as(p64), 3, small, len(small))
+    assert rc < 0
