@@ -202,7 +202,8 @@ int rt_build_schedule(int64_t nnodes, const int64_t *tree_csr_indices,
  * never, 1 always): rt_sites_create compiles (hiprtc, once per distinct tree
  * and set of observed nodes) a pruning kernel specialised for the tree when
  * n <= 4; automatic = batches of at least 16 384 sites.  Results are
- * bit-identical with and without it.                                         */
+ * bit-identical with and without it.  "jit_block_sites" (0 automatic, 1..64):
+ * sites per wave of those kernels (automatic balances the waves over the CUs). */
 int rt_set_option(const char *key, int64_t value);
 /* Diagnostics, host only: the HIP source rt_sites_create would compile for this
  * tree (n <= 4), observation stream obs_nodes and prefetch distance.         */

@@ -522,12 +522,18 @@ static int g_force_generic = 0;
 // RT_JIT_MIN_SITES sites), 0 = never, 1 = always (lane family only)
 static int g_jit = -1;
 static const int64_t RT_JIT_MIN_SITES = 16384;
+static int g_jit_block_sites = 0;    // 0 = automatic (see sites_jit)
 
 extern "C" int rt_set_option(const char *key, int64_t value)
 {
     RT_REQUIRE(key, "null key");
     if (strcmp(key, "force_generic") == 0) { g_force_generic = value != 0; return RT_OK; }
     if (strcmp(key, "jit") == 0) { g_jit = value < 0 ? -1 : value != 0; return RT_OK; }
+    if (strcmp(key, "jit_block_sites") == 0) {
+        RT_REQUIRE(value >= 0 && value <= 64, "jit_block_sites must be 0 (automatic) .. 64");
+        g_jit_block_sites = (int)value;
+        return RT_OK;
+    }
     rt_set_error("unknown option %s", key);
     return RT_ERR_INVALID;
 }
@@ -641,11 +647,13 @@ static int sites_alloc(rt_sites *s, bool generic)
     const int64_t K = s->nobs;
     int64_t padded;
     if (s->layout == RT_LAYOUT_LANE) {
+        const int64_t S = s->block_sites;
+        s->nblocks = std::max<int64_t>(1, (s->nsites + S - 1) / S);
         // an even number of blocks: the LDS-DMA kernel may give a wave two
-        s->nblocks = (std::max<int64_t>(1, (s->nsites + 63) / 64) + 1) & ~1ll;
+        if (S == 64) s->nblocks = (s->nblocks + 1) & ~1ll;
         const int64_t np = (n + 1) & ~1ll;
-        s->obs_bytes = s->nblocks * K * 64 * np * 8;
-        padded = s->nblocks * 64;
+        s->obs_bytes = s->nblocks * K * S * np * 8;
+        padded = s->nblocks * S;
         s->npartials = s->nblocks;
     } else {
         s->nblocks = std::max<int64_t>(1, (s->nsites + 15) / 16);
@@ -713,7 +721,22 @@ static int sites_jit(rt_sites *s, bool generic)
     if (const char *v = getenv("RAOTEH_JIT_PREFETCH")) D = std::max(1, atoi(v));
     int LA = 2;
     if (const char *v = getenv("RAOTEH_JIT_LOOKAHEAD")) LA = std::max(1, atoi(v));
-    const std::string src = rt_jit_lane_source(s->ops, (int)s->model->n, (int)s->nobs, D, LA);
+    // Sites per wave.  One wave per workgroup, at most 8 waves per CU (VGPRs): a
+    // batch that fits the chip in one round (<= 2 048 blocks of 64) is cut into a
+    // multiple of 256 waves instead, each with S <= 64 active lanes, so that every
+    // CU streams the same number of bytes (C2: 1 563 blocks of 64 would be 6 or 7
+    // waves per CU, 1 792 blocks of 56 are 7 everywhere).
+    int S = 64;
+    const int64_t nb64 = (s->nsites + 63) / 64;
+    if (nb64 >= 256 && nb64 <= 2048) {
+        const int64_t nw = (nb64 + 255) / 256 * 256;
+        S = (int)((s->nsites + nw - 1) / nw);
+    }
+    if (g_jit_block_sites > 0) S = g_jit_block_sites;
+    if (const char *v = getenv("RAOTEH_JIT_BLOCK_SITES")) S = atoi(v);
+    S = std::min(64, std::max(1, S));
+    const std::string src =
+        rt_jit_lane_source(s->ops, (int)s->model->n, (int)s->nobs, D, LA, S);
     s->jit_prefetch = D;
     const int rc = rt_jit_get(s->model->ctx, src, &s->jit_fn);
     if (rc != RT_OK && !forced) {
@@ -722,6 +745,7 @@ static int sites_jit(rt_sites *s, bool generic)
         s->jit_fn = nullptr;
         return RT_OK;
     }
+    if (rc == RT_OK) s->block_sites = S;
     return rc;
 }
 
@@ -746,7 +770,7 @@ extern "C" int rt_jit_source(int64_t nnodes, const int64_t *idx, const int64_t *
     for (auto &op : m.ops)
         if (node_obs[(size_t)op.node] >= 0) op.obs = k++;
     const int LA = getenv("RAOTEH_JIT_LOOKAHEAD") ? std::max(1, atoi(getenv("RAOTEH_JIT_LOOKAHEAD"))) : 2;
-    const std::string src = rt_jit_lane_source(m.ops, (int)n, (int)nobs, (int)prefetch, LA);
+    const std::string src = rt_jit_lane_source(m.ops, (int)n, (int)nobs, (int)prefetch, LA, 64);
     RT_REQUIRE((int64_t)src.size() + 1 <= capacity, "buffer too small: %lld bytes needed",
                (long long)src.size() + 1);
     memcpy(buf, src.c_str(), src.size() + 1);
@@ -808,9 +832,9 @@ extern "C" int rt_sites_create(rt_model *m, int64_t nsites, int kind, int64_t no
     if (const char *v = getenv("RAOTEH_LANE_VARIANT")) s->lane_dma = strcmp(v, "dma") == 0;
     if (const char *r = getenv("RAOTEH_LANE_RING")) s->lane_ring = atoi(r);
     else s->lane_ring = s->lane_dma ? 0 : 8;      // 0: rt_launch_prune picks what fits
-    int rc = sites_alloc(s, generic);
+    int rc = sites_jit(s, generic);          // before the layout is fixed: block_sites
+    if (rc == RT_OK) rc = sites_alloc(s, generic);
     if (rc == RT_OK) rc = rt_sites_pack(s, kind, src_of_k.data(), data);
-    if (rc == RT_OK) rc = sites_jit(s, generic);
     if (rc != RT_OK) {
         rt_sites_destroy(s);
         return rc;
@@ -835,6 +859,7 @@ extern "C" int rt_sites_clone(rt_sites *src, rt_sites **out)
     s->lane_ring = src->lane_ring;
     s->jit_fn = src->jit_fn;
     s->jit_prefetch = src->jit_prefetch;
+    s->block_sites = src->block_sites;
     s->node_obs = src->node_obs;
     s->ops = src->ops;
     int rc = sites_alloc(s, src->d_scratch != nullptr);

@@ -1102,11 +1102,12 @@ __device__ __forceinline__ double obs_value(int kind, const void *data, long sit
     return ((m >> s) & 1ull) ? 1.0 : 0.0;
 }
 
-// lane family: [blk64][k][pair][lane][2]; the generic fallback keeps the simpler
-// [blk64][k][lane][np]
+// lane family: [blk][k][pair][lane][2] with S sites per block (64 unless the batch
+// runs a tree-specialised kernel, jit.hip); the generic fallback keeps the
+// simpler [blk64][k][lane][np]
 __global__ void pack_sites_lane_kernel(int kind, const void *__restrict__ data,
                                        const int *__restrict__ src_of_k, long nsites,
-                                       long nobs, int K, int n, int np, int paired,
+                                       long nobs, int K, int n, int np, int paired, int S,
                                        double *__restrict__ out, size_t total)
 {
     const int hp = np / 2;
@@ -1116,19 +1117,19 @@ __global__ void pack_sites_lane_kernel(int kind, const void *__restrict__ data,
         size_t r2;
         if (paired) {
             const int e2 = e & 1;
-            lane = (e >> 1) & 63;
-            const size_t r = e >> 7;
+            lane = (int)((e >> 1) % S);
+            const size_t r = (e >> 1) / S;
             s = 2 * (int)(r % hp) + e2;
             r2 = r / hp;
         } else {
             s = e % np;
             const size_t r = e / np;
-            lane = r & 63;
-            r2 = r >> 6;
+            lane = (int)(r % S);
+            r2 = r / S;
         }
         const int k = r2 % K;
         const long blk = r2 / K;
-        const long site = blk * 64 + lane;
+        const long site = blk * S + lane;
         double v;
         if (s >= n) v = 0.0;
         else if (site >= nsites) v = 1.0;
@@ -1216,7 +1217,7 @@ int rt_sites_pack(rt_sites *s, int kind, const int64_t *src_of_k, const void *da
             const int paired = s->d_scratch == nullptr;
             hipLaunchKernelGGL(pack_sites_lane_kernel, dim3((unsigned)blocks), dim3(256),
                                0, st, kind, d_in, d_src, (long)s->nsites, (long)K, K, n,
-                               np, paired, s->d_obs, total);
+                               np, paired, s->block_sites, s->d_obs, total);
         } else {
             const int KP = (ks_of(n) + 1) / 2;
             hipLaunchKernelGGL(pack_sites_mfma_kernel, dim3((unsigned)blocks), dim3(256),

@@ -481,20 +481,31 @@ def test_tree_specialised_kernel_is_bit_identical(ra, n):
         model.set_transitions(esd)
         model.set_root_distn(w)
         out = {}
-        for jit in (0, 1):
+        # (jit, sites per wave): 64 = the interpreter's blocks; fewer sites per
+        # wave change the HBM layout and the partial sums, not a site's value
+        for jit, bs in ((0, 0), (1, 64), (1, 49), (1, 7)):
             ra.lib.check(set_option(b'jit', jit))
+            ra.lib.check(set_option(b'jit_block_sites', bs))
             try:
                 batch = model.upload_sites(obs_nodes, dense, kind='dense')
                 ll, st = model.log_likelihoods(batch)
                 name = ra.ctx.kernel_time(1)[2]
-                out[jit] = (ll, st, model.fetch_totals(batch), name)
+                out[jit, bs] = (ll, st, model.fetch_totals(batch), name)
+                twin = batch.clone()
+                ll2, st2 = model.log_likelihoods(twin)
+                np.testing.assert_array_equal(ll, ll2)
             finally:
                 ra.lib.check(set_option(b'jit', -1))
-        assert out[0][3].startswith('prune_lane'), out[0][3]
-        assert out[1][3].startswith('prune_tree_jit'), out[1][3]
-        np.testing.assert_array_equal(out[0][0], out[1][0])
-        np.testing.assert_array_equal(out[0][1], out[1][1])
-        np.testing.assert_array_equal(out[0][2], out[1][2])
+                ra.lib.check(set_option(b'jit_block_sites', 0))
+        assert out[0, 0][3].startswith('prune_lane'), out[0, 0][3]
+        for key in ((1, 64), (1, 49), (1, 7)):
+            assert out[key][3].startswith('prune_tree_jit'), out[key][3]
+            np.testing.assert_array_equal(out[0, 0][0], out[key][0])
+            np.testing.assert_array_equal(out[0, 0][1], out[key][1])
+            assert out[key][2][1] == out[0, 0][2][1] and out[key][2][2] == nsites
+            assert out[key][2][0] == pytest.approx(out[0, 0][2][0], rel=1e-13)
+        np.testing.assert_array_equal(out[0, 0][2], out[1, 64][2])
+        out[1] = out[1, 64]
         np.testing.assert_array_equal(out[1][1] & 1, wst)
         np.testing.assert_allclose(out[1][0][wst == 0], want[wst == 0], rtol=RTOL_LL)
 
