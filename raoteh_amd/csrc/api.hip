@@ -721,12 +721,13 @@ static int sites_jit(rt_sites *s, bool generic)
     if (const char *v = getenv("RAOTEH_JIT_PREFETCH")) D = std::max(1, atoi(v));
     int LA = 2;
     if (const char *v = getenv("RAOTEH_JIT_LOOKAHEAD")) LA = std::max(1, atoi(v));
-    // Sites per wave.  One wave per workgroup, at most 8 waves per CU (VGPRs): a
-    // batch that fits the chip in one round (<= 2 048 blocks of 64) is cut into a
-    // multiple of 256 waves instead, each with S <= 64 active lanes, so that every
-    // CU streams the same number of bytes (C2: 1 563 blocks of 64 would be 6 or 7
-    // waves per CU, 1 792 blocks of 56 are 7 everywhere).
-    int S = 64;
+    // Sites per wave S (at most 8 waves per CU: VGPRs).  A batch that fits the chip
+    // in one round (<= 2 048 blocks of 64) is cut into a multiple of 256 waves of
+    // S <= 64 active lanes, so that every CU streams the same number of bytes (C2:
+    // 1 563 blocks of 64 would be 6 or 7 waves per CU; 1 792 waves of 56 sites are
+    // 7 everywhere: 41 -> 39 us).  Waves per workgroup: 1 (each wave stages its own
+    // copy of the P table; sharing one per CU, RAOTEH_JIT_WAVES=7, measured the same).
+    int S = 64, WG = 1;
     const int64_t nb64 = (s->nsites + 63) / 64;
     if (nb64 >= 256 && nb64 <= 2048) {
         const int64_t nw = (nb64 + 255) / 256 * 256;
@@ -734,9 +735,11 @@ static int sites_jit(rt_sites *s, bool generic)
     }
     if (g_jit_block_sites > 0) S = g_jit_block_sites;
     if (const char *v = getenv("RAOTEH_JIT_BLOCK_SITES")) S = atoi(v);
+    if (const char *v = getenv("RAOTEH_JIT_WAVES")) WG = atoi(v);
     S = std::min(64, std::max(1, S));
+    WG = std::min(8, std::max(1, WG));
     const std::string src =
-        rt_jit_lane_source(s->ops, (int)s->model->n, (int)s->nobs, D, LA, S);
+        rt_jit_lane_source(s->ops, (int)s->model->n, (int)s->nobs, D, LA, S, WG);
     s->jit_prefetch = D;
     const int rc = rt_jit_get(s->model->ctx, src, &s->jit_fn);
     if (rc != RT_OK && !forced) {
@@ -745,7 +748,10 @@ static int sites_jit(rt_sites *s, bool generic)
         s->jit_fn = nullptr;
         return RT_OK;
     }
-    if (rc == RT_OK) s->block_sites = S;
+    if (rc == RT_OK) {
+        s->block_sites = S;
+        s->jit_waves = WG;
+    }
     return rc;
 }
 
@@ -770,7 +776,7 @@ extern "C" int rt_jit_source(int64_t nnodes, const int64_t *idx, const int64_t *
     for (auto &op : m.ops)
         if (node_obs[(size_t)op.node] >= 0) op.obs = k++;
     const int LA = getenv("RAOTEH_JIT_LOOKAHEAD") ? std::max(1, atoi(getenv("RAOTEH_JIT_LOOKAHEAD"))) : 2;
-    const std::string src = rt_jit_lane_source(m.ops, (int)n, (int)nobs, (int)prefetch, LA, 64);
+    const std::string src = rt_jit_lane_source(m.ops, (int)n, (int)nobs, (int)prefetch, LA, 64, 4);
     RT_REQUIRE((int64_t)src.size() + 1 <= capacity, "buffer too small: %lld bytes needed",
                (long long)src.size() + 1);
     memcpy(buf, src.c_str(), src.size() + 1);
@@ -860,6 +866,7 @@ extern "C" int rt_sites_clone(rt_sites *src, rt_sites **out)
     s->jit_fn = src->jit_fn;
     s->jit_prefetch = src->jit_prefetch;
     s->block_sites = src->block_sites;
+    s->jit_waves = src->jit_waves;
     s->node_obs = src->node_obs;
     s->ops = src->ops;
     int rc = sites_alloc(s, src->d_scratch != nullptr);

@@ -134,6 +134,7 @@ struct rt_sites {
     void *jit_fn = nullptr;         // hipFunction_t of the tree-specialised kernel (jit.hip)
     int jit_prefetch = 0;           // its prefetch distance (stream positions)
     int block_sites = 64;           // lane family: sites per block (< 64 only with jit_fn)
+    int jit_waves = 1;              // waves per workgroup of the tree-specialised kernel
     double *d_scratch = nullptr;    // generic kernel message stack
     int64_t scratch_bytes = 0;
 };
@@ -151,7 +152,7 @@ int rt_launch_pfrag(rt_model *m);
 int rt_launch_prune(rt_model *m, rt_sites *s);
 // jit.hip
 std::string rt_jit_lane_source(const std::vector<rt_op> &ops, int n, int K, int D, int LA,
-                               int S);
+                               int S, int WG);
 int rt_jit_get(rt_ctx *ctx, const std::string &src, void **fn);
 void rt_jit_release(const rt_ctx *ctx);
 int rt_launch_prune_jit(rt_model *m, rt_sites *s);
