@@ -186,9 +186,11 @@ def main():
         step(j)
     ctx.sync()
     ll0, st0 = model.fetch_log_likelihoods(batch0)
-    # HIP events on the kernels' own stream, sampled: every 8th launch of each
-    # kernel (an event pair per kernel per step would cost ~22 us per step)
-    ctx.set_timing(0 if os.environ.get('RAOTEH_BENCH_NO_EVENTS') else 8)
+    # HIP events stamped with each kernel's own begin / end (hipExtLaunchKernelGGL,
+    # on the library's stream), sampled: every 16th launch of each kernel, every
+    # 8th in short runs (timing every launch would cost ~20 us per step)
+    period = 16 if args.steps >= 160 else 8
+    ctx.set_timing(0 if os.environ.get('RAOTEH_BENCH_NO_EVENTS') else period)
     ctx.reset_timing()
 
     ctl.barrier()

@@ -148,29 +148,42 @@ extern "C" int rt_ctx_kernel_time(rt_ctx *ctx, int kernel, double *total_ms,
     return RT_OK;
 }
 
+static hipEvent_t slot_event(rt_timing_slot &s)
+{
+    hipEvent_t ev = nullptr;
+    if (!s.pool.empty()) { ev = s.pool.back(); s.pool.pop_back(); }
+    else if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+    return ev;
+}
+
+// Sampled timing of ONE kernel launch: between begin and end the launch goes
+// through RT_LAUNCH_TIMED / rt_launch_prune_jit, which hand ctx->ev_start/ev_stop to
+// the runtime (hipExtLaunchKernelGGL / hipExtModuleLaunchKernel).
 void rt_time_begin(rt_ctx *ctx, int kernel, const char *name, hipEvent_t *start)
 {
     *start = nullptr;
+    ctx->ev_start = ctx->ev_stop = nullptr;
     rt_timing_slot &s = ctx->slots[kernel];
     if (name && name[0]) s.name = name;
     if (!ctx->timing) return;
     if ((s.seen++ % ctx->timing_period) != 0) return;
-    hipEvent_t ev = nullptr;
-    if (!s.pool.empty()) { ev = s.pool.back(); s.pool.pop_back(); }
-    else if (hipEventCreate(&ev) != hipSuccess) return;
-    hipEventRecord(ev, ctx->stream);
-    *start = ev;
+    hipEvent_t a = slot_event(s), b = slot_event(s);
+    if (!a || !b) {
+        if (a) s.pool.push_back(a);
+        if (b) s.pool.push_back(b);
+        return;
+    }
+    ctx->ev_start = a;
+    ctx->ev_stop = b;
+    *start = a;
 }
 
 void rt_time_end(rt_ctx *ctx, int kernel, hipEvent_t start)
 {
     if (!start) return;
     rt_timing_slot &s = ctx->slots[kernel];
-    hipEvent_t ev = nullptr;
-    if (!s.pool.empty()) { ev = s.pool.back(); s.pool.pop_back(); }
-    else if (hipEventCreate(&ev) != hipSuccess) { s.pool.push_back(start); return; }
-    hipEventRecord(ev, ctx->stream);
-    s.pending.emplace_back(start, ev);
+    s.pending.emplace_back(ctx->ev_start, ctx->ev_stop);
+    ctx->ev_start = ctx->ev_stop = nullptr;
     if (s.pending.size() > 4096) drain_slot(s, false);
 }
 

@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -59,6 +60,8 @@ struct rt_ctx {
     bool timing = false;
     int timing_period = 1;
     rt_timing_slot slots[RT_K_COUNT];
+    // events of the launch being timed (rt_time_begin .. rt_time_end), else null
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     void *comm = nullptr;          // ncclComm_t
     hipStream_t comm_stream = nullptr;   // collectives overlap the next step's kernels
     void *rccl = nullptr;          // dlopen handle
@@ -148,6 +151,12 @@ int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
                    const int32_t *d_qidx, const double *d_t, double *d_P,
                    int32_t *d_info, const int32_t *d_step_of_node, int frag_kind,
                    double *d_Pfrag);
+// A timed launch: the runtime stamps the two events with the kernel's own begin and
+// end (what rocprofv3's kernel trace reports), not with the stream position of an
+// event record, which adds 2-3 us per pair.  Null events: a plain launch.
+#define RT_LAUNCH_TIMED(ctx, kern, grid, block, lds, ...)                               \
+    hipExtLaunchKernelGGL(kern, grid, block, lds, (ctx)->stream, (ctx)->ev_start,      \
+                          (ctx)->ev_stop, 0, __VA_ARGS__)
 int rt_launch_pfrag(rt_model *m);
 int rt_launch_prune(rt_model *m, rt_sites *s);
 // jit.hip

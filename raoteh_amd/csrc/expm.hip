@@ -632,7 +632,7 @@ int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
         const unsigned grid = (unsigned)((count + 63) / 64);
         const int *son = frag_kind == 0 ? d_step_of_node : nullptr;
 #define RT_SMALL(NV)                                                                 \
-        hipLaunchKernelGGL(expm_small_kernel<NV>, dim3(grid), dim3(64), 0, ctx->stream, \
+        RT_LAUNCH_TIMED(ctx, expm_small_kernel<NV>, dim3(grid), dim3(64), 0, \
                            (int)count, d_Q, d_qidx, d_t, d_P, d_info, son, d_Pfrag)
         switch ((int)n) {
         case 1: RT_SMALL(1); break;
@@ -647,7 +647,7 @@ int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
     }
     hipEvent_t ev = nullptr;
     rt_time_begin(ctx, RT_K_EXPM, "expm_mfma_regsolve", &ev);
-    hipLaunchKernelGGL(expm_kernel, dim3((unsigned)count), dim3(TPB), lds, ctx->stream,
+    RT_LAUNCH_TIMED(ctx, expm_kernel, dim3((unsigned)count), dim3(TPB), lds,
                        (int)n, d_Q, d_qidx, d_t, d_P, d_info, d_step_of_node, frag_kind,
                        d_Pfrag, getenv("RAOTEH_EXPM_DBG") ? atoi(getenv("RAOTEH_EXPM_DBG")) : 0);
     RT_HIP(hipGetLastError());

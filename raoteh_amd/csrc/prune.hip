@@ -1026,10 +1026,25 @@ reduce_partials_kernel(const double *__restrict__ partial, long npartials,
 {
     __shared__ double ssum[256];
     __shared__ double szero[256];
+    // thread t adds partials t, t + 256, ... in that order (the order fixes the
+    // rounding: totals are bitwise reproducible); the loads of eight of them are
+    // issued together so that the pass costs one L2 round trip per 2 048 partials
     double s = 0.0, z = 0.0;
-    for (long i = threadIdx.x; i < npartials; i += 256) {
-        s += partial[2 * i];
-        z += partial[2 * i + 1];
+    const double2 *p2 = (const double2 *)partial;
+    for (long base = threadIdx.x; base < npartials; base += 256 * 8) {
+        double2 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long i = base + 256 * j;
+            v[j] = i < npartials ? p2[i] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (base + 256 * j < npartials) {
+                s += v[j].x;
+                z += v[j].y;
+            }
+        }
     }
     ssum[threadIdx.x] = s;
     szero[threadIdx.x] = z;
@@ -1249,16 +1264,16 @@ static int launch_lane_reg(rt_model *m, rt_sites *s, bool *plds_out)
         auto kern = prune_lane_kernel<N, R, true>;
         RT_HIP(hipFuncSetAttribute((const void *)kern,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)((s->nblocks + 3) / 4)), dim3(256), lds,
-                           m->ctx->stream, m->d_Pfrag, (const int4_t *)s->d_lane_ops, nops,
+        RT_LAUNCH_TIMED(m->ctx, kern, dim3((unsigned)((s->nblocks + 3) / 4)), dim3(256), lds,
+                           m->d_Pfrag, (const int4_t *)s->d_lane_ops, nops,
                            s->d_obs, (int)s->nobs, m->d_root, depth_arg, s->d_loglik,
                            s->d_status, s->d_partial, (long)s->nsites, (long)s->nblocks);
     } else {
         auto kern = prune_lane_kernel<N, R, false>;
         RT_HIP(hipFuncSetAttribute((const void *)kern,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, stack));
-        hipLaunchKernelGGL(kern, dim3((unsigned)s->nblocks), dim3(64), stack,
-                           m->ctx->stream, m->d_Pfrag, (const int4_t *)s->d_lane_ops, nops,
+        RT_LAUNCH_TIMED(m->ctx, kern, dim3((unsigned)s->nblocks), dim3(64), stack,
+                           m->d_Pfrag, (const int4_t *)s->d_lane_ops, nops,
                            s->d_obs, (int)s->nobs, m->d_root, depth, s->d_loglik,
                            s->d_status, s->d_partial, (long)s->nsites, (long)s->nblocks);
     }
@@ -1289,8 +1304,8 @@ static int launch_lane_dma(rt_model *m, rt_sites *s)
     auto kern = prune_lanedma_kernel<N, R, B, WPB>;
     RT_HIP(hipFuncSetAttribute((const void *)kern,
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)((nwaves + WPB - 1) / WPB)), dim3(64 * WPB), lds,
-                       m->ctx->stream, m->d_Pfrag, (const int4_t *)s->d_lane_ops, nops, nrec,
+    RT_LAUNCH_TIMED(m->ctx, kern, dim3((unsigned)((nwaves + WPB - 1) / WPB)), dim3(64 * WPB), lds,
+                       m->d_Pfrag, (const int4_t *)s->d_lane_ops, nops, nrec,
                        s->d_obs, (int)s->nobs, m->d_root, depth, s->d_loglik, s->d_status,
                        s->d_partial, (long)s->nsites, nwaves);
     return RT_OK;
@@ -1358,7 +1373,7 @@ static int launch_mfma_inst(rt_model *m, rt_sites *s)
             auto kern = prune_mfma_solo_kernel<NT, KS>;
             RT_HIP(hipFuncSetAttribute((const void *)kern,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, m->ctx->stream, m->d_Pfrag,
+            RT_LAUNCH_TIMED(m->ctx, kern, dim3(grid), dim3(256), lds, m->d_Pfrag,
                                (const int4_t *)s->d_lane_ops, (int)s->ops.size(), s->d_obs,
                                (int)s->nobs, m->d_root, (int)m->n, lds_slots, s->d_loglik,
                                s->d_status, s->d_partial, (long)s->nsites, (long)s->nblocks);
@@ -1372,7 +1387,7 @@ static int launch_mfma_inst(rt_model *m, rt_sites *s)
     auto kern = prune_mfma_kernel<NT, KS>;
     RT_HIP(hipFuncSetAttribute((const void *)kern,
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, m->ctx->stream,
+    RT_LAUNCH_TIMED(m->ctx, kern, dim3(grid), dim3(WAVES * 64), lds,
                        m->d_Pfrag, (const int4_t *)s->d_lane_ops, (int)s->ops.size(),
                        s->d_obs, (int)s->nobs, m->d_root, (int)m->n, lds_slots,
                        s->d_loglik, s->d_status, s->d_partial, (long)s->nsites,
@@ -1415,9 +1430,8 @@ static int launch_generic(rt_model *m, rt_sites *s, const char **name)
     const int np = (n + 1) & ~1;
     const long nsp = s->nblocks * 64;
     const unsigned grid = (unsigned)s->nblocks;
-    hipStream_t st = m->ctx->stream;
 #define RT_GEN(NMAX)                                                               \
-    hipLaunchKernelGGL(prune_generic_kernel<NMAX>, dim3(grid), dim3(64), 0, st,    \
+    RT_LAUNCH_TIMED(m->ctx, prune_generic_kernel<NMAX>, dim3(grid), dim3(64), 0,    \
                        m->d_P, s->d_ops, (int)s->ops.size(), s->d_obs,             \
                        (int)s->nobs, n, np, m->d_root, s->d_loglik, s->d_status,   \
                        s->d_partial, s->d_scratch, nsp, (long)s->nsites)
@@ -1466,7 +1480,7 @@ int rt_launch_prune(rt_model *m, rt_sites *s)
         s->comm_pending = false;
     }
     rt_time_begin(ctx, RT_K_REDUCE, "reduce_partials", &ev);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, ctx->stream,
+    RT_LAUNCH_TIMED(ctx, reduce_partials_kernel, dim3(1), dim3(256), 0,
                        s->d_partial, (long)s->npartials, s->d_totals,
                        (double)s->nsites);
     RT_HIP(hipGetLastError());
