@@ -53,7 +53,7 @@ for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
 
 prune = None
 for k in out.get('FETCH_SIZE', {}):
-    if 'prune_' in k:
+    if 'prune' in k and 'pack' not in k:
         prune = k
 if prune:
     f = out['FETCH_SIZE'][prune]['avg_kb'] * 1024.0
