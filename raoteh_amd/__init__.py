@@ -6,7 +6,9 @@ independent sites.  Host code is Python over a ctypes C ABI
 (include/raoteh_hip.h); there is no CPU fallback.
 
 Modules mirror the reference's (raoteh/sampler/...):
-  _mjp_dense, _mcy_dense, _mcx_dense, _mcz, _mc0_dense, _util
+  dense ndarray API   _mjp_dense, _mcy_dense, _mcx_dense, _mc0_dense (+ _mcz_dense)
+  sparse nx/dict API  _mjp, _mcy, _mcx, _mcz, _mc0
+  _util
 and ``device`` holds the batched device-resident objects.
 """
 

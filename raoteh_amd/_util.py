@@ -17,3 +17,9 @@ class StructuralZeroProb(ZeroProbError):
 
 class NumericalZeroProb(ZeroProbError):
     pass
+
+
+def get_first_element(elements):
+    # raoteh/sampler/_util.py:23-25
+    for x in elements:
+        return x

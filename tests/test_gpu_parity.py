@@ -26,7 +26,7 @@ RTOL_LL = 1e-10
 @pytest.fixture(scope='module')
 def ra():
     import raoteh_amd
-    from raoteh_amd import (_mjp_dense, _mcy_dense, _mcx_dense, _mcz, device,
+    from raoteh_amd import (_mjp_dense, _mcy_dense, _mcx_dense, _mcz_dense as _mcz, device,
                             _lib, synth, pyfelscore_compat)
     class NS(object):
         pass
@@ -461,6 +461,90 @@ def test_generic_kernel_agrees(ra, n):
         ra.lib.check(ra.lib.lib().rt_set_option(b'force_generic', 0))
     np.testing.assert_allclose(gen, want, rtol=RTOL_LL)
     np.testing.assert_allclose(fast, want, rtol=RTOL_LL)
+
+
+def test_sparse_api_matches_reference_golden(ra):
+    """The reference's sparse surface (nx.DiGraph matrices over arbitrary state
+    labels, dict results): _mjp (:349-428), _mcy (:323-741), _mcx (:36-256),
+    _mcz (:30-209) against values produced by the reference's own pure-Python
+    functions (tests/golden/sparse_api.json)."""
+    from raoteh_amd import _mjp, _mcy, _mcx, _mcz as mcz_sparse
+    from _sparse_cases import build, int_keys
+    fx = load_golden('sparse_api')
+
+    def check_pmap(got, want):
+        want = int_keys(want)
+        assert set(got) == set(want)
+        for v, m in want.items():
+            assert set(got[v]) == set(int(k) for k in m), v
+            for k, x in m.items():
+                assert got[v][int(k)] == pytest.approx(x, rel=1e-11, abs=1e-300)
+
+    for c in fx['cases']:
+        # continuous time: per-edge expm of the sparse rate matrices
+        T, root, Q_default, allowed, node_to_state, root_distn = build(c, False)
+        T_aug = _mjp.get_expm_augmented_tree(T, root, Q_default=Q_default)
+        for na, nb in nx.bfs_edges(T, root):
+            want = dict(((a, b), w) for a, b, w in c['P'][str(nb)])
+            P = T_aug[na][nb]['P']
+            assert set(P.edges()) == set(want)
+            for (a, b), w in want.items():
+                assert P[a][b]['weight'] == pytest.approx(w, rel=1e-10, abs=1e-15)
+        if c['y_zero']:
+            with pytest.raises(ra.pkg.StructuralZeroProb):
+                _mjp.get_likelihood(T, allowed, root, root_distn=root_distn,
+                                    Q_default=Q_default)
+        else:
+            lk = _mjp.get_likelihood(T, allowed, root, root_distn=root_distn,
+                                     Q_default=Q_default)
+            assert lk == pytest.approx(c['y_likelihood'], rel=1e-10)
+        # discrete time on the reference's own P digraphs
+        T, root, _, allowed, node_to_state, root_distn = build(c, True)
+        nset = _mcy.get_node_to_set(T, root, node_to_allowed_states=allowed)
+        assert nset == dict((v, set(s)) for v, s in int_keys(c['y_set']).items())
+        pset = _mcy.get_node_to_pset(T, root, node_to_allowed_states=allowed)
+        for v, s in int_keys(c['y_pset']).items():
+            assert set(s) <= pset[v] and nset[v] <= pset[v]
+        if not c['y_zero']:
+            check_pmap(_mcy.get_node_to_pmap(T, root, node_to_allowed_states=allowed),
+                       c['y_pmap'])
+            check_pmap(_mcy.get_node_to_pmap(T, root, node_to_allowed_states=allowed,
+                                             node_to_set=nset), c['y_pmap'])
+            assert _mcy.get_likelihood(
+                T, root, node_to_allowed_states=allowed, root_distn=root_distn
+            ) == pytest.approx(c['y_likelihood'], rel=1e-11)
+            obs = dict((v, int_keys(m)) for v, m in int_keys(c['z_obs']).items())
+            check_pmap(mcz_sparse.get_node_to_pmap(
+                T, root, node_to_state_to_likelihood=obs), c['z_pmap'])
+            check_pmap(mcz_sparse.get_node_to_pmap(
+                T, root, node_to_state_to_likelihood=obs, node_to_set=nset),
+                c['z_pmap'])
+            assert mcz_sparse.get_node_to_set(
+                T, root, node_to_state_to_likelihood=obs) == nset
+        else:
+            with pytest.raises(ra.pkg.StructuralZeroProb):
+                _mcy.get_likelihood(T, root, node_to_allowed_states=allowed,
+                                    root_distn=root_distn)
+        if c['x_zero']:
+            with pytest.raises(ra.pkg.StructuralZeroProb):
+                _mcx.get_likelihood(T, root, node_to_state=node_to_state,
+                                    root_distn=root_distn)
+        else:
+            check_pmap(_mcx.get_node_to_pmap(T, root, node_to_state=node_to_state),
+                       c['x_pmap'])
+            assert _mcx.get_likelihood(
+                T, root, node_to_state=node_to_state, root_distn=root_distn
+            ) == pytest.approx(c['x_likelihood'], rel=1e-11)
+    # single-node trees and argument errors (_mcy.py:721-735, _mjp.py:397-398)
+    S = nx.Graph()
+    S.add_node(9)
+    assert _mcy.get_likelihood(S, 9, node_to_allowed_states={9: {1, 2}}) == 1
+    assert _mcy.get_likelihood(S, 9, node_to_allowed_states={9: {1, 2}},
+                               root_distn={2: 0.25, 5: 0.5}) == 0.25
+    with pytest.raises(ra.pkg.StructuralZeroProb):
+        _mcy.get_likelihood(S, 9, node_to_allowed_states={9: set()})
+    with pytest.raises(ValueError):
+        _mjp.get_likelihood(nx.Graph([(0, 1, dict(weight=1.0))]), {}, 5)
 
 
 @pytest.mark.parametrize('n', [1, 2, 3, 4])

@@ -19,6 +19,7 @@ Reference functions exercised:
   _mc0.get_node_to_set_unaccelerated           raoteh/sampler/_mc0.py:89-138
   _mcy.unaccelerated_get_node_to_pset/_pmap    raoteh/sampler/_mcy.py:396-470,611-682
   _mcz.get_node_to_pmap                        raoteh/sampler/_mcz.py:94-166
+  _linalg.sparse_expm_naive                    raoteh/sampler/_linalg.py:72-90
   _conditional_expectation.get_jukes_cantor_*  raoteh/sampler/_conditional_expectation.py:15-33
 expm per edge is ``scipy.linalg.expm(Q*t)`` exactly as ``_mjp_dense.py:24-25``.
 
@@ -316,6 +317,142 @@ def fixture_random_sparse(mods, ncases=24):
     return dict(cases=cases)
 
 
+def fixture_sparse_api(mods, ncases=16):
+    """The sparse (nx.DiGraph / dict) API with arbitrary, unsorted state labels:
+    rate matrices as sparse digraphs without loops, per-edge P from the
+    reference's own _linalg.sparse_expm_naive (raoteh/sampler/_linalg.py:72-90;
+    networkx >= 2 returns an iterator from all_pairs_shortest_path_length, so
+    the harness hands that function a dict, as SURVEY.md 8a row 3 asks), then
+    the reference's pure-Python twins: _mcx (:36-256), _mcy unaccelerated
+    (:396-470, 611-682), _mc0 (:89-138, 202-252), _mcz (:94-166)."""
+    _mc0, _mcx, _mcy, _mcz, _util = (mods[k] for k in
+                                     ('_mc0', '_mcx', '_mcy', '_mcz', '_util'))
+    _linalg = importlib.import_module('raoteh.sampler._linalg')
+    real_apspl = nx.all_pairs_shortest_path_length
+
+    class _NxShim(object):
+        def __getattr__(self, name):
+            return getattr(nx, name)
+        @staticmethod
+        def all_pairs_shortest_path_length(G):
+            return dict(real_apspl(G))
+    _linalg.nx = _NxShim()
+
+    rng = np.random.RandomState(4321)
+    labels_pool = [3, 40, 7, 11, 25, 2]
+    cases = []
+    for case in range(ncases):
+        n = int(rng.randint(2, 6))
+        labels = [labels_pool[i] for i in rng.permutation(len(labels_pool))[:n]]
+        nnodes = int(rng.randint(2, 9))
+        ids = (rng.permutation(30)[:nnodes] + 3).tolist()
+        T = nx.Graph()
+        T.add_node(ids[0])
+        for k in range(1, nnodes):
+            T.add_edge(ids[rng.randint(k)], ids[k],
+                       weight=float(rng.uniform(0.05, 0.6)))
+        root = ids[int(rng.randint(nnodes))]
+
+        def random_Q():
+            Q = nx.DiGraph()
+            Q.add_nodes_from(labels)
+            for sa in labels:
+                for sb in labels:
+                    if sa != sb and rng.uniform() < 0.55:
+                        Q.add_edge(sa, sb, weight=float(rng.exponential()))
+            return Q
+        Q_default = random_Q()
+        edge_Q = {}
+        for na, nb in nx.bfs_edges(T, root):
+            if rng.uniform() < 0.4:
+                edge_Q[nb] = random_Q()
+        T_aug = nx.Graph()
+        T_aug.add_nodes_from(T)
+        P_json = {}
+        for na, nb in nx.bfs_edges(T, root):
+            Q = edge_Q.get(nb, Q_default)
+            P = _linalg.sparse_expm_naive(Q, T[na][nb]['weight'])
+            T_aug.add_edge(na, nb, weight=T[na][nb]['weight'], P=P)
+            P_json[str(int(nb))] = [[int(sa), int(sb), float(d['weight'])]
+                                    for sa, sb, d in P.edges(data=True)]
+        w = rng.exponential(size=n)
+        if n > 2:
+            w[rng.randint(n)] = 0
+        root_distn = dict((labels[i], float(p)) for i, p in enumerate(w / w.sum())
+                          if p)
+        allowed = dict((v, set(labels)) for v in T)
+        for v in T:
+            if rng.uniform() < 0.7:
+                allowed[v].discard(labels[int(rng.randint(n))])
+        node_to_state = dict((v, labels[int(rng.randint(n))]) for v in T
+                             if T.degree(v) == 1 and v != root
+                             and rng.uniform() < 0.8)
+        rec = dict(
+            labels=[int(x) for x in labels], root=int(root),
+            nodes=[int(v) for v in T],
+            edges=[[int(a), int(b), float(d['weight'])]
+                   for a, b, d in T.edges(data=True)],
+            Q_default=[[int(a), int(b), float(d['weight'])]
+                       for a, b, d in Q_default.edges(data=True)],
+            edge_Q=dict((str(int(k)), [[int(a), int(b), float(d['weight'])]
+                                       for a, b, d in Q.edges(data=True)])
+                        for k, Q in edge_Q.items()),
+            P=P_json,
+            root_distn=dict((str(k), v) for k, v in root_distn.items()),
+            allowed=dict((str(int(v)), sorted(int(x) for x in ss))
+                         for v, ss in allowed.items()),
+            node_to_state=dict((str(int(v)), int(x))
+                               for v, x in node_to_state.items()))
+
+        def sets_json(d):
+            return dict((str(int(v)), sorted(int(x) for x in ss))
+                        for v, ss in d.items())
+
+        def pmap_sparse_json(d):
+            return dict((str(int(v)), dict((str(int(k)), float(x))
+                                           for k, x in m.items()))
+                        for v, m in d.items())
+
+        # type y
+        pset = _mcy.unaccelerated_get_node_to_pset(
+            T_aug, root, node_to_allowed_states=allowed)
+        nset = _mc0.get_node_to_set_unaccelerated(T_aug, root, pset)
+        rec['y_pset'] = sets_json(pset)
+        rec['y_set'] = sets_json(nset)
+        try:
+            pmap = _mcy.unaccelerated_get_node_to_pmap(
+                T_aug, root, node_to_allowed_states=allowed, node_to_set=nset)
+            rec['y_pmap'] = pmap_sparse_json(pmap)
+            rec['y_likelihood'] = float(_mc0.get_likelihood(
+                pmap[root], root_distn=root_distn))
+            rec['y_zero'] = False
+        except (_util.StructuralZeroProb, ValueError):
+            # an empty node set: the reference's pure-Python pmap raises
+            # 'internal error'; the likelihood is a structural zero
+            rec['y_zero'] = True
+        # type x
+        try:
+            rec['x_likelihood'] = float(_mcx.get_likelihood(
+                T_aug, root, node_to_state=node_to_state,
+                root_distn=root_distn))
+            rec['x_pmap'] = pmap_sparse_json(_mcx.get_node_to_pmap(
+                T_aug, root, node_to_state=node_to_state))
+            rec['x_zero'] = False
+        except (_util.StructuralZeroProb, ValueError):
+            rec['x_zero'] = True
+        # type z on the type-y support
+        if not rec['y_zero']:
+            obs = dict((v, dict((s, float(rng.uniform(0.1, 1.0)))
+                                for s in allowed[v])) for v in T)
+            pz = _mcz.get_node_to_pmap(T_aug, root,
+                                       node_to_state_to_likelihood=obs,
+                                       node_to_set=nset)
+            rec['z_obs'] = pmap_sparse_json(obs)
+            rec['z_pmap'] = pmap_sparse_json(pz)
+        cases.append(rec)
+    return dict(cases=cases)
+
+
 def fixture_config(mods, name, nsites, with_pmap=False):
     """A BASELINE.json-shaped configuration evaluated by the reference path:
     E x scipy.linalg.expm + _mcx.get_likelihood (type-x observations, C1-C3)
@@ -420,6 +557,7 @@ def main():
         kat_history=fixture_kat_history(mods),
         jukes_cantor=fixture_jukes_cantor(mods),
         random_sparse=fixture_random_sparse(mods),
+        sparse_api=fixture_sparse_api(mods),
         expm=fixture_expm(mods),
         config_c1=fixture_config(mods, 'c1', 4, with_pmap=True),
         config_c2=fixture_config(mods, 'c2', 6),
