@@ -206,7 +206,7 @@ int rt_build_schedule(int64_t nnodes, const int64_t *tree_csr_indices,
  * sites per wave of those kernels (automatic balances the waves over the CUs). */
 int rt_set_option(const char *key, int64_t value);
 /* Diagnostics, host only: the HIP source rt_sites_create would compile for this
- * tree (n <= 4), observation stream obs_nodes and prefetch distance.         */
+ * tree (n <= 32; MFMA family for n > 4), observation stream and prefetch distance. */
 int rt_jit_source(int64_t nnodes, const int64_t *tree_csr_indices,
             const int64_t *tree_csr_indptr, int64_t n, int64_t nobs,
             const int64_t *obs_nodes, int64_t prefetch, char *buf, int64_t capacity);

@@ -684,6 +684,8 @@ static int sites_alloc(rt_sites *s, bool generic)
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_loglik, padded * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_status, padded * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_partial, s->npartials * 16);
+    // entries no kernel writes (padding of the last workgroup) must read as zero
+    if (e == hipSuccess) e = hipMemset(s->d_partial, 0, s->npartials * 16);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_totals, 3 * 8);
     if (e == hipSuccess) e = hipMemset(s->d_totals, 0, 3 * 8);
     if (e == hipSuccess && generic) {
@@ -726,9 +728,38 @@ static int sites_jit(rt_sites *s, bool generic)
     if (const char *v = getenv("RAOTEH_JIT")) want = atoi(v);
     const bool forced = want > 0;
     if (want < 0) want = s->nsites >= RT_JIT_MIN_SITES;
-    if (!want || generic || s->layout != RT_LAYOUT_LANE) return RT_OK;
+    if (!want || generic) return RT_OK;
     // straight-line code: keep it inside the instruction cache's reach
     if (s->ops.size() > 1024) return RT_OK;
+    if (s->layout == RT_LAYOUT_MFMA) {
+        // one wave = T site tiles (jit.hip, MFMA family): n <= 32 only (row tiles of
+        // larger matrices do not fit one wave's registers)
+        if (s->model->n > 32 || !s->mfma_solo) return RT_OK;
+        const int64_t ntiles = (s->nsites + 15) / 16;
+        const int KS = (int)((s->model->n + 3) / 4), NT = (int)((s->model->n + 15) / 16);
+        // tiles per wave: as few waves as SIMDs (1 024) when the batch allows it,
+        // within the register file (pending accumulators: KS doubles per lane, tile
+        // and level)
+        int T = (int)std::min<int64_t>(4, std::max<int64_t>(1, (ntiles + 1023) / 1024));
+        auto regs = [&](int t) {
+            return 2 * (s->model->max_depth * t * KS + 2 * NT * KS + 3 * t * KS + 4 * t * NT) + 48;
+        };
+        while (T > 1 && regs(T) > 480) --T;
+        if (const char *v = getenv("RAOTEH_JIT_TILES")) T = std::min(4, std::max(1, atoi(v)));
+        int D = 2, LA = 1;
+        if (const char *v = getenv("RAOTEH_JIT_PREFETCH")) D = std::max(1, atoi(v));
+        if (const char *v = getenv("RAOTEH_JIT_LOOKAHEAD")) LA = std::max(1, atoi(v));
+        const std::string src =
+            rt_jit_mfma_source(s->ops, (int)s->model->n, (int)s->nobs, T, D, LA);
+        s->jit_prefetch = D;
+        const int rc = rt_jit_get(s->model->ctx, src, &s->jit_fn, true);
+        if (rc != RT_OK && !forced) {
+            s->jit_fn = nullptr;
+            return RT_OK;
+        }
+        if (rc == RT_OK) s->jit_tiles = T;
+        return rc;
+    }
     // measured on C2: 6 stream positions and 2 P records ahead (tools/ab_jit.sh)
     int D = 6;
     if (const char *v = getenv("RAOTEH_JIT_PREFETCH")) D = std::max(1, atoi(v));
@@ -774,7 +805,7 @@ extern "C" int rt_jit_source(int64_t nnodes, const int64_t *idx, const int64_t *
 {
     RT_REQUIRE(nnodes >= 1 && ptr && (idx || nnodes == 1) && buf && capacity > 0,
                "bad arguments");
-    RT_REQUIRE(n >= 1 && n <= 4, "tree-specialised kernels exist for n <= 4");
+    RT_REQUIRE(n >= 1 && n <= 32, "tree-specialised kernels exist for n <= 32");
     rt_model m;
     m.nnodes = nnodes;
     if (nnodes > 1) m.indices.assign(idx, idx + (nnodes - 1));
@@ -789,7 +820,10 @@ extern "C" int rt_jit_source(int64_t nnodes, const int64_t *idx, const int64_t *
     for (auto &op : m.ops)
         if (node_obs[(size_t)op.node] >= 0) op.obs = k++;
     const int LA = getenv("RAOTEH_JIT_LOOKAHEAD") ? std::max(1, atoi(getenv("RAOTEH_JIT_LOOKAHEAD"))) : 2;
-    const std::string src = rt_jit_lane_source(m.ops, (int)n, (int)nobs, (int)prefetch, LA, 64, 4);
+    const int T = getenv("RAOTEH_JIT_TILES") ? std::min(4, std::max(1, atoi(getenv("RAOTEH_JIT_TILES")))) : 2;
+    const std::string src = n <= 4
+        ? rt_jit_lane_source(m.ops, (int)n, (int)nobs, (int)prefetch, LA, 64, 4)
+        : rt_jit_mfma_source(m.ops, (int)n, (int)nobs, T, (int)prefetch, 1);
     RT_REQUIRE((int64_t)src.size() + 1 <= capacity, "buffer too small: %lld bytes needed",
                (long long)src.size() + 1);
     memcpy(buf, src.c_str(), src.size() + 1);
@@ -880,6 +914,7 @@ extern "C" int rt_sites_clone(rt_sites *src, rt_sites **out)
     s->jit_prefetch = src->jit_prefetch;
     s->block_sites = src->block_sites;
     s->jit_waves = src->jit_waves;
+    s->jit_tiles = src->jit_tiles;
     s->node_obs = src->node_obs;
     s->ops = src->ops;
     int rc = sites_alloc(s, src->d_scratch != nullptr);

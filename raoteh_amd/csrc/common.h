@@ -138,6 +138,7 @@ struct rt_sites {
     int jit_prefetch = 0;           // its prefetch distance (stream positions)
     int block_sites = 64;           // lane family: sites per block (< 64 only with jit_fn)
     int jit_waves = 1;              // waves per workgroup of the tree-specialised kernel
+    int jit_tiles = 1;              // MFMA family: site tiles per wave of that kernel
     double *d_scratch = nullptr;    // generic kernel message stack
     int64_t scratch_bytes = 0;
 };
@@ -162,7 +163,8 @@ int rt_launch_prune(rt_model *m, rt_sites *s);
 // jit.hip
 std::string rt_jit_lane_source(const std::vector<rt_op> &ops, int n, int K, int D, int LA,
                                int S, int WG);
-int rt_jit_get(rt_ctx *ctx, const std::string &src, void **fn);
+std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int T, int D, int LA);
+int rt_jit_get(rt_ctx *ctx, const std::string &src, void **fn, bool mfma = false);
 void rt_jit_release(const rt_ctx *ctx);
 int rt_launch_prune_jit(rt_model *m, rt_sites *s);
 int rt_sites_pack(rt_sites *s, int kind, const int64_t *obs_order,

@@ -1457,8 +1457,12 @@ int rt_launch_prune(rt_model *m, rt_sites *s)
     if (generic) rc = launch_generic(m, s, &name);
     else if (s->jit_fn) {
         rc = rt_launch_prune_jit(m, s);
-        snprintf(jit_name, sizeof(jit_name), "prune_tree_jit<%d,D%d>", (int)m->n,
-                 s->jit_prefetch);
+        if (s->layout == RT_LAYOUT_LANE)
+            snprintf(jit_name, sizeof(jit_name), "prune_tree_jit<%d,D%d>", (int)m->n,
+                     s->jit_prefetch);
+        else
+            snprintf(jit_name, sizeof(jit_name), "prune_tree_jit_mfma<%d,T%d>", (int)m->n,
+                     s->jit_tiles);
         name = jit_name;
     } else if (s->layout == RT_LAYOUT_LANE) {
         switch ((int)m->n) {

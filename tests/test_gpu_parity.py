@@ -9,6 +9,7 @@ use RTOL_LL = 1e-10 for log-likelihoods and 1e-11..1e-12 where the arithmetic
 is a plain re-ordering of the same f64 sums.  Masks / statuses are bit-exact.
 """
 import itertools
+import os
 import warnings
 
 import networkx as nx
@@ -547,7 +548,7 @@ def test_sparse_api_matches_reference_golden(ra):
         _mjp.get_likelihood(nx.Graph([(0, 1, dict(weight=1.0))]), {}, 5)
 
 
-@pytest.mark.parametrize('n', [1, 2, 3, 4])
+@pytest.mark.parametrize('n', [1, 2, 3, 4, 5, 13, 16, 20, 32])
 def test_tree_specialised_kernel_is_bit_identical(ra, n):
     """jit.hip: the hiprtc-compiled straight-line kernel for one tree performs
     the interpreter kernel's arithmetic in the interpreter's order."""
@@ -567,9 +568,15 @@ def test_tree_specialised_kernel_is_bit_identical(ra, n):
         out = {}
         # (jit, sites per wave): 64 = the interpreter's blocks; fewer sites per
         # wave change the HBM layout and the partial sums, not a site's value
-        for jit, bs in ((0, 0), (1, 64), (1, 49), (1, 7)):
+        # n > 4 (MFMA family): 1..4 site tiles per wave instead
+        variants = (((0, 0), (1, 64), (1, 49), (1, 7)) if n <= 4 else
+                    ((0, 0), (1, 64), (1, 2), (1, 3), (1, 4)))
+        for jit, bs in variants:
             ra.lib.check(set_option(b'jit', jit))
-            ra.lib.check(set_option(b'jit_block_sites', bs))
+            if n <= 4:
+                ra.lib.check(set_option(b'jit_block_sites', bs))
+            elif jit:
+                os.environ['RAOTEH_JIT_TILES'] = str(1 if bs == 64 else bs)
             try:
                 batch = model.upload_sites(obs_nodes, dense, kind='dense')
                 ll, st = model.log_likelihoods(batch)
@@ -581,8 +588,9 @@ def test_tree_specialised_kernel_is_bit_identical(ra, n):
             finally:
                 ra.lib.check(set_option(b'jit', -1))
                 ra.lib.check(set_option(b'jit_block_sites', 0))
-        assert out[0, 0][3].startswith('prune_lane'), out[0, 0][3]
-        for key in ((1, 64), (1, 49), (1, 7)):
+                os.environ.pop('RAOTEH_JIT_TILES', None)
+        assert out[0, 0][3].startswith(('prune_lane', 'prune_mfma_solo')), out[0, 0][3]
+        for key in variants[1:]:
             assert out[key][3].startswith('prune_tree_jit'), out[key][3]
             np.testing.assert_array_equal(out[0, 0][0], out[key][0])
             np.testing.assert_array_equal(out[0, 0][1], out[key][1])
