@@ -193,3 +193,33 @@ def test_tree_specialised_source_is_generated_on_the_host():
         ta.nnodes, ta.indices.ctypes.data_as(p64), ta.indptr.ctypes.data_as(p64),
         4, len(obs), obs.ctypes.data_as(p64), 3, small, len(small))
     assert rc < 0
+
+
+def test_tree_specialised_mfma_source_is_generated_on_the_host(monkeypatch):
+    """MFMA family (4 < n <= 32): NT * KS MFMAs per step and tile, T tiles per
+    wave, one A-fragment load per (step, row tile, k-pair) whatever T is."""
+    import ctypes
+    import re
+    from raoteh_amd import _lib, synth
+    from raoteh_amd._tree import TreeArrays
+    T, root, leaves = synth.balanced_tree(8, seed=0)
+    ta = TreeArrays(T, root)
+    obs = np.array([ta.node_to_index[v] for v in leaves], dtype=np.int64)
+    p64 = ctypes.POINTER(ctypes.c_int64)
+    buf = ctypes.create_string_buffer(1 << 22)
+    for n, tiles in ((5, 1), (20, 3), (32, 2)):
+        monkeypatch.setenv('RAOTEH_JIT_TILES', str(tiles))
+        _lib.check(_lib.lib().rt_jit_source(
+            ta.nnodes, ta.indices.ctypes.data_as(p64), ta.indptr.ctypes.data_as(p64),
+            n, len(obs), obs.ctypes.data_as(p64), 2, buf, len(buf)))
+        src = buf.value.decode()
+        nt, ks = (n + 15) // 16, (n + 3) // 4
+        kp = (ks + 1) // 2
+        steps = ta.nnodes - 1                      # the root step has no product
+        assert src.count('__builtin_amdgcn_mfma_f64_16x16x4f64') == steps * nt * ks * tiles
+        assert len(re.findall(r'const rt_d2 A\d+_\d+_\d+ = ag\[', src)) == steps * nt * kp
+        assert len(re.findall(r'const rt_d2 o\d+_\d+_\d+ = g\d+\[', src)) == len(obs) * kp * tiles
+    rc = _lib.lib().rt_jit_source(
+        ta.nnodes, ta.indices.ctypes.data_as(p64), ta.indptr.ctypes.data_as(p64),
+        33, len(obs), obs.ctypes.data_as(p64), 2, buf, len(buf))
+    assert rc < 0
