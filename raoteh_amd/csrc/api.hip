@@ -734,7 +734,31 @@ static int sites_jit(rt_sites *s, bool generic)
     if (s->layout == RT_LAYOUT_MFMA) {
         // one wave = T site tiles (jit.hip, MFMA family): n <= 32 only (row tiles of
         // larger matrices do not fit one wave's registers)
-        if (s->model->n > 32 || !s->mfma_solo) return RT_OK;
+        if (s->model->n > 32 || !s->mfma_solo) {
+            // split-M family: NT waves share T tiles.  T = 2 halves the A-fragment
+            // traffic and the barriers per MFMA but needs the whole register file
+            // (one workgroup per CU): worth it once the batch is several rounds deep
+            if (s->model->n > 64) return RT_OK;
+            const int64_t ntiles = (s->nsites + 15) / 16;
+            int T = ntiles >= 2048 ? 2 : 1;
+            if (const char *v = getenv("RAOTEH_JIT_TILES")) T = std::min(3, std::max(1, atoi(v)));
+            int D = 1, LA = 1;
+            if (const char *v = getenv("RAOTEH_JIT_PREFETCH")) D = std::max(1, atoi(v));
+            if (const char *v = getenv("RAOTEH_JIT_LOOKAHEAD")) LA = std::max(1, atoi(v));
+            const std::string src =
+                rt_jit_mfma_split_source(s->ops, (int)s->model->n, (int)s->nobs, T, D, LA);
+            s->jit_prefetch = D;
+            const int rc = rt_jit_get(s->model->ctx, src, &s->jit_fn, true);
+            if (rc != RT_OK && !forced) {
+                s->jit_fn = nullptr;
+                return RT_OK;
+            }
+            if (rc == RT_OK) {
+                s->jit_tiles = T;
+                s->jit_waves = (int)((s->model->n + 15) / 16);
+            }
+            return rc;
+        }
         const int64_t ntiles = (s->nsites + 15) / 16;
         const int KS = (int)((s->model->n + 3) / 4), NT = (int)((s->model->n + 15) / 16);
         // tiles per wave: as few waves as SIMDs (1 024) when the batch allows it,
@@ -805,7 +829,7 @@ extern "C" int rt_jit_source(int64_t nnodes, const int64_t *idx, const int64_t *
 {
     RT_REQUIRE(nnodes >= 1 && ptr && (idx || nnodes == 1) && buf && capacity > 0,
                "bad arguments");
-    RT_REQUIRE(n >= 1 && n <= 32, "tree-specialised kernels exist for n <= 32");
+    RT_REQUIRE(n >= 1 && n <= 64, "tree-specialised kernels exist for n <= 64");
     rt_model m;
     m.nnodes = nnodes;
     if (nnodes > 1) m.indices.assign(idx, idx + (nnodes - 1));
@@ -823,7 +847,9 @@ extern "C" int rt_jit_source(int64_t nnodes, const int64_t *idx, const int64_t *
     const int T = getenv("RAOTEH_JIT_TILES") ? std::min(4, std::max(1, atoi(getenv("RAOTEH_JIT_TILES")))) : 2;
     const std::string src = n <= 4
         ? rt_jit_lane_source(m.ops, (int)n, (int)nobs, (int)prefetch, LA, 64, 4)
-        : rt_jit_mfma_source(m.ops, (int)n, (int)nobs, T, (int)prefetch, 1);
+        : n <= 32 ? rt_jit_mfma_source(m.ops, (int)n, (int)nobs, T, (int)prefetch, 1)
+                  : rt_jit_mfma_split_source(m.ops, (int)n, (int)nobs, std::min(T, 3),
+                                             (int)prefetch, 1);
     RT_REQUIRE((int64_t)src.size() + 1 <= capacity, "buffer too small: %lld bytes needed",
                (long long)src.size() + 1);
     memcpy(buf, src.c_str(), src.size() + 1);

@@ -164,6 +164,8 @@ int rt_launch_prune(rt_model *m, rt_sites *s);
 std::string rt_jit_lane_source(const std::vector<rt_op> &ops, int n, int K, int D, int LA,
                                int S, int WG);
 std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int T, int D, int LA);
+std::string rt_jit_mfma_split_source(const std::vector<rt_op> &ops, int n, int K, int T, int D,
+                                     int LA);
 int rt_jit_get(rt_ctx *ctx, const std::string &src, void **fn, bool mfma = false);
 void rt_jit_release(const rt_ctx *ctx);
 int rt_launch_prune_jit(rt_model *m, rt_sites *s);

@@ -548,7 +548,7 @@ def test_sparse_api_matches_reference_golden(ra):
         _mjp.get_likelihood(nx.Graph([(0, 1, dict(weight=1.0))]), {}, 5)
 
 
-@pytest.mark.parametrize('n', [1, 2, 3, 4, 5, 13, 16, 20, 32])
+@pytest.mark.parametrize('n', [1, 2, 3, 4, 5, 13, 16, 20, 32, 33, 48, 61, 64])
 def test_tree_specialised_kernel_is_bit_identical(ra, n):
     """jit.hip: the hiprtc-compiled straight-line kernel for one tree performs
     the interpreter kernel's arithmetic in the interpreter's order."""
@@ -569,8 +569,10 @@ def test_tree_specialised_kernel_is_bit_identical(ra, n):
         # (jit, sites per wave): 64 = the interpreter's blocks; fewer sites per
         # wave change the HBM layout and the partial sums, not a site's value
         # n > 4 (MFMA family): 1..4 site tiles per wave instead
+        # (n > 32: tiles per workgroup of NT waves, at most 3)
         variants = (((0, 0), (1, 64), (1, 49), (1, 7)) if n <= 4 else
-                    ((0, 0), (1, 64), (1, 2), (1, 3), (1, 4)))
+                    ((0, 0), (1, 64), (1, 2), (1, 3), (1, 4)) if n <= 32 else
+                    ((0, 0), (1, 64), (1, 2), (1, 3)))
         for jit, bs in variants:
             ra.lib.check(set_option(b'jit', jit))
             if n <= 4:
@@ -589,7 +591,7 @@ def test_tree_specialised_kernel_is_bit_identical(ra, n):
                 ra.lib.check(set_option(b'jit', -1))
                 ra.lib.check(set_option(b'jit_block_sites', 0))
                 os.environ.pop('RAOTEH_JIT_TILES', None)
-        assert out[0, 0][3].startswith(('prune_lane', 'prune_mfma_solo')), out[0, 0][3]
+        assert out[0, 0][3].startswith(('prune_lane', 'prune_mfma')), out[0, 0][3]
         for key in variants[1:]:
             assert out[key][3].startswith('prune_tree_jit'), out[key][3]
             np.testing.assert_array_equal(out[0, 0][0], out[key][0])
