@@ -200,8 +200,8 @@ int rt_build_schedule(int64_t nnodes, const int64_t *tree_csr_indices,
 /* Process-wide options: "force_generic" (0/1) routes every later
  * rt_sites_create to the generic fallback kernel.  "jit" (-1 automatic, 0
  * never, 1 always): rt_sites_create compiles (hiprtc, once per distinct tree
- * and set of observed nodes) a pruning kernel specialised for the tree when
- * n <= 4; automatic = batches of at least 16 384 sites.  Results are
+ * and set of observed nodes) a pruning kernel specialised for the tree (n <=
+ * 64); automatic = batches of at least 65 536 / n sites.  Results are
  * bit-identical with and without it.  "jit_block_sites" (0 automatic, 1..64):
  * sites per wave of those kernels (automatic balances the waves over the CUs). */
 int rt_set_option(const char *key, int64_t value);

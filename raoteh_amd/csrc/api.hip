@@ -532,9 +532,9 @@ extern "C" int rt_model_schedule_depth(const rt_model *m)
 static const int RT_FAST_MAX_DEPTH = 16;   // LDS accumulator stack of the fast kernels
 static int g_force_generic = 0;
 // tree-specialised kernels (jit.hip): -1 = automatic (batches of at least
-// RT_JIT_MIN_SITES sites), 0 = never, 1 = always (lane family only)
+// RT_JIT_MIN_WORK site-states), 0 = never, 1 = always
 static int g_jit = -1;
-static const int64_t RT_JIT_MIN_SITES = 16384;
+static const int64_t RT_JIT_MIN_WORK = 65536;
 static int g_jit_block_sites = 0;    // 0 = automatic (see sites_jit)
 
 extern "C" int rt_set_option(const char *key, int64_t value)
@@ -727,7 +727,9 @@ static int sites_jit(rt_sites *s, bool generic)
     int want = g_jit;
     if (const char *v = getenv("RAOTEH_JIT")) want = atoi(v);
     const bool forced = want > 0;
-    if (want < 0) want = s->nsites >= RT_JIT_MIN_SITES;
+    // automatic: enough work per batch to be worth a second or two of compilation
+    // (16 384 sites at 4 states, 1 075 at 61)
+    if (want < 0) want = s->nsites * s->model->n >= RT_JIT_MIN_WORK;
     if (!want || generic) return RT_OK;
     // straight-line code: keep it inside the instruction cache's reach
     if (s->ops.size() > 1024) return RT_OK;

@@ -196,7 +196,7 @@ def test_tree_specialised_source_is_generated_on_the_host():
 
 
 def test_tree_specialised_mfma_source_is_generated_on_the_host(monkeypatch):
-    """MFMA family (4 < n <= 32): NT * KS MFMAs per step and tile, T tiles per
+    """MFMA families: 4 < n <= 32: NT * KS MFMAs per step and tile, T tiles per
     wave, one A-fragment load per (step, row tile, k-pair) whatever T is."""
     import ctypes
     import re
@@ -219,7 +219,21 @@ def test_tree_specialised_mfma_source_is_generated_on_the_host(monkeypatch):
         assert src.count('__builtin_amdgcn_mfma_f64_16x16x4f64') == steps * nt * ks * tiles
         assert len(re.findall(r'const rt_d2 A\d+_\d+_\d+ = ag\[', src)) == steps * nt * kp
         assert len(re.findall(r'const rt_d2 o\d+_\d+_\d+ = g\d+\[', src)) == len(obs) * kp * tiles
+    # 32 < n <= 64: split-M family, NT waves share T tiles; wave m owns KS MFMAs per
+    # step and tile and loads only its own slice of P_e (KP pairs per step)
+    for n, tiles in ((33, 1), (61, 2)):
+        monkeypatch.setenv('RAOTEH_JIT_TILES', str(tiles))
+        _lib.check(_lib.lib().rt_jit_source(
+            ta.nnodes, ta.indices.ctypes.data_as(p64), ta.indptr.ctypes.data_as(p64),
+            n, len(obs), obs.ctypes.data_as(p64), 1, buf, len(buf)))
+        src = buf.value.decode()
+        ks = (n + 3) // 4
+        kp = (ks + 1) // 2
+        steps = ta.nnodes - 1
+        assert src.count('__builtin_amdgcn_mfma_f64_16x16x4f64') == steps * ks * tiles
+        assert len(re.findall(r'const rt_d2 A\d+_\d+ = ag\[', src)) == steps * kp
+        assert src.count('__syncthreads()') == steps + 1      # one per step + the root's
     rc = _lib.lib().rt_jit_source(
         ta.nnodes, ta.indices.ctypes.data_as(p64), ta.indptr.ctypes.data_as(p64),
-        33, len(obs), obs.ctypes.data_as(p64), 2, buf, len(buf))
+        65, len(obs), obs.ctypes.data_as(p64), 2, buf, len(buf))
     assert rc < 0
