@@ -556,9 +556,10 @@ extern "C" int rt_sites_destroy(rt_sites *s)
     if (!s) return RT_OK;
     hipSetDevice(s->model->ctx->device);
     hipStreamSynchronize(s->model->ctx->stream);
+    // an all-reduce of this batch's totals may still be in flight on the comm stream
     hipFree(s->d_ops); hipFree(s->d_lane_ops); hipFree(s->d_obs); hipFree(s->d_loglik); hipFree(s->d_status);
-    hipFree(s->d_partial); hipFree(s->d_totals); hipFree(s->d_scratch);
     if (s->model->ctx->comm_stream) hipStreamSynchronize(s->model->ctx->comm_stream);
+    hipFree(s->d_partial); hipFree(s->d_totals); hipFree(s->d_scratch);
     if (s->ev_reduced) hipEventDestroy(s->ev_reduced);
     if (s->ev_comm_done) hipEventDestroy(s->ev_comm_done);
     delete s;
