@@ -309,18 +309,31 @@ expm_kernel(int n, const double *__restrict__ Q, const int *__restrict__ qidx,
         // (exponent + 15 mantissa bits: partial pivoting does not need more) with
         // 63 - lane in the low 6 bits, so one unsigned max yields the row too
         // (ties -> lowest row).
-        const unsigned hi = (unsigned)(__double_as_longlong(fabs(cb[lane])) >> 32);
+        const double cv = cb[lane];
+        // this thread's rows of column k (for the multipliers below): requested now,
+        // used after the barrier
+        double ck[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) ck[a] = cb[ri + 16 * a];
+        const unsigned hi = (unsigned)(__double_as_longlong(fabs(cv)) >> 32);
         unsigned key = used ? 0u : ((hi & ~63u) | (63u - (unsigned)lane));
+        // every lane inverts its own candidate while the scan runs; the winner's
+        // value and reciprocal then come out of registers (v_readlane), not LDS
+        const double rc = 1.0 / cv;
         key = wave_umax_dpp(key);
         const int pr = 63 - (int)(key & 63u);
-        const double pvt = cb[pr];
+        const double pvt = __longlong_as_double(
+            ((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(cv) >> 32), pr) << 32) |
+            (unsigned)__builtin_amdgcn_readlane((int)__double_as_longlong(cv), pr));
         if ((key & ~63u) == 0u || !(fabs(pvt) > 0.0) || !(fabs(pvt) < 1e308 * 10.0)) {
             // zero / denormal column, or inf / NaN: wave-uniform
             if (tid == 0) ibuf[2] = 1;
             break;
         }
         if (lane == pr) used = true;
-        const double rinv = 1.0 / pvt;
+        const double rinv = __longlong_as_double(
+            ((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(rc) >> 32), pr) << 32) |
+            (unsigned)__builtin_amdgcn_readlane((int)__double_as_longlong(rc), pr));
         if (tid == 0) { dinv[pr] = rinv; kof[pr] = k; }
         // pivot-row owners publish their 8 columns
         if (ri == (pr & 15)) {
@@ -349,7 +362,7 @@ expm_kernel(int n, const double *__restrict__ Q, const int *__restrict__ qidx,
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const int i = ri + 16 * a;
-            f[a] = (i == pr || i >= n) ? 0.0 : cb[i] * rinv;
+            f[a] = (i == pr || i >= n) ? 0.0 : ck[a] * rinv;
         }
 #pragma unroll
         for (int bb = 0; bb < 8; ++bb) {
