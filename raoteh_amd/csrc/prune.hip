@@ -448,6 +448,9 @@ prune_lane_kernel(const double *__restrict__ Pord,   // [nops][N][N]
 // ---------------------------------------------------------------------------
 
 // B site blocks per wave (see LaneCtx), WPB waves per workgroup.
+// cache policy of the leaf-vector stream: non-temporal (read exactly once)
+#define RT_AUX_NT 2
+
 template <int N, int R, int B, int WPB>
 __global__ void __launch_bounds__(64 * WPB)
 prune_lanedma_kernel(const double *__restrict__ Pord,   // [nrec][N][N]
@@ -496,7 +499,7 @@ prune_lanedma_kernel(const double *__restrict__ Pord,   // [nrec][N][N]
             for (int j = 0; j < IPS; ++j)
                 __builtin_amdgcn_global_load_lds(
                     (glb_void *)(g + b * bstride + (size_t)kk * SLOT + j * 1024),
-                    (lds_void *)(ring + (b * R + r) * SLOT + j * 1024), 16, 0, 0);
+                    (lds_void *)(ring + (b * R + r) * SLOT + j * 1024), 16, 0, RT_AUX_NT);
     };
     // prologue: fill the ring
 #pragma unroll
