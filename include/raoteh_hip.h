@@ -223,6 +223,10 @@ int rt_sites_destroy(rt_sites *sites);
 int64_t rt_sites_device_bytes(const rt_sites *sites);
 
 int rt_prune(rt_model *model, rt_sites *sites);
+/* One evaluation of the repeated-evaluation loop (optimiser / MCMC iteration) in
+ * one call: rt_model_recompute_transitions (if recompute_transitions != 0) +
+ * rt_prune.                                                                   */
+int rt_step(rt_model *model, rt_sites *sites, int recompute_transitions);
 /* loglik f64[nsites] (-inf where status has RT_SITE_ZERO_PROB),
  * status int32[nsites]; either may be NULL.                                 */
 int rt_sites_get_logliks(rt_sites *sites, double *loglik, int32_t *status);
@@ -238,8 +242,13 @@ int rt_comm_unique_id(unsigned char id[128]);
 int rt_comm_init(rt_ctx *ctx, int nranks, int rank, const unsigned char id[128]);
 int rt_comm_destroy(rt_ctx *ctx);
 /* ncclAllReduce(sum, f64, 3) of the totals of `sites`, in place on the
- * device, on the context stream.                                            */
+ * device, asynchronously on the context's communication stream (the next
+ * rt_prune of the batch and rt_sites_get_totals wait for it).               */
 int rt_allreduce_totals(rt_ctx *ctx, rt_sites *sites);
+/* The totals of `count` batches in one collective (3 * count doubles) when the
+ * batches were created one after the other (their totals are then neighbours in
+ * device memory), else one collective each.                                  */
+int rt_allreduce_totals_group(rt_ctx *ctx, rt_sites **sites, int64_t count);
 
 #ifdef __cplusplus
 }

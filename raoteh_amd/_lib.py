@@ -96,12 +96,14 @@ SIGNATURES = {
     'rt_sites_destroy': (c_int, [c_void_p]),
     'rt_sites_device_bytes': (c_int64, [c_void_p]),
     'rt_prune': (c_int, [c_void_p, c_void_p]),
+    'rt_step': (c_int, [c_void_p, c_void_p, c_int]),
     'rt_sites_get_logliks': (c_int, [c_void_p, _p_f64, _p_i32]),
     'rt_sites_get_totals': (c_int, [c_void_p, _p_f64]),
     'rt_comm_unique_id': (c_int, [POINTER(c_ubyte)]),
     'rt_comm_init': (c_int, [c_void_p, c_int, c_int, POINTER(c_ubyte)]),
     'rt_comm_destroy': (c_int, [c_void_p]),
     'rt_allreduce_totals': (c_int, [c_void_p, c_void_p]),
+    'rt_allreduce_totals_group': (c_int, [c_void_p, POINTER(c_void_p), c_int64]),
 }
 
 _lib = None

@@ -104,25 +104,67 @@ extern "C" int rt_comm_destroy(rt_ctx *ctx)
     ctx->comm = nullptr;
     if (ctx->comm_stream) hipStreamDestroy(ctx->comm_stream);
     ctx->comm_stream = nullptr;
+    if (ctx->ev_reduced) {
+        hipEventDestroy(ctx->ev_reduced);
+        ctx->ev_reduced = nullptr;
+        for (auto &e : ctx->comm_events) { hipEventDestroy(e); e = nullptr; }
+    }
+    return RT_OK;
+}
+
+// The totals of `count` site batches in ONE collective.  The batches' slots in the
+// context's totals arena must be consecutive and ascending (batches created one
+// after the other are); otherwise every batch gets its own collective.  Cost of the
+// stream bookkeeping (one event on the compute stream, a wait and an event on the
+// comm stream): 10.7 us per call on an MI355X whatever the payload -- a quarter of a
+// C2 step, which is why a ring of K rotating batches reduces once per K steps.
+extern "C" int rt_allreduce_totals_group(rt_ctx *ctx, rt_sites **sites, int64_t count)
+{
+    RT_REQUIRE(ctx && sites && count >= 1, "bad arguments");
+    RT_REQUIRE(ctx->comm, "rt_comm_init has not been called");
+    for (int64_t k = 0; k < count; ++k) {
+        RT_REQUIRE(sites[k] && sites[k]->model->ctx == ctx, "batch %lld: wrong context",
+                   (long long)k);
+    }
+    RT_HIP(hipSetDevice(ctx->device));
+    if (!ctx->ev_reduced) {
+        RT_HIP(hipEventCreateWithFlags(&ctx->ev_reduced, hipEventDisableTiming));
+        for (auto &e : ctx->comm_events)
+            RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    bool contiguous = sites[0]->totals_slot >= 0;
+    for (int64_t k = 1; k < count && contiguous; ++k)
+        contiguous = sites[k]->totals_slot == sites[0]->totals_slot + (int)k;
+    // comm stream: wait for the totals (compute stream), reduce them in place, signal
+    RT_HIP(hipEventRecord(ctx->ev_reduced, ctx->stream));
+    RT_HIP(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_reduced, 0));
+    if (contiguous) {
+        const int rc = g_rccl.AllReduce(sites[0]->d_totals, sites[0]->d_totals,
+                                        (size_t)(3 * count), NCCL_FLOAT64, NCCL_SUM,
+                                        (nccl_comm)ctx->comm, ctx->comm_stream);
+        if (rc != 0) return rccl_fail("ncclAllReduce", rc);
+    } else {
+        for (int64_t k = 0; k < count; ++k) {
+            const int rc = g_rccl.AllReduce(sites[k]->d_totals, sites[k]->d_totals, 3,
+                                            NCCL_FLOAT64, NCCL_SUM, (nccl_comm)ctx->comm,
+                                            ctx->comm_stream);
+            if (rc != 0) return rccl_fail("ncclAllReduce", rc);
+        }
+    }
+    hipEvent_t done = ctx->comm_events[ctx->comm_event_next];
+    ctx->comm_event_next = (ctx->comm_event_next + 1) % 8;
+    RT_HIP(hipEventRecord(done, ctx->comm_stream));
+    for (int64_t k = 0; k < count; ++k) {
+        // a later record of the same event only strengthens what it stands for (the
+        // comm stream is in order)
+        sites[k]->ev_comm_done = done;
+        sites[k]->comm_pending = true;
+    }
     return RT_OK;
 }
 
 extern "C" int rt_allreduce_totals(rt_ctx *ctx, rt_sites *s)
 {
     RT_REQUIRE(ctx && s, "null pointer");
-    RT_REQUIRE(ctx->comm, "rt_comm_init has not been called");
-    RT_HIP(hipSetDevice(ctx->device));
-    if (!s->ev_reduced) {
-        RT_HIP(hipEventCreateWithFlags(&s->ev_reduced, hipEventDisableTiming));
-        RT_HIP(hipEventCreateWithFlags(&s->ev_comm_done, hipEventDisableTiming));
-    }
-    // comm stream: wait for this batch's totals, reduce them in place, signal
-    RT_HIP(hipEventRecord(s->ev_reduced, ctx->stream));
-    RT_HIP(hipStreamWaitEvent(ctx->comm_stream, s->ev_reduced, 0));
-    const int rc = g_rccl.AllReduce(s->d_totals, s->d_totals, 3, NCCL_FLOAT64, NCCL_SUM,
-                                    (nccl_comm)ctx->comm, ctx->comm_stream);
-    if (rc != 0) return rccl_fail("ncclAllReduce", rc);
-    RT_HIP(hipEventRecord(s->ev_comm_done, ctx->comm_stream));
-    s->comm_pending = true;
-    return RT_OK;
+    return rt_allreduce_totals_group(ctx, &s, 1);
 }

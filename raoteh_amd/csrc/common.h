@@ -53,6 +53,8 @@ struct rt_timing_slot {
     const char *name = "";
 };
 
+static const int RT_TOTALS_SLOTS = 4096;   // site batches per context sharing the arena
+
 struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -62,6 +64,13 @@ struct rt_ctx {
     rt_timing_slot slots[RT_K_COUNT];
     // events of the launch being timed (rt_time_begin .. rt_time_end), else null
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    // totals of every site batch of this context live in one arena ([slot][3] doubles)
+    // so that the totals of several batches can be all-reduced by ONE collective
+    double *d_totals_arena = nullptr;
+    std::vector<int> totals_free;          // free slots, highest index last popped first
+    hipEvent_t ev_reduced = nullptr;       // compute stream: totals of a group written
+    hipEvent_t comm_events[8] = {};        // comm stream: a collective finished (ring)
+    int comm_event_next = 0;
     void *comm = nullptr;          // ncclComm_t
     hipStream_t comm_stream = nullptr;   // collectives overlap the next step's kernels
     void *rccl = nullptr;          // dlopen handle
@@ -130,9 +139,9 @@ struct rt_sites {
     int32_t *d_status = nullptr;
     double *d_partial = nullptr;    // [npartials][2] (sum, nzero)
     int64_t npartials = 0;
-    double *d_totals = nullptr;     // [3]
-    hipEvent_t ev_reduced = nullptr;    // totals written (compute stream)
-    hipEvent_t ev_comm_done = nullptr;  // all-reduce of the totals finished (comm stream)
+    double *d_totals = nullptr;     // [3]: a slot of the context's arena (or its own)
+    int totals_slot = -1;           // arena slot, -1: d_totals is its own allocation
+    hipEvent_t ev_comm_done = nullptr;  // ctx-owned: the collective that last touched the totals
     bool comm_pending = false;
     void *jit_fn = nullptr;         // hipFunction_t of the tree-specialised kernel (jit.hip)
     int jit_prefetch = 0;           // its prefetch distance (stream positions)
@@ -156,8 +165,13 @@ int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
 // end (what rocprofv3's kernel trace reports), not with the stream position of an
 // event record, which adds 2-3 us per pair.  Null events: a plain launch.
 #define RT_LAUNCH_TIMED(ctx, kern, grid, block, lds, ...)                               \
-    hipExtLaunchKernelGGL(kern, grid, block, lds, (ctx)->stream, (ctx)->ev_start,      \
-                          (ctx)->ev_stop, 0, __VA_ARGS__)
+    do {                                                                                \
+        if ((ctx)->ev_start)                                                            \
+            hipExtLaunchKernelGGL(kern, grid, block, lds, (ctx)->stream,                \
+                                  (ctx)->ev_start, (ctx)->ev_stop, 0, __VA_ARGS__);     \
+        else                                                                            \
+            hipLaunchKernelGGL(kern, grid, block, lds, (ctx)->stream, __VA_ARGS__);     \
+    } while (0)
 int rt_launch_pfrag(rt_model *m);
 int rt_launch_prune(rt_model *m, rt_sites *s);
 // jit.hip

@@ -1482,8 +1482,11 @@ int rt_launch_prune(rt_model *m, rt_sites *s)
 
     if (s->comm_pending) {
         // the previous all-reduce of this batch's totals must have finished before
-        // the totals are rewritten
-        RT_HIP(hipStreamWaitEvent(ctx->stream, s->ev_comm_done, 0));
+        // the totals are rewritten; usually it has, long ago, and a wait packet on
+        // the compute stream (a few us of dispatch latency each) is not needed
+        if (ctx->comm && hipEventQuery(s->ev_comm_done) != hipSuccess)
+            RT_HIP(hipStreamWaitEvent(ctx->stream, s->ev_comm_done, 0));
+        (void)hipGetLastError();             // hipErrorNotReady is not an error
         s->comm_pending = false;
     }
     rt_time_begin(ctx, RT_K_REDUCE, "reduce_partials", &ev);

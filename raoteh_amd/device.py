@@ -355,8 +355,19 @@ class TreeModel(object):
         """Asynchronous: upward pass + root reduce + batch sum on the device."""
         _lib.check(_lib.lib().rt_prune(self._h, batch._h))
 
+    def step(self, batch, recompute_transitions=True):
+        """One iteration of a repeated-evaluation loop in one call (rt_step):
+        per-edge expm from the resident rates (optional) + prune; asynchronous."""
+        _lib.check(_lib.lib().rt_step(self._h, batch._h,
+                                      1 if recompute_transitions else 0))
+
     def allreduce(self, batch):
         _lib.check(_lib.lib().rt_allreduce_totals(self.ctx._h, batch._h))
+
+    def allreduce_group(self, batches):
+        """The totals of several batches in one collective (rt_allreduce_totals_group)."""
+        arr = (c_void_p * len(batches))(*[b._h for b in batches])
+        _lib.check(_lib.lib().rt_allreduce_totals_group(self.ctx._h, arr, len(batches)))
 
     def fetch_log_likelihoods(self, batch):
         ll = np.empty(batch.nsites, dtype=np.float64)
