@@ -206,6 +206,9 @@ class Context(object):
         buf = (ctypes.c_ubyte * 128).from_buffer_copy(uid)
         _lib.check(_lib.lib().rt_comm_init(self._h, int(nranks), int(rank), buf))
 
+    def comm_destroy(self):
+        _lib.check(_lib.lib().rt_comm_destroy(self._h))
+
 
 _contexts = {}
 

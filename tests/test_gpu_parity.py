@@ -739,3 +739,47 @@ def test_timing_and_clone(ra):
     assert cnt == 1 and name.startswith('expm')
     ctx.set_timing(False)
     assert batch.device_bytes == 32 * 64 * 64 * 4 * 8
+
+
+def test_rccl_reduce_single_rank(ra):
+    """The N > 1 data path on one GPU: a 1-rank RCCL communicator; per-batch and
+    grouped all-reduce of the totals (csrc/comm.hip) leave a single rank's totals
+    unchanged, in neighbouring and in scattered slots of the totals arena, and a
+    batch can be pruned again right after."""
+    cfg = ra.synth.make_config('c2', nsites=700)
+    model = ra.device.TreeModel(cfg['T'], cfg['root'], cfg['nstates'])
+    model.set_rates(Q_default=cfg['Q_default'])
+    model.set_root_distn(cfg['root_distn'])
+    states = cfg['leaf_states'].astype(np.uint8)
+    first = model.upload_sites(cfg['leaves'], states, kind='state')
+    batches = [first] + [first.clone() for _ in range(4)]
+    want = []
+    for b in batches:
+        model.step(b)
+        want.append(model.fetch_totals(b))
+    assert want[0][2] == 700 and want[0][1] == 0
+    ctx = ra.ctx
+    ctx.comm_init(1, 0, ra.device.Context.comm_unique_id())
+    try:
+        for b in batches:
+            model.step(b)
+        model.allreduce(batches[0])
+        model.allreduce_group(batches[1:])             # neighbouring slots: one collective
+        for b, w in zip(batches, want):
+            np.testing.assert_array_equal(model.fetch_totals(b), w)
+        del batches[2]                                  # leaves a hole in the arena
+        import gc
+        gc.collect()
+        extra = first.clone()                           # reuses the freed slot
+        group = [batches[3], extra, batches[0]]         # not ascending neighbours
+        for b in group:
+            model.step(b)
+        model.allreduce_group(group)
+        for b in group:
+            model.step(b, recompute_transitions=False)  # waits for the collective
+            np.testing.assert_array_equal(model.fetch_totals(b), want[0])
+    finally:
+        ctx.comm_destroy()
+    # after the communicator is gone the batches still work
+    model.step(first)
+    np.testing.assert_array_equal(model.fetch_totals(first), want[0])
