@@ -96,19 +96,39 @@ def _build(T, root, nstates, obs_nodes, data, kind, root_distn, Q_default,
 
 
 def get_log_likelihoods(T, root, nstates, obs_nodes, data, kind='dense',
-                        root_distn=None, Q_default=None, model=None):
+                        root_distn=None, Q_default=None, model=None,
+                        compress=False):
     """Per-site log-likelihoods for a batch of independent sites sharing
     (T, Q, branch lengths).  Returns (loglik f64[nsites], status int32[nsites]);
     status 1 marks a zero-probability site (loglik = -inf), for which the
-    reference would raise StructuralZeroProb."""
+    reference would raise StructuralZeroProb.  compress=True evaluates every
+    distinct site pattern once (alignment columns repeat a lot) and copies the
+    result to its duplicates."""
+    if compress:
+        from .io import compress_patterns
+        unique, inverse, _ = compress_patterns(data)
+        ll, st = get_log_likelihoods(T, root, nstates, obs_nodes, unique, kind=kind,
+                                     root_distn=root_distn, Q_default=Q_default,
+                                     model=model)
+        return ll[inverse], st[inverse]
     model, batch = _build(T, root, nstates, obs_nodes, data, kind, root_distn,
                           Q_default, model)
     return model.log_likelihoods(batch)
 
 
 def get_total_log_likelihood(T, root, nstates, obs_nodes, data, kind='dense',
-                             root_distn=None, Q_default=None, model=None):
-    """Sum over sites of the log-likelihood (examples/p53/p53.py:98-99)."""
+                             root_distn=None, Q_default=None, model=None,
+                             compress=False):
+    """Sum over sites of the log-likelihood (examples/p53/p53.py:98-99).  With
+    compress=True: sum over distinct patterns of count * log-likelihood (the sum
+    is taken on the host; zero-probability patterns give -inf)."""
+    if compress:
+        from .io import compress_patterns
+        unique, _, counts = compress_patterns(data)
+        ll, _ = get_log_likelihoods(T, root, nstates, obs_nodes, unique, kind=kind,
+                                    root_distn=root_distn, Q_default=Q_default,
+                                    model=model)
+        return float(np.dot(counts, ll))
     model, batch = _build(T, root, nstates, obs_nodes, data, kind, root_distn,
                           Q_default, model)
     return model.total_log_likelihood(batch)[0]

@@ -783,3 +783,38 @@ def test_rccl_reduce_single_rank(ra):
     # after the communicator is gone the batches still work
     model.step(first)
     np.testing.assert_array_equal(model.fetch_totals(first), want[0])
+
+
+def test_p53_alignment_from_files(ra):
+    """The reference's p53 example (examples/p53/p53.py:62-100) end to end: PHYLIP
+    alignment + newick tree + genetic code -> MG94 -> per-column log-likelihoods,
+    against the oracle; with and without site-pattern compression."""
+    from test_io_cpu import p53_problem
+    T, root, leaves, states, Q, distn, _, _ = p53_problem()
+    pre, idx, ptr, esd = orc.get_expm_augmented_transitions(T, root, 61, Q_default=Q)
+    dense = np.zeros((393, 25, 61))
+    ii, kk = np.indices(states.shape)
+    dense[ii, kk, states] = 1.0
+    want, wst = orc.batch_log_likelihoods(idx, ptr, esd, [pre.index(v) for v in leaves],
+                                          dense, distn)
+    ll, st = ra.mjp.get_log_likelihoods(T, root, 61, leaves, states, kind='state',
+                                        root_distn=distn, Q_default=Q)
+    np.testing.assert_array_equal(st, wst)
+    np.testing.assert_allclose(ll, want, rtol=RTOL_LL)
+    llc, stc = ra.mjp.get_log_likelihoods(T, root, 61, leaves, states, kind='state',
+                                          root_distn=distn, Q_default=Q, compress=True)
+    np.testing.assert_allclose(llc, want, rtol=RTOL_LL)
+    np.testing.assert_array_equal(stc, wst)
+    tot = ra.mjp.get_total_log_likelihood(T, root, 61, leaves, states, kind='state',
+                                          root_distn=distn, Q_default=Q)
+    totc = ra.mjp.get_total_log_likelihood(T, root, 61, leaves, states, kind='state',
+                                           root_distn=distn, Q_default=Q, compress=True)
+    assert tot == pytest.approx(-11202.4288003113, rel=1e-11)
+    assert totc == pytest.approx(tot, rel=1e-12)
+    # the reference's own single-site call on one column (p53.py:88-97)
+    col = 7
+    allowed = dict((v, set(range(61))) for v in T)
+    for leaf, s0 in zip(leaves, states[col]):
+        allowed[leaf] = {int(s0)}
+    lk = ra.mjp.get_likelihood(T, allowed, root, 61, root_distn=distn, Q_default=Q)
+    assert np.log(lk) == pytest.approx(want[col], rel=RTOL_LL)

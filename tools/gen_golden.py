@@ -453,6 +453,31 @@ def fixture_sparse_api(mods, ncases=16):
     return dict(cases=cases)
 
 
+def fixture_p53_mg94(mods):
+    """The MG94 codon rate matrix the reference's p53 example builds
+    (examples/p53/create_mg94.py:23-142 called as examples/p53/p53.py:44-47) on the
+    genetic-code table shipped with it.  networkx >= 3 dropped to_numpy_matrix,
+    which raoteh/sampler/_density.py:52 calls: the harness provides it."""
+    sys.path.insert(0, REF + '/examples/p53')
+    if not hasattr(nx, 'to_numpy_matrix'):
+        nx.to_numpy_matrix = lambda G, **kw: np.asmatrix(nx.to_numpy_array(G, **kw))
+    import create_mg94
+    from raoteh_amd import io as rio
+    here = os.path.join(os.path.dirname(HERE), 'tests', 'golden', 'p53')
+    code = rio.read_genetic_code(os.path.join(here, 'universal.code.txt'))
+    nt = dict(A=0.25039, C=0.30126, G=0.25952, T=0.18883)
+    kappa, omega = 3.17632, 0.21925
+    Qnx, distn, _, _ = create_mg94.create_mg94(
+        nt['A'], nt['C'], nt['G'], nt['T'], kappa, omega, code,
+        target_expected_rate=1.0)
+    n = len(code)
+    Q = np.zeros((n, n))
+    for a, b, d in Qnx.edges(data=True):
+        Q[a, b] = d['weight']
+    return dict(Q_offdiagonal=Q.tolist(), distn=[float(distn[i]) for i in range(n)],
+                kappa=kappa, omega=omega, nt=nt)
+
+
 def fixture_config(mods, name, nsites, with_pmap=False):
     """A BASELINE.json-shaped configuration evaluated by the reference path:
     E x scipy.linalg.expm + _mcx.get_likelihood (type-x observations, C1-C3)
@@ -558,6 +583,7 @@ def main():
         jukes_cantor=fixture_jukes_cantor(mods),
         random_sparse=fixture_random_sparse(mods),
         sparse_api=fixture_sparse_api(mods),
+        p53_mg94=fixture_p53_mg94(mods),
         expm=fixture_expm(mods),
         config_c1=fixture_config(mods, 'c1', 4, with_pmap=True),
         config_c2=fixture_config(mods, 'c2', 6),
