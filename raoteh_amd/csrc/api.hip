@@ -760,8 +760,10 @@ static int sites_jit(rt_sites *s, bool generic)
     // (16 384 sites at 4 states, 1 075 at 61)
     if (want < 0) want = s->nsites * s->model->n >= RT_JIT_MIN_WORK;
     if (!want || generic) return RT_OK;
-    // straight-line code: keep it inside the instruction cache's reach
-    if (s->ops.size() > 1024) return RT_OK;
+    // straight-line code, one block of arithmetic per step and tile: bound what
+    // hiprtc is asked to compile (64 leaves x 4 states: 1.7 s; 512 leaves: 11 s)
+    if (!forced && s->ops.size() > 600) return RT_OK;
+    if (s->ops.size() > 2048) return RT_OK;
     if (s->layout == RT_LAYOUT_MFMA) {
         // one wave = T site tiles (jit.hip, MFMA family): n <= 32 only (row tiles of
         // larger matrices do not fit one wave's registers)
@@ -771,7 +773,7 @@ static int sites_jit(rt_sites *s, bool generic)
             // (one workgroup per CU): worth it once the batch is several rounds deep
             if (s->model->n > 64) return RT_OK;
             const int64_t ntiles = (s->nsites + 15) / 16;
-            int T = ntiles >= 2048 ? 2 : 1;
+            int T = (ntiles >= 2048 && s->ops.size() <= 300) ? 2 : 1;
             if (const char *v = getenv("RAOTEH_JIT_TILES")) T = std::min(3, std::max(1, atoi(v)));
             int D = 1, LA = 1;
             if (const char *v = getenv("RAOTEH_JIT_PREFETCH")) D = std::max(1, atoi(v));
@@ -799,7 +801,8 @@ static int sites_jit(rt_sites *s, bool generic)
         auto regs = [&](int t) {
             return 2 * (s->model->max_depth * t * KS + 2 * NT * KS + 3 * t * KS + 4 * t * NT) + 48;
         };
-        while (T > 1 && regs(T) > 480) --T;
+        // up to two tiles: two waves per SIMD, 256 registers each; more: the whole file
+        while (T > 1 && (regs(T) > (T <= 2 ? 240 : 480) || (int64_t)s->ops.size() * T > 600)) --T;
         if (const char *v = getenv("RAOTEH_JIT_TILES")) T = std::min(4, std::max(1, atoi(v)));
         int D = 2, LA = 1;
         if (const char *v = getenv("RAOTEH_JIT_PREFETCH")) D = std::max(1, atoi(v));
@@ -826,7 +829,21 @@ static int sites_jit(rt_sites *s, bool generic)
     // 1 563 blocks of 64 would be 6 or 7 waves per CU; 1 792 waves of 56 sites are
     // 7 everywhere: 41 -> 39 us).  Waves per workgroup: 1 (each wave stages its own
     // copy of the P table; sharing one per CU, RAOTEH_JIT_WAVES=7, measured the same).
+    {
+        // registers: pending accumulators + P records in flight + leaf vectors in flight
+        const int64_t n = s->model->n, np = (n + 1) & ~1ll;
+        const int64_t regs = 2 * (s->model->max_depth * n + (1 + LA) * n * n + (D + 1) * np) + 40;
+        if (!forced && regs > 250) return RT_OK;    // would spill: the interpreter is faster
+    }
+    // A tree whose P table is large gets workgroups of 2, 4 or 8 waves sharing one copy,
+    // so that the 8 waves of a CU still fit its 160 KB of LDS; beyond that the
+    // interpreter kernels run.
     int S = 64, WG = 1;
+    {
+        const int64_t ptab = (int64_t)s->ops.size() * s->model->n * s->model->n * 8;
+        while (WG < 8 && (8 / WG) * ptab > 150 * 1024) WG *= 2;
+        if (ptab > 150 * 1024) return RT_OK;
+    }
     const int64_t nb64 = (s->nsites + 63) / 64;
     if (nb64 >= 256 && nb64 <= 2048) {
         const int64_t nw = (nb64 + 255) / 256 * 256;
