@@ -818,3 +818,38 @@ def test_p53_alignment_from_files(ra):
         allowed[leaf] = {int(s0)}
     lk = ra.mjp.get_likelihood(T, allowed, root, 61, root_distn=distn, Q_default=Q)
     assert np.log(lk) == pytest.approx(want[col], rel=RTOL_LL)
+
+
+def test_tree_specialised_kernel_large_tree(ra):
+    """A 256-leaf tree: the step-ordered P table (65 KB at 4 states) no longer fits
+    one copy per wave, so the tree-specialised kernel shares it between the waves of
+    a workgroup; results stay bit-identical with the interpreter kernel."""
+    set_option = ra.lib.lib().rt_set_option
+    T, root, leaves = ra.synth.balanced_tree(256, seed=5)
+    Q, pi = ra.synth.hky85()
+    rng = np.random.RandomState(77)
+    states = rng.randint(0, 4, size=(3000, 256)).astype(np.uint8)
+    states[rng.uniform(size=states.shape) < 0.05] = 255
+    out = {}
+    for jit in (0, 1):
+        ra.lib.check(set_option(b'jit', jit))
+        try:
+            out[jit] = ra.mjp.get_log_likelihoods(T, root, 4, leaves, states, kind='state',
+                                                  root_distn=pi, Q_default=Q)
+            out[jit] += (ra.ctx.kernel_time(1)[2],)
+        finally:
+            ra.lib.check(set_option(b'jit', -1))
+    assert out[0][2].startswith('prune_lane') and out[1][2].startswith('prune_tree_jit')
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    # and against the oracle on a few sites
+    pre, idx, ptr, esd = orc.get_expm_augmented_transitions(T, root, 4, Q_default=Q)
+    dense = np.ones((40, 256, 4))
+    sub = states[:40]
+    obs = sub != 255
+    dense[obs] = 0.0
+    ii, kk = np.nonzero(obs)
+    dense[ii, kk, sub[ii, kk]] = 1.0
+    want, _ = orc.batch_log_likelihoods(idx, ptr, esd, [pre.index(v) for v in leaves],
+                                        dense, pi)
+    np.testing.assert_allclose(out[1][0][:40], want, rtol=RTOL_LL)
