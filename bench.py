@@ -118,8 +118,8 @@ def cpu_baseline(cfg, gpu_ll, budget_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=400)
+    ap.add_argument('--warmup', type=int, default=40)
     ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
     ap.add_argument('--sites', type=int, default=None,
                     help='sites per GPU (default: the configuration size)')
