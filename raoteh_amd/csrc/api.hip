@@ -778,12 +778,16 @@ static int sites_jit(rt_sites *s, bool generic)
             int D = 1, LA = 1;
             if (const char *v = getenv("RAOTEH_JIT_PREFETCH")) D = std::max(1, atoi(v));
             if (const char *v = getenv("RAOTEH_JIT_LOOKAHEAD")) LA = std::max(1, atoi(v));
-            const std::string src =
-                rt_jit_mfma_split_source(s->ops, (int)s->model->n, (int)s->nobs, T, D, LA);
             s->jit_prefetch = D;
-            const int rc = rt_jit_get(s->model->ctx, src, &s->jit_fn, true);
-            if (rc != RT_OK && !forced) {
-                s->jit_fn = nullptr;
+            int rc = RT_ERR_UNSUPPORTED;
+            for (; T >= 1 && rc == RT_ERR_UNSUPPORTED; --T) {     // fewer tiles if it spills
+                const std::string src =
+                    rt_jit_mfma_split_source(s->ops, (int)s->model->n, (int)s->nobs, T, D, LA);
+                rc = rt_jit_get(s->model->ctx, src, &s->jit_fn, true);
+            }
+            ++T;
+            if (rc != RT_OK && (!forced || rc == RT_ERR_UNSUPPORTED)) {
+                s->jit_fn = nullptr;           // the interpreter kernel runs
                 return RT_OK;
             }
             if (rc == RT_OK) {
@@ -807,12 +811,16 @@ static int sites_jit(rt_sites *s, bool generic)
         int D = 2, LA = 1;
         if (const char *v = getenv("RAOTEH_JIT_PREFETCH")) D = std::max(1, atoi(v));
         if (const char *v = getenv("RAOTEH_JIT_LOOKAHEAD")) LA = std::max(1, atoi(v));
-        const std::string src =
-            rt_jit_mfma_source(s->ops, (int)s->model->n, (int)s->nobs, T, D, LA);
         s->jit_prefetch = D;
-        const int rc = rt_jit_get(s->model->ctx, src, &s->jit_fn, true);
-        if (rc != RT_OK && !forced) {
-            s->jit_fn = nullptr;
+        int rc = RT_ERR_UNSUPPORTED;
+        for (; T >= 1 && rc == RT_ERR_UNSUPPORTED; --T) {         // fewer tiles if it spills
+            const std::string src =
+                rt_jit_mfma_source(s->ops, (int)s->model->n, (int)s->nobs, T, D, LA);
+            rc = rt_jit_get(s->model->ctx, src, &s->jit_fn, true);
+        }
+        ++T;
+        if (rc != RT_OK && (!forced || rc == RT_ERR_UNSUPPORTED)) {
+            s->jit_fn = nullptr;               // the interpreter kernel runs
             return RT_OK;
         }
         if (rc == RT_OK) s->jit_tiles = T;
@@ -858,9 +866,9 @@ static int sites_jit(rt_sites *s, bool generic)
         rt_jit_lane_source(s->ops, (int)s->model->n, (int)s->nobs, D, LA, S, WG);
     s->jit_prefetch = D;
     const int rc = rt_jit_get(s->model->ctx, src, &s->jit_fn);
-    if (rc != RT_OK && !forced) {
-        // automatic mode: the interpreter kernel (prune.hip) computes the same
-        // numbers; rt_last_error() keeps the compiler's message
+    if (rc != RT_OK && (!forced || rc == RT_ERR_UNSUPPORTED)) {
+        // the interpreter kernel (prune.hip) computes the same numbers;
+        // rt_last_error() keeps the compiler's message / the rejection
         s->jit_fn = nullptr;
         return RT_OK;
     }
