@@ -10,6 +10,7 @@ is a plain re-ordering of the same f64 sums.  Masks / statuses are bit-exact.
 """
 import itertools
 import os
+import sys
 import warnings
 
 import networkx as nx
@@ -853,3 +854,17 @@ def test_tree_specialised_kernel_large_tree(ra):
     want, _ = orc.batch_log_likelihoods(idx, ptr, esd, [pre.index(v) for v in leaves],
                                         dense, pi)
     np.testing.assert_allclose(out[1][0][:40], want, rtol=RTOL_LL)
+
+
+def test_randomised_soak_short(ra, monkeypatch):
+    """A few seconds of tools/soak.py and tools/soak_passes.py (random trees, state
+    counts, encodings, tilings; specialised vs interpreter kernel bit for bit, both
+    against the oracle).  The long runs are recorded in DESIGN.md section 5."""
+    import importlib.util
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools')
+    for name, seed in (('soak', 4242), ('soak_passes', 4243)):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(tools, name + '.py'))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        monkeypatch.setattr(sys, 'argv', [name, '6', str(seed)])
+        mod.main()          # exits the process with status 1 on any mismatch
