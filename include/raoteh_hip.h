@@ -130,6 +130,14 @@ int rt_mcy_esd_get_node_to_pmap(rt_ctx *ctx, int64_t nnodes, int64_t n,
             const int64_t *tree_csr_indptr, const double *esd_transitions,
             const int64_t *state_mask, const double *obs_likelihood,
             double *subtree_probability);
+/* The three passes above in one call (the sequence _mcy_dense.py:261-291 runs:
+ * pset, set, pmap; with obs_likelihood the type-z upward pass, _mcz.py:128-163):
+ * state_mask is updated in place by the two boolean passes, subtree_probability
+ * is filled; one upload of the tree and the matrices instead of three.        */
+int rt_mcy_esd_passes(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t nsites,
+            const int64_t *tree_csr_indices, const int64_t *tree_csr_indptr,
+            const double *esd_transitions, int64_t *state_mask,
+            const double *obs_likelihood, double *subtree_probability);
 
 /* pyfelscore.mc0_esd_get_node_to_distn (_mc0_dense.py:381, _mcy_dense.py:195;
  * pure-Python twin _mc0_dense.py:446-486): downward pass, posterior marginal

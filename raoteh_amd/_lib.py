@@ -68,6 +68,9 @@ SIGNATURES = {
     'rt_mcy_esd_get_node_to_pmap': (c_int, [c_void_p, c_int64, c_int64, c_int64,
                                             _p_i64, _p_i64, _p_f64, _p_i64,
                                             _p_f64, _p_f64]),
+    'rt_mcy_esd_passes': (c_int, [c_void_p, c_int64, c_int64, c_int64,
+                                  _p_i64, _p_i64, _p_f64, _p_i64,
+                                  _p_f64, _p_f64]),
     'rt_mc0_esd_get_node_to_distn': (c_int, [c_void_p, c_int64, c_int64, c_int64,
                                              _p_i64, _p_i64, _p_f64, _p_f64,
                                              _p_f64, _p_f64, _p_i32]),

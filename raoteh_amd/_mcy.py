@@ -80,14 +80,15 @@ def get_node_to_pmap(T, root, node_to_allowed_states=None, P_default=None,
             allowed_states &= set(node_to_allowed_states[root])
         return {root: dict((s, 1.0) for s in allowed_states)}
     _check_root(T, root)
-    prob, mask = _masks(T, root, node_to_allowed_states, P_default, True)
+    prob = SparseProblem(T, root, P_default=P_default)
+    mask = prob.mask_from_allowed(node_to_allowed_states)
+    pmap = np.empty(mask.shape, dtype=np.float64)
+    # pset + set + pmap in one device call (rt_mcy_esd_passes)
+    get_context().passes(prob.ta.indices, prob.ta.indptr, prob.esd, mask, pmap)
     if node_to_set is not None:
         mine = prob.mask_to_dict(mask)
         if mine != dict((k, set(v)) for k, v in node_to_set.items()):
             raise Exception('internal error %s %s' % (mine, node_to_set))
-    pmap = np.empty(mask.shape, dtype=np.float64)
-    get_context().node_to_pmap(prob.ta.indices, prob.ta.indptr, prob.esd, mask,
-                               pmap)
     return prob.pmap_to_dict(mask, pmap)
 
 

@@ -22,12 +22,12 @@ def _define_state_mask(node_to_allowed_states, preorder_nodes, nstates):
     """raoteh/sampler/_mcy_dense.py:43-54 (KeyError for a node missing from a
     given dict is the reference's behaviour)."""
     nnodes = len(preorder_nodes)
-    all_states = set(range(nstates))
-    state_mask = np.ones((nnodes, nstates), dtype=np.int64)
-    if node_to_allowed_states is not None:
-        for na_index, na in enumerate(preorder_nodes):
-            for sa in all_states - set(node_to_allowed_states[na]):
-                state_mask[na_index, sa] = 0
+    if node_to_allowed_states is None:
+        return np.ones((nnodes, nstates), dtype=np.int64)
+    state_mask = np.zeros((nnodes, nstates), dtype=np.int64)
+    for na_index, na in enumerate(preorder_nodes):
+        allowed = [sa for sa in node_to_allowed_states[na] if 0 <= sa < nstates]
+        state_mask[na_index, allowed] = 1
     return state_mask
 
 
@@ -38,12 +38,9 @@ def _check_root(T, root):
 
 def _run_passes(ta, esd, state_mask, obs_likelihood=None):
     """The pass sequence of _mcy_dense.py:261-291 on the device."""
-    ctx = get_context()
-    ctx.node_to_pset(ta.indices, ta.indptr, esd, state_mask)
-    ctx.node_to_set(ta.indices, ta.indptr, esd, state_mask)
     pmap = np.empty(state_mask.shape, dtype=np.float64)
-    ctx.node_to_pmap(ta.indices, ta.indptr, esd, state_mask, pmap,
-                     obs_likelihood=obs_likelihood)
+    get_context().passes(ta.indices, ta.indptr, esd, state_mask, pmap,
+                         obs_likelihood=obs_likelihood)
     return pmap
 
 

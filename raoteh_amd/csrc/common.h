@@ -71,6 +71,10 @@ struct rt_ctx {
     hipEvent_t ev_reduced = nullptr;       // compute stream: totals of a group written
     hipEvent_t comm_events[8] = {};        // comm stream: a collective finished (ring)
     int comm_event_next = 0;
+    // grow-only device scratch of the reference-format calls (no hipMalloc / hipFree
+    // per call: single-site calls are latency-bound)
+    unsigned char *d_scratch = nullptr;
+    size_t scratch_bytes = 0;
     void *comm = nullptr;          // ncclComm_t
     hipStream_t comm_stream = nullptr;   // collectives overlap the next step's kernels
     void *rccl = nullptr;          // dlopen handle

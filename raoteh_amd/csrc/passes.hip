@@ -12,6 +12,8 @@
 // log-likelihood hot path is prune.hip.
 #include "common.h"
 
+#include <algorithm>
+
 namespace {
 
 __global__ void __launch_bounds__(64)
@@ -167,7 +169,78 @@ int mask_pass(rt_ctx *ctx, bool forward, int64_t nnodes, int64_t n, int64_t nsit
     return RT_OK;
 }
 
+// bump allocation out of the context's grow-only scratch (valid until the next call)
+struct scratch_plan {
+    size_t total = 0;
+    size_t take(size_t bytes)
+    {
+        const size_t off = total;
+        total += (bytes + 255) & ~(size_t)255;
+        return off;
+    }
+};
+
+int scratch_reserve(rt_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->scratch_bytes) return RT_OK;
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    hipFree(ctx->d_scratch);
+    ctx->d_scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    const size_t want = std::max(bytes + bytes / 2, (size_t)1 << 20);
+    RT_HIP(hipMalloc((void **)&ctx->d_scratch, want));
+    ctx->scratch_bytes = want;
+    return RT_OK;
+}
+
 }  // namespace
+
+// The pass sequence of _mcy_dense.py:261-291 / _mcz.py:128-163 in ONE call: the tree,
+// the transition matrices and the masks go to the device once, the three kernels
+// run back to back, masks and pmaps come back once.  (Through the three separate
+// entry points a single 61-state site uploads its 3.75 MB of matrices three times
+// and pays eleven hipMalloc / hipFree pairs: 11.7 ms per site.)
+extern "C" int rt_mcy_esd_passes(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t nsites,
+        const int64_t *idx, const int64_t *ptr, const double *esd, int64_t *state_mask,
+        const double *obs_likelihood, double *subtree_probability)
+{
+    RT_REQUIRE(ctx, "null context");
+    RT_TRY(check_tree(nnodes, n, nsites, idx, ptr, esd));
+    RT_REQUIRE((state_mask && subtree_probability) || nsites == 0, "null array");
+    if (nsites == 0) return RT_OK;
+    RT_HIP(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)nsites * nnodes * n * 8;
+    const size_t ni = (size_t)(nnodes > 1 ? nnodes - 1 : 1);
+    scratch_plan plan;
+    const size_t o_idx = plan.take(ni * 8), o_ptr = plan.take((size_t)(nnodes + 1) * 8);
+    const size_t o_esd = plan.take((size_t)nnodes * n * n * 8);
+    const size_t o_mask = plan.take(bytes), o_out = plan.take(bytes);
+    const size_t o_obs = obs_likelihood ? plan.take(bytes) : 0;
+    RT_TRY(scratch_reserve(ctx, plan.total));
+    unsigned char *base = ctx->d_scratch;
+    long *d_idx = (long *)(base + o_idx), *d_ptr = (long *)(base + o_ptr);
+    double *d_esd = (double *)(base + o_esd), *d_out = (double *)(base + o_out);
+    long *d_mask = (long *)(base + o_mask);
+    double *d_obs = obs_likelihood ? (double *)(base + o_obs) : nullptr;
+    hipStream_t st = ctx->stream;
+    if (nnodes > 1)
+        RT_HIP(hipMemcpyAsync(d_idx, idx, (size_t)(nnodes - 1) * 8, hipMemcpyHostToDevice, st));
+    RT_HIP(hipMemcpyAsync(d_ptr, ptr, (size_t)(nnodes + 1) * 8, hipMemcpyHostToDevice, st));
+    RT_HIP(hipMemcpyAsync(d_esd, esd, (size_t)nnodes * n * n * 8, hipMemcpyHostToDevice, st));
+    RT_HIP(hipMemcpyAsync(d_mask, state_mask, bytes, hipMemcpyHostToDevice, st));
+    if (d_obs) RT_HIP(hipMemcpyAsync(d_obs, obs_likelihood, bytes, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(pset_kernel, dim3((unsigned)nsites), dim3(64), 0, st, (int)nnodes,
+                       (int)n, d_idx, d_ptr, d_esd, d_mask);
+    hipLaunchKernelGGL(set_kernel, dim3((unsigned)nsites), dim3(64), 0, st, (int)nnodes,
+                       (int)n, d_idx, d_ptr, d_esd, d_mask);
+    hipLaunchKernelGGL(pmap_kernel, dim3((unsigned)nsites), dim3(64), 0, st, (int)nnodes,
+                       (int)n, d_idx, d_ptr, d_esd, d_mask, d_obs, d_out);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipMemcpyAsync(state_mask, d_mask, bytes, hipMemcpyDeviceToHost, st));
+    RT_HIP(hipMemcpyAsync(subtree_probability, d_out, bytes, hipMemcpyDeviceToHost, st));
+    RT_HIP(hipStreamSynchronize(st));
+    return RT_OK;
+}
 
 extern "C" int rt_mcy_esd_get_node_to_pset(rt_ctx *ctx, int64_t nnodes, int64_t n,
         int64_t nsites, const int64_t *idx, const int64_t *ptr, const double *esd,

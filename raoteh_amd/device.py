@@ -163,6 +163,27 @@ class Context(object):
             _ptr(state_mask, c_int64),
             None if obs is None else _ptr(obs, c_double), _ptr(out, c_double)))
 
+    def passes(self, indices, indptr, esd, state_mask, out, obs_likelihood=None):
+        """pset + set + pmap in one call (rt_mcy_esd_passes): state_mask (int64,
+        C-contiguous) is updated in place, ``out`` receives the pmaps."""
+        if (state_mask.dtype != np.int64 or not state_mask.flags['C_CONTIGUOUS']):
+            raise ValueError('state_mask must be a C-contiguous int64 array')
+        if out.dtype != np.float64 or not out.flags['C_CONTIGUOUS']:
+            raise ValueError('subtree_probability must be C-contiguous f64')
+        indices, indptr, esd, nnodes, n, nsites = self._pass_args(
+            indices, indptr, esd, state_mask)
+        if out.shape != state_mask.shape:
+            raise ValueError('shape mismatch')
+        obs = None
+        if obs_likelihood is not None:
+            obs = _f64(obs_likelihood)
+            if obs.shape != state_mask.shape:
+                raise ValueError('obs_likelihood shape mismatch')
+        _lib.check(_lib.lib().rt_mcy_esd_passes(
+            self._h, nnodes, n, nsites, _ptr(indices, c_int64), _ptr(indptr, c_int64),
+            _ptr(esd, c_double), _ptr(state_mask, c_int64),
+            None if obs is None else _ptr(obs, c_double), _ptr(out, c_double)))
+
     def node_to_distn(self, indices, indptr, esd, root_distn, pmap):
         """Downward pass (mc0_esd_get_node_to_distn): returns (distn, status)."""
         pmap = _f64(pmap)
