@@ -38,25 +38,44 @@ class TreeArrays(object):
         if root not in T:
             raise ValueError('the specified root is not in the tree')
         self.root = root
-        self.preorder_nodes = list(nx.dfs_preorder_nodes(T, root))
-        n = len(self.preorder_nodes)
+        # one depth-first walk in adjacency order: the preorder of
+        # nx.dfs_preorder_nodes and, per node, the child order of nx.bfs_edges
+        # (both follow the adjacency order; _density.py:104-140, _mcy_dense.py:255)
+        adj = T._adj if hasattr(T, '_adj') else T.adj
+        preorder, parent_of, children = [root], {root: None}, {root: []}
+        stack = [(root, iter(adj[root]))]
+        while stack:
+            node, it = stack[-1]
+            for nb in it:
+                if nb in parent_of:
+                    if nb != parent_of[node]:
+                        raise ValueError('the graph is not a tree')
+                    continue
+                parent_of[nb] = node
+                children[node].append(nb)
+                children[nb] = []
+                preorder.append(nb)
+                stack.append((nb, iter(adj[nb])))
+                break
+            else:
+                stack.pop()
+        self.preorder_nodes = preorder
+        n = len(preorder)
         if n != T.number_of_nodes():
             raise ValueError('the number of nodes is inconsistent')
         if T.number_of_edges() != n - 1:
             raise ValueError('the graph is not a tree')
-        self.node_to_index = dict((v, i) for i, v in
-                                  enumerate(self.preorder_nodes))
-        children = dict((v, []) for v in self.preorder_nodes)
+        self.node_to_index = dict((v, i) for i, v in enumerate(preorder))
         self.parent = np.full(n, -1, dtype=np.int64)
         self.edge_data = [None] * n
-        for na, nb in nx.bfs_edges(T, root):
-            children[na].append(nb)
-            ib = self.node_to_index[nb]
+        for ib in range(1, n):
+            nb = preorder[ib]
+            na = parent_of[nb]
             self.parent[ib] = self.node_to_index[na]
-            self.edge_data[ib] = T[na][nb]
+            self.edge_data[ib] = adj[na][nb]
         indices = []
         indptr = [0]
-        for na in self.preorder_nodes:
+        for na in preorder:
             indices.extend(self.node_to_index[nb] for nb in children[na])
             indptr.append(len(indices))
         self.indices = np.array(indices, dtype=np.int64)
