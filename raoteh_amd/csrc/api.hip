@@ -570,6 +570,7 @@ extern "C" int rt_sites_destroy(rt_sites *s)
     hipSetDevice(s->model->ctx->device);
     hipStreamSynchronize(s->model->ctx->stream);
     // an all-reduce of this batch's totals may still be in flight on the comm stream
+    rt_jit_ref(s->model->ctx, s->jit_fn, -1);
     hipFree(s->d_ops); hipFree(s->d_lane_ops); hipFree(s->d_obs); hipFree(s->d_loglik); hipFree(s->d_status);
     if (s->model->ctx->comm_stream) hipStreamSynchronize(s->model->ctx->comm_stream);
     hipFree(s->d_partial); hipFree(s->d_scratch);
@@ -994,6 +995,7 @@ extern "C" int rt_sites_clone(rt_sites *src, rt_sites **out)
     s->mfma_solo = src->mfma_solo;
     s->lane_ring = src->lane_ring;
     s->jit_fn = src->jit_fn;
+    rt_jit_ref(src->model->ctx, s->jit_fn, +1);
     s->jit_prefetch = src->jit_prefetch;
     s->block_sites = src->block_sites;
     s->jit_waves = src->jit_waves;

@@ -185,6 +185,7 @@ std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int 
 std::string rt_jit_mfma_split_source(const std::vector<rt_op> &ops, int n, int K, int T, int D,
                                      int LA);
 int rt_jit_get(rt_ctx *ctx, const std::string &src, void **fn, bool mfma = false);
+void rt_jit_ref(const rt_ctx *ctx, void *fn, int delta);
 void rt_jit_release(const rt_ctx *ctx);
 int rt_launch_prune_jit(rt_model *m, rt_sites *s);
 int rt_sites_pack(rt_sites *s, int kind, const int64_t *obs_order,
