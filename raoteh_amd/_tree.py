@@ -98,12 +98,12 @@ class TreeArrays(object):
         node_q = np.zeros(self.nnodes, dtype=np.int64)
         for i in range(1, self.nnodes):
             Q = self.edge_data[i].get('Q', Q_default)
-            check_square_dense(Q)
-            if Q.shape[0] != nstates:
-                raise ValueError('rate matrix shape %s does not match nstates '
-                                 '%d' % (Q.shape, nstates))
             key = id(Q)
-            if key not in slots:
+            if key not in slots:            # every distinct matrix is checked once
+                check_square_dense(Q)
+                if Q.shape[0] != nstates:
+                    raise ValueError('rate matrix shape %s does not match nstates '
+                                     '%d' % (Q.shape, nstates))
                 slots[key] = len(mats)
                 mats.append(np.ascontiguousarray(Q, dtype=np.float64))
             node_q[i] = slots[key]

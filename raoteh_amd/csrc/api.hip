@@ -473,8 +473,16 @@ extern "C" int rt_model_set_rates(rt_model *m, const double *Q, int64_t nq,
     // pageable sources: hipMemcpy (synchronous) so the vectors above may go away
     RT_HIP(hipStreamSynchronize(st));
     RT_HIP(hipMemcpy(m->d_Q, Q, nq * nn * 8, hipMemcpyHostToDevice));
-    RT_HIP(hipMemcpy(m->d_qidx, qi.data(), m->nnodes * 4, hipMemcpyHostToDevice));
-    RT_HIP(hipMemcpy(m->d_t, tt.data(), m->nnodes * 8, hipMemcpyHostToDevice));
+    // an optimiser changes the rates far more often than the assignment of matrices
+    // to edges or the branch lengths: those go up only when they differ
+    if (qi != m->h_qidx) {
+        RT_HIP(hipMemcpy(m->d_qidx, qi.data(), m->nnodes * 4, hipMemcpyHostToDevice));
+        m->h_qidx = qi;
+    }
+    if (tt != m->h_t) {
+        RT_HIP(hipMemcpy(m->d_t, tt.data(), m->nnodes * 8, hipMemcpyHostToDevice));
+        m->h_t = tt;
+    }
     return model_run_expm(m);
 }
 

@@ -98,6 +98,8 @@ struct rt_model {
     std::vector<int64_t> indices, indptr;   // host copy of the CSR
     std::vector<int32_t> parent;            // preorder parent index, -1 root
     std::vector<rt_op> ops;                 // post-order schedule
+    std::vector<int32_t> h_qidx;            // what d_qidx / d_t hold (rt_model_set_rates)
+    std::vector<double> h_t;
     int max_depth = 0;                      // accumulator slots needed
     // device
     int64_t *d_indices = nullptr, *d_indptr = nullptr;
