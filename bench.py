@@ -126,6 +126,10 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-rotate', action='store_true')
+    ap.add_argument('--encoding', default='dense', choices=('dense', 'state'),
+                    help="resident observation encoding: 'dense' f64 leaf vectors (the "
+                         "headline, 8*n bytes per leaf) or 'state' (uint8 per leaf; "
+                         "workloads whose leaves are observed states)")
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -157,9 +161,16 @@ def main():
     model = device.TreeModel(T, root, n, ctx=ctx)
     model.set_rates(Q_default=cfg['Q_default'])
     model.set_root_distn(cfg['root_distn'])
-    dense = synth.leaf_likelihoods(cfg)
-    batch0 = model.upload_sites(cfg['leaves'], dense, kind='dense')
-    del dense
+    if args.encoding == 'state':
+        if cfg['obs_kind'] != 'state':
+            raise SystemExit('--encoding state: the leaves of this workload are allowed-state '
+                             'sets, not states')
+        batch0 = model.upload_sites(cfg['leaves'], cfg['leaf_states'].astype(np.uint8),
+                                    kind='state')
+    else:
+        dense = synth.leaf_likelihoods(cfg)
+        batch0 = model.upload_sites(cfg['leaves'], dense, kind='dense')
+        del dense
     batches = [batch0]
     uses_rccl = world > 1 or bool(os.environ.get('RAOTEH_BENCH_FORCE_RCCL'))
     if not args.no_rotate:
@@ -243,6 +254,10 @@ def main():
         return
 
     alg_bytes = nsites * (8.0 * n * nleaves + 8.0)
+    if args.encoding == 'state' and batch0.device_bytes < nsites * 8 * n * nleaves / 4:
+        # the batch really is resident as states (bytes/site drop to L; the
+        # kernel is then bound by instruction issue, not by HBM)
+        alg_bytes = nsites * (1.0 * nleaves + 8.0)
     alg_flops = nsites * (2.0 * n * n * nedges + n * nedges + 2.0 * n)
     avg_prune_s = prune_ms / max(prune_cnt, 1) * 1e-3
     if prune_cnt == 0:          # events disabled (overhead experiment only)
@@ -282,7 +297,11 @@ def main():
         'vs_baseline': None,
         'dtype': 'f64',
         'data': 'synthetic',
-        'config': {'workload': '%s: %s' % (args.workload, wl['desc']),
+        'config': {'workload': '%s: %s' % (
+                       args.workload, wl['desc'] if args.encoding == 'dense' else
+                       wl['desc'].replace('dense f64 leaf likelihood vectors',
+                                          'uint8 leaf states (compact encoding)')),
+                   'encoding': args.encoding,
                    'sites_per_gpu': nsites, 'states': n, 'leaves': nleaves,
                    'edges': nedges, 'batches_rotated': len(batches),
                    'reduce': reduce_kind},

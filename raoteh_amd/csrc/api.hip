@@ -695,7 +695,8 @@ static int sites_alloc(rt_sites *s, bool generic)
         // an even number of blocks: the LDS-DMA kernel may give a wave two
         if (S == 64) s->nblocks = (s->nblocks + 1) & ~1ll;
         const int64_t np = (n + 1) & ~1ll;
-        s->obs_bytes = s->nblocks * K * S * np * 8;
+        s->obs_bytes = s->compact_states ? s->nblocks * ((K + 3) / 4) * S * 4
+                                         : s->nblocks * K * S * np * 8;
         padded = s->nblocks * S;
         s->npartials = s->nblocks;
     } else {
@@ -761,7 +762,7 @@ static int sites_alloc(rt_sites *s, bool generic)
 
 // Tree-specialised kernel for this batch (lane family): source from the
 // schedule, compiled once per distinct (tree, observed nodes) and device.
-static int sites_jit(rt_sites *s, bool generic)
+static int sites_jit(rt_sites *s, bool generic, int kind)
 {
     int want = g_jit;
     if (const char *v = getenv("RAOTEH_JIT")) want = atoi(v);
@@ -872,8 +873,12 @@ static int sites_jit(rt_sites *s, bool generic)
     if (const char *v = getenv("RAOTEH_JIT_WAVES")) WG = atoi(v);
     S = std::min(64, std::max(1, S));
     WG = std::min(8, std::max(1, WG));
+    // uint8 states stay states on the device (64 B per site instead of 2 KB) when the
+    // specialised kernel runs them; RAOTEH_JIT_DENSE_STATES=1 expands them as before
+    const bool states = kind == RT_OBS_STATE && s->nobs > 0 && s->nobs <= 1024 &&
+                        !getenv("RAOTEH_JIT_DENSE_STATES");
     const std::string src =
-        rt_jit_lane_source(s->ops, (int)s->model->n, (int)s->nobs, D, LA, S, WG);
+        rt_jit_lane_source(s->ops, (int)s->model->n, (int)s->nobs, D, LA, S, WG, states);
     s->jit_prefetch = D;
     const int rc = rt_jit_get(s->model->ctx, src, &s->jit_fn);
     if (rc != RT_OK && (!forced || rc == RT_ERR_UNSUPPORTED)) {
@@ -885,6 +890,7 @@ static int sites_jit(rt_sites *s, bool generic)
     if (rc == RT_OK) {
         s->block_sites = S;
         s->jit_waves = WG;
+        s->compact_states = states;
     }
     return rc;
 }
@@ -977,7 +983,7 @@ extern "C" int rt_sites_create(rt_model *m, int64_t nsites, int kind, int64_t no
     if (const char *v = getenv("RAOTEH_LANE_VARIANT")) s->lane_dma = strcmp(v, "dma") == 0;
     if (const char *r = getenv("RAOTEH_LANE_RING")) s->lane_ring = atoi(r);
     else s->lane_ring = s->lane_dma ? 0 : 8;      // 0: rt_launch_prune picks what fits
-    int rc = sites_jit(s, generic);          // before the layout is fixed: block_sites
+    int rc = sites_jit(s, generic, kind);    // before the layout is fixed: block_sites
     if (rc == RT_OK) rc = sites_alloc(s, generic);
     if (rc == RT_OK) rc = rt_sites_pack(s, kind, src_of_k.data(), data);
     if (rc != RT_OK) {
@@ -1008,6 +1014,7 @@ extern "C" int rt_sites_clone(rt_sites *src, rt_sites **out)
     s->block_sites = src->block_sites;
     s->jit_waves = src->jit_waves;
     s->jit_tiles = src->jit_tiles;
+    s->compact_states = src->compact_states;
     s->node_obs = src->node_obs;
     s->ops = src->ops;
     int rc = sites_alloc(s, src->d_scratch != nullptr);

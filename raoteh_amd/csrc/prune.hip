@@ -1156,6 +1156,31 @@ __global__ void pack_sites_lane_kernel(int kind, const void *__restrict__ data,
     }
 }
 
+// lane family, compact: uint8 states stay states, [blk][word][lane], byte j of word q =
+// stream position 4q + j (255: unobserved, padding positions and padding sites)
+__global__ void pack_sites_lane_state_kernel(const unsigned char *__restrict__ data,
+                                             const int *__restrict__ src_of_k, long nsites,
+                                             long nobs, int K, int S,
+                                             unsigned *__restrict__ out, size_t total)
+{
+    const int KQ = (K + 3) / 4;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(e % S);
+        const size_t r = e / S;
+        const int q = (int)(r % KQ);
+        const long site = (long)(r / KQ) * S + lane;
+        unsigned w = 0;
+        for (int j = 0; j < 4; ++j) {
+            const int k = 4 * q + j;
+            unsigned st = 255u;
+            if (k < K && site < nsites) st = data[(size_t)site * nobs + src_of_k[k]];
+            w |= st << (8 * j);
+        }
+        out[e] = w;
+    }
+}
+
 // [blk16][k][kkpair][lane][2]: element e2 of pair q is k-step 2q+e2, state
 // 4(2q+e2) + (lane>>4), site blk*16 + (lane&15)
 __global__ void pack_sites_mfma_kernel(int kind, const void *__restrict__ data,
@@ -1230,7 +1255,14 @@ int rt_sites_pack(rt_sites *s, int kind, const int64_t *src_of_k, const void *da
         const size_t total = (size_t)s->obs_bytes / 8;
         size_t blocks = (total + 255) / 256;
         if (blocks > 65536) blocks = 65536;
-        if (s->layout == RT_LAYOUT_LANE) {
+        if (s->layout == RT_LAYOUT_LANE && s->compact_states) {
+            const size_t words = (size_t)s->obs_bytes / 4;
+            hipLaunchKernelGGL(pack_sites_lane_state_kernel,
+                               dim3((unsigned)std::min<size_t>((words + 255) / 256, 65536)),
+                               dim3(256), 0, st, (const unsigned char *)d_in, d_src,
+                               (long)s->nsites, (long)K, K, s->block_sites,
+                               (unsigned *)s->d_obs, words);
+        } else if (s->layout == RT_LAYOUT_LANE) {
             const int np = (n + 1) & ~1;
             const int paired = s->d_scratch == nullptr;
             hipLaunchKernelGGL(pack_sites_lane_kernel, dim3((unsigned)blocks), dim3(256),
@@ -1461,8 +1493,8 @@ int rt_launch_prune(rt_model *m, rt_sites *s)
     else if (s->jit_fn) {
         rc = rt_launch_prune_jit(m, s);
         if (s->layout == RT_LAYOUT_LANE)
-            snprintf(jit_name, sizeof(jit_name), "prune_tree_jit<%d,D%d>", (int)m->n,
-                     s->jit_prefetch);
+            snprintf(jit_name, sizeof(jit_name), "prune_tree_jit<%d,D%d%s>", (int)m->n,
+                     s->jit_prefetch, s->compact_states ? ",states" : "");
         else
             snprintf(jit_name, sizeof(jit_name), "prune_tree_jit_mfma<%d,T%d>", (int)m->n,
                      s->jit_tiles);

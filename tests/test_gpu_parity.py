@@ -868,3 +868,52 @@ def test_randomised_soak_short(ra, monkeypatch):
         spec.loader.exec_module(mod)
         monkeypatch.setattr(sys, 'argv', [name, '6', str(seed)])
         mod.main()          # exits the process with status 1 on any mismatch
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 4])
+def test_compact_state_batches_match_dense(ra, n):
+    """uint8 states stay states on the device when a tree-specialised lane kernel runs
+    them (64 B per site instead of 2 KB); the kernel expands them to 0/1 vectors in
+    registers, so the results equal the dense encoding's bit for bit."""
+    rng = np.random.RandomState(500 + n)
+    set_option = ra.lib.lib().rt_set_option
+    for nnodes, nsites in ((2, 70), (11, 129), (40, 3000), (130, 700)):
+        T, root, obs_nodes, w = _random_case(ra, rng, n, nnodes, nsites)
+        pre, idx, ptr, esd = orc.get_esd_transitions(T, root, n)
+        states = rng.randint(0, n, size=(nsites, len(obs_nodes))).astype(np.uint8)
+        states[rng.uniform(size=states.shape) < 0.2] = 255
+        dense = np.ones((nsites, len(obs_nodes), n))
+        seen = states != 255
+        dense[seen] = 0.0
+        ii, kk = np.nonzero(seen)
+        dense[ii, kk, states[ii, kk]] = 1.0
+        model = ra.device.TreeModel(T, root, n)
+        model.set_transitions(esd)
+        model.set_root_distn(w)
+        out = {}
+        for key, jit, bs, data, kind in (('dense', 1, 64, dense, 'dense'),
+                                         ('state', 1, 64, states, 'state'),
+                                         ('state51', 1, 51, states, 'state'),
+                                         ('interp', 0, 0, states, 'state')):
+            ra.lib.check(set_option(b'jit', jit))
+            ra.lib.check(set_option(b'jit_block_sites', bs))
+            try:
+                batch = model.upload_sites(obs_nodes, data, kind=kind)
+                ll, st = model.log_likelihoods(batch)
+                out[key] = (ll, st, ra.ctx.kernel_time(1)[2], batch.device_bytes)
+                ll2, _ = model.log_likelihoods(batch.clone())
+                np.testing.assert_array_equal(ll, ll2)
+            finally:
+                ra.lib.check(set_option(b'jit', -1))
+                ra.lib.check(set_option(b'jit_block_sites', 0))
+        assert out['state'][2].endswith(',states>'), out['state'][2]
+        assert not out['dense'][2].endswith(',states>')
+        assert out['state'][3] * 8 <= out['dense'][3]
+        for key in ('state', 'state51', 'interp'):
+            np.testing.assert_array_equal(out['dense'][0], out[key][0])
+            np.testing.assert_array_equal(out['dense'][1], out[key][1])
+        want, wst = orc.batch_log_likelihoods(idx, ptr, esd, [pre.index(v) for v in obs_nodes],
+                                              dense[:64], w)
+        np.testing.assert_array_equal(out['state'][1][:64] & 1, wst)
+        ok = wst == 0
+        np.testing.assert_allclose(out['state'][0][:64][ok], want[ok], rtol=RTOL_LL)
