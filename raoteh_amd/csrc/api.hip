@@ -854,29 +854,35 @@ static int sites_jit(rt_sites *s, bool generic, int kind)
         const int64_t regs = 2 * (s->model->max_depth * n + (1 + LA) * n * n + (D + 1) * np) + 40;
         if (!forced && regs > 250) return RT_OK;    // would spill: the interpreter is faster
     }
-    // A tree whose P table is large gets workgroups of 2, 4 or 8 waves sharing one copy,
-    // so that the 8 waves of a CU still fit its 160 KB of LDS; beyond that the
-    // interpreter kernels run.
+    // uint8 states stay states on the device (64 B per site instead of 2 KB) when the
+    // specialised kernel runs them; RAOTEH_JIT_DENSE_STATES=1 expands them as before
+    const bool states = kind == RT_OBS_STATE && s->nobs > 0 && s->nobs <= 1024 &&
+                        !getenv("RAOTEH_JIT_DENSE_STATES");
+    // LDS tables of a workgroup: the step-ordered P table and, for state batches, the
+    // column table of the observed leaves (jit.hip).  Each wave keeps its own copy
+    // while the (up to 8) waves of a CU fit the 160 KB that way; else the waves of a
+    // CU form one workgroup (balanced batches) or workgroups of 2, 4, 8 waves share.
     int S = 64, WG = 1;
-    {
-        const int64_t ptab = (int64_t)s->ops.size() * s->model->n * s->model->n * 8;
-        while (WG < 8 && (8 / WG) * ptab > 150 * 1024) WG *= 2;
-        if (ptab > 150 * 1024) return RT_OK;
-    }
+    int64_t tables = (int64_t)s->ops.size() * s->model->n * s->model->n * 8;
+    if (states)
+        for (const rt_op &op : s->ops)
+            if (op.pop < 0 && op.obs >= 0 && op.dst >= 0)
+                tables += s->model->n * (s->model->n + 1) * 8;
+    if (tables > 150 * 1024) return RT_OK;
     const int64_t nb64 = (s->nsites + 63) / 64;
     if (nb64 >= 256 && nb64 <= 2048) {
         const int64_t nw = (nb64 + 255) / 256 * 256;
         S = (int)((s->nsites + nw - 1) / nw);
+        const int64_t per_cu = nw / 256;
+        if (per_cu * tables > 150 * 1024) WG = (int)per_cu;     // one workgroup per CU
+    } else {
+        while (WG < 8 && (8 / WG) * tables > 150 * 1024) WG *= 2;
     }
     if (g_jit_block_sites > 0) S = g_jit_block_sites;
     if (const char *v = getenv("RAOTEH_JIT_BLOCK_SITES")) S = atoi(v);
     if (const char *v = getenv("RAOTEH_JIT_WAVES")) WG = atoi(v);
     S = std::min(64, std::max(1, S));
     WG = std::min(8, std::max(1, WG));
-    // uint8 states stay states on the device (64 B per site instead of 2 KB) when the
-    // specialised kernel runs them; RAOTEH_JIT_DENSE_STATES=1 expands them as before
-    const bool states = kind == RT_OBS_STATE && s->nobs > 0 && s->nobs <= 1024 &&
-                        !getenv("RAOTEH_JIT_DENSE_STATES");
     const std::string src =
         rt_jit_lane_source(s->ops, (int)s->model->n, (int)s->nobs, D, LA, S, WG, states);
     s->jit_prefetch = D;
@@ -918,7 +924,8 @@ extern "C" int rt_jit_source(int64_t nnodes, const int64_t *idx, const int64_t *
     const int LA = getenv("RAOTEH_JIT_LOOKAHEAD") ? std::max(1, atoi(getenv("RAOTEH_JIT_LOOKAHEAD"))) : 2;
     const int T = getenv("RAOTEH_JIT_TILES") ? std::min(4, std::max(1, atoi(getenv("RAOTEH_JIT_TILES")))) : 2;
     const std::string src = n <= 4
-        ? rt_jit_lane_source(m.ops, (int)n, (int)nobs, (int)prefetch, LA, 64, 4)
+        ? rt_jit_lane_source(m.ops, (int)n, (int)nobs, (int)prefetch, LA, 64, 4,
+                             getenv("RAOTEH_JIT_SOURCE_STATES") != nullptr)
         : n <= 32 ? rt_jit_mfma_source(m.ops, (int)n, (int)nobs, T, (int)prefetch, 1)
                   : rt_jit_mfma_split_source(m.ops, (int)n, (int)nobs, std::min(T, 3),
                                              (int)prefetch, 1);
