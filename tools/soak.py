@@ -50,6 +50,17 @@ def main():
         w = rng.uniform(0.0, 1.0, size=n)
         dense = rng.uniform(0.05, 1.0, size=(nsites, len(obs_nodes), n))
         dense[rng.uniform(size=dense.shape) < 0.15] = 0.0
+        # half of the lane-family cases: observed states (the compact resident encoding
+        # of the specialised kernel) against their dense 0/1 expansion
+        states = None
+        if n <= 4 and rng.uniform() < 0.5:
+            states = rng.randint(0, n, size=(nsites, len(obs_nodes))).astype(np.uint8)
+            states[rng.uniform(size=states.shape) < 0.15] = 255
+            dense = np.ones((nsites, len(obs_nodes), n))
+            seen = states != 255
+            dense[seen] = 0.0
+            ii, kk = np.nonzero(seen)
+            dense[ii, kk, states[ii, kk]] = 1.0
         pre, idx, ptr, esd = orc.get_esd_transitions(T, root, n)
         oidx = [pre.index(v) for v in obs_nodes]
         # the oracle on a bounded sample of the sites
@@ -78,7 +89,10 @@ def main():
                 os.environ['RAOTEH_JIT_TILES'] = str(tiles)
                 _lib.check(set_option(b'jit_block_sites', bs if n <= 4 else 0))
             try:
-                batch = model.upload_sites(obs_nodes, dense, kind='dense')
+                if jit and states is not None:
+                    batch = model.upload_sites(obs_nodes, states, kind='state')
+                else:
+                    batch = model.upload_sites(obs_nodes, dense, kind='dense')
                 ll, st = model.log_likelihoods(batch)
                 tot = model.fetch_totals(batch)
                 out.append((ll, st, tot, ctx.kernel_time(1)[2], (jit, tiles, bs)))
