@@ -854,10 +854,11 @@ static int sites_jit(rt_sites *s, bool generic, int kind)
         const int64_t regs = 2 * (s->model->max_depth * n + (1 + LA) * n * n + (D + 1) * np) + 40;
         if (!forced && regs > 250) return RT_OK;    // would spill: the interpreter is faster
     }
-    // uint8 states stay states on the device (64 B per site instead of 2 KB) when the
-    // specialised kernel runs them; RAOTEH_JIT_DENSE_STATES=1 expands them as before
-    const bool states = kind == RT_OBS_STATE && s->nobs > 0 && s->nobs <= 1024 &&
-                        !getenv("RAOTEH_JIT_DENSE_STATES");
+    // uint8 states and (n <= 4) allowed-set masks stay one byte per leaf on the device
+    // (64 B per site instead of 2 KB) when the specialised kernel runs them;
+    // RAOTEH_JIT_DENSE_STATES=1 expands them as before
+    const int states = (s->nobs > 0 && s->nobs <= 1024 && !getenv("RAOTEH_JIT_DENSE_STATES"))
+                           ? (kind == RT_OBS_STATE ? 1 : kind == RT_OBS_MASK ? 2 : 0) : 0;
     // LDS tables of a workgroup: the step-ordered P table and, for state batches, the
     // column table of the observed leaves (jit.hip).  Each wave keeps its own copy
     // while the (up to 8) waves of a CU fit the 160 KB that way; else the waves of a
@@ -867,7 +868,7 @@ static int sites_jit(rt_sites *s, bool generic, int kind)
     if (states)
         for (const rt_op &op : s->ops)
             if (op.pop < 0 && op.obs >= 0 && op.dst >= 0)
-                tables += s->model->n * (s->model->n + 1) * 8;
+                tables += s->model->n * (states == 2 ? (1 << s->model->n) : s->model->n + 1) * 8;
     if (tables > 150 * 1024) return RT_OK;
     const int64_t nb64 = (s->nsites + 63) / 64;
     if (nb64 >= 256 && nb64 <= 2048) {

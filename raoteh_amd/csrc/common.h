@@ -154,8 +154,8 @@ struct rt_sites {
     int block_sites = 64;           // lane family: sites per block (< 64 only with jit_fn)
     int jit_waves = 1;              // waves per workgroup of the tree-specialised kernel
     int jit_tiles = 1;              // MFMA family: site tiles per wave of that kernel
-    bool compact_states = false;    // lane family + specialised kernel + uint8 states: the
-                                    // batch stays resident as states (1 byte per leaf)
+    int compact_states = 0;         // lane family + specialised kernel: the batch stays resident
+                                    // as one byte per leaf: 1 = uint8 states, 2 = allowed-set masks
     double *d_scratch = nullptr;    // generic kernel message stack
     int64_t scratch_bytes = 0;
 };
@@ -184,7 +184,7 @@ int rt_launch_pfrag(rt_model *m);
 int rt_launch_prune(rt_model *m, rt_sites *s);
 // jit.hip
 std::string rt_jit_lane_source(const std::vector<rt_op> &ops, int n, int K, int D, int LA,
-                               int S, int WG, bool states = false);
+                               int S, int WG, int compact = 0);
 std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int T, int D, int LA);
 std::string rt_jit_mfma_split_source(const std::vector<rt_op> &ops, int n, int K, int T, int D,
                                      int LA);

@@ -1158,11 +1158,13 @@ __global__ void pack_sites_lane_kernel(int kind, const void *__restrict__ data,
 
 // lane family, compact: uint8 states stay states, [blk][word][lane], byte j of word q =
 // stream position 4q + j (255: unobserved, padding positions and padding sites)
-__global__ void pack_sites_lane_state_kernel(const unsigned char *__restrict__ data,
+__global__ void pack_sites_lane_state_kernel(int kind, int n, const void *__restrict__ data,
                                              const int *__restrict__ src_of_k, long nsites,
                                              long nobs, int K, int S,
                                              unsigned *__restrict__ out, size_t total)
 {
+    // states: 255 = unobserved; masks (n <= 4): the low n bits, all set = unobserved
+    const unsigned unobserved = kind == RT_OBS_MASK ? (1u << n) - 1u : 255u;
     const int KQ = (K + 3) / 4;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (size_t)gridDim.x * blockDim.x) {
@@ -1173,8 +1175,13 @@ __global__ void pack_sites_lane_state_kernel(const unsigned char *__restrict__ d
         unsigned w = 0;
         for (int j = 0; j < 4; ++j) {
             const int k = 4 * q + j;
-            unsigned st = 255u;
-            if (k < K && site < nsites) st = data[(size_t)site * nobs + src_of_k[k]];
+            unsigned st = unobserved;
+            if (k < K && site < nsites) {
+                const size_t at = (size_t)site * nobs + src_of_k[k];
+                st = kind == RT_OBS_MASK
+                         ? (unsigned)(((const unsigned long long *)data)[at] & unobserved)
+                         : ((const unsigned char *)data)[at];
+            }
             w |= st << (8 * j);
         }
         out[e] = w;
@@ -1259,7 +1266,7 @@ int rt_sites_pack(rt_sites *s, int kind, const int64_t *src_of_k, const void *da
             const size_t words = (size_t)s->obs_bytes / 4;
             hipLaunchKernelGGL(pack_sites_lane_state_kernel,
                                dim3((unsigned)std::min<size_t>((words + 255) / 256, 65536)),
-                               dim3(256), 0, st, (const unsigned char *)d_in, d_src,
+                               dim3(256), 0, st, kind, n, d_in, d_src,
                                (long)s->nsites, (long)K, K, s->block_sites,
                                (unsigned *)s->d_obs, words);
         } else if (s->layout == RT_LAYOUT_LANE) {
@@ -1494,7 +1501,8 @@ int rt_launch_prune(rt_model *m, rt_sites *s)
         rc = rt_launch_prune_jit(m, s);
         if (s->layout == RT_LAYOUT_LANE)
             snprintf(jit_name, sizeof(jit_name), "prune_tree_jit<%d,D%d%s>", (int)m->n,
-                     s->jit_prefetch, s->compact_states ? ",states" : "");
+                     s->jit_prefetch, s->compact_states == 1 ? ",states"
+                                      : s->compact_states == 2 ? ",masks" : "");
         else
             snprintf(jit_name, sizeof(jit_name), "prune_tree_jit_mfma<%d,T%d>", (int)m->n,
                      s->jit_tiles);

@@ -917,3 +917,29 @@ def test_compact_state_batches_match_dense(ra, n):
         np.testing.assert_array_equal(out['state'][1][:64] & 1, wst)
         ok = wst == 0
         np.testing.assert_allclose(out['state'][0][:64][ok], want[ok], rtol=RTOL_LL)
+        # allowed-set masks (type y; the IUPAC codes of a DNA alignment): one byte per
+        # leaf as well, a 2^n-column table instead of the n + 1 columns of states
+        masks = rng.randint(1, 1 << n, size=(nsites, len(obs_nodes))).astype(np.uint64)
+        masks[rng.uniform(size=masks.shape) < 0.02] = 0          # a few impossible sites
+        dm = ((masks[..., None] >> np.arange(n, dtype=np.uint64)) & 1).astype(np.float64)
+        outm = {}
+        for key, jit, data, kind in (('dense', 1, dm, 'dense'), ('mask', 1, masks, 'mask'),
+                                     ('interp', 0, masks, 'mask')):
+            ra.lib.check(set_option(b'jit', jit))
+            try:
+                batch = model.upload_sites(obs_nodes, data, kind=kind)
+                ll, st = model.log_likelihoods(batch)
+                outm[key] = (ll, st, ra.ctx.kernel_time(1)[2], model.fetch_totals(batch))
+            finally:
+                ra.lib.check(set_option(b'jit', -1))
+        assert outm['mask'][2].endswith(',masks>'), outm['mask'][2]
+        for key in ('mask', 'interp'):
+            np.testing.assert_array_equal(outm['dense'][0], outm[key][0])
+            np.testing.assert_array_equal(outm['dense'][1], outm[key][1])
+        np.testing.assert_array_equal(outm['dense'][3], outm['mask'][3])
+        want, wst = orc.batch_log_likelihoods(idx, ptr, esd, [pre.index(v) for v in obs_nodes],
+                                              dm[:64], w)
+        np.testing.assert_array_equal(outm['mask'][1][:64] & 1, wst)
+        ok = wst == 0
+        if ok.any():
+            np.testing.assert_allclose(outm['mask'][0][:64][ok], want[ok], rtol=RTOL_LL)

@@ -52,15 +52,21 @@ def main():
         dense[rng.uniform(size=dense.shape) < 0.15] = 0.0
         # half of the lane-family cases: observed states (the compact resident encoding
         # of the specialised kernel) against their dense 0/1 expansion
-        states = None
+        states, skind = None, 'state'
         if n <= 4 and rng.uniform() < 0.5:
-            states = rng.randint(0, n, size=(nsites, len(obs_nodes))).astype(np.uint8)
-            states[rng.uniform(size=states.shape) < 0.15] = 255
-            dense = np.ones((nsites, len(obs_nodes), n))
-            seen = states != 255
-            dense[seen] = 0.0
-            ii, kk = np.nonzero(seen)
-            dense[ii, kk, states[ii, kk]] = 1.0
+            if rng.uniform() < 0.5:
+                states = rng.randint(0, n, size=(nsites, len(obs_nodes))).astype(np.uint8)
+                states[rng.uniform(size=states.shape) < 0.15] = 255
+                dense = np.ones((nsites, len(obs_nodes), n))
+                seen = states != 255
+                dense[seen] = 0.0
+                ii, kk = np.nonzero(seen)
+                dense[ii, kk, states[ii, kk]] = 1.0
+            else:                                  # allowed-set masks
+                skind = 'mask'
+                states = rng.randint(0, 1 << n, size=(nsites, len(obs_nodes))).astype(np.uint64)
+                dense = ((states[..., None] >> np.arange(n, dtype=np.uint64)) & 1
+                         ).astype(np.float64)
         pre, idx, ptr, esd = orc.get_esd_transitions(T, root, n)
         oidx = [pre.index(v) for v in obs_nodes]
         # the oracle on a bounded sample of the sites
@@ -90,7 +96,7 @@ def main():
                 _lib.check(set_option(b'jit_block_sites', bs if n <= 4 else 0))
             try:
                 if jit and states is not None:
-                    batch = model.upload_sites(obs_nodes, states, kind='state')
+                    batch = model.upload_sites(obs_nodes, states, kind=skind)
                 else:
                     batch = model.upload_sites(obs_nodes, dense, kind='dense')
                 ll, st = model.log_likelihoods(batch)
