@@ -115,6 +115,32 @@ def cpu_baseline(cfg, gpu_ll, budget_s):
 
 # ---------------------------------------------------------------------------
 
+def reduce_group_after_step(j, nb):
+    """Ring of nb batches, step j runs batch j % nb.  The totals are all-reduced once
+    per half rotation: -> (lo, hi) = the slice of the ring whose steps have just
+    completed, or None.  A batch is reduced after its step and before the ring comes
+    back to it, while the other half is being computed."""
+    half = max(1, nb // 2)
+    r = j % nb
+    if r == half - 1:
+        return (0, half)
+    if r == nb - 1 and nb > half:
+        return (half, nb)
+    return None
+
+
+def reduce_group_at_end(steps, nb):
+    """The batches stepped since the last reduce_group_after_step group, after `steps`
+    steps: -> (lo, hi) or None."""
+    half = max(1, nb // 2)
+    r = steps % nb
+    if 0 < r < half:
+        return (0, r)
+    if half < r:
+        return (half, r)
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -190,8 +216,6 @@ def main():
         ctx.comm_init(1, 0, device.Context.comm_unique_id())
         reduce_kind = 'rccl'
 
-    half = max(1, len(batches) // 2)
-
     def step(j):
         b = batches[j % len(batches)]
         model.step(b)          # expm of every edge + prune + reduce (rt_step)
@@ -200,11 +224,9 @@ def main():
         # stream bookkeeping around a collective costs ~11 us of GPU time per call
         # whatever the payload, a quarter of a C2 step
         if reduce_kind == 'rccl':
-            r = j % len(batches)
-            if r == half - 1:
-                model.allreduce_group(batches[:half])
-            elif r == len(batches) - 1 and len(batches) > half:
-                model.allreduce_group(batches[half:])
+            grp = reduce_group_after_step(j, len(batches))
+            if grp is not None:
+                model.allreduce_group(batches[grp[0]:grp[1]])
         return b
 
     for j in range(args.warmup):
@@ -224,12 +246,9 @@ def main():
     for j in range(args.steps):
         last = step(j)
     if reduce_kind == 'rccl':
-        # the incomplete group at the end of the timed region
-        r = args.steps % len(batches)
-        if 0 < r < half:
-            model.allreduce_group(batches[:r])
-        elif half < r:
-            model.allreduce_group(batches[half:r])
+        grp = reduce_group_at_end(args.steps, len(batches))     # the incomplete group
+        if grp is not None:
+            model.allreduce_group(batches[grp[0]:grp[1]])
     t_enq = time.perf_counter()      # all steps enqueued (the launches are asynchronous)
     ctx.sync()
     ctl.barrier()

@@ -66,3 +66,34 @@ def test_sharded_reduce_matches_single_process(tmp_path, world):
     assert ranges[0][0] == 0 and ranges[-1][1] == 1003
     for a, b in zip(ranges, ranges[1:]):
         assert a[1] == b[0]
+
+
+def test_bench_reduce_grouping_covers_every_step_once():
+    """bench.py (N > 1) all-reduces the totals of its batch ring once per half rotation:
+    every step's totals are reduced exactly once, after the step and before the ring
+    comes back to that batch."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        'bench', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                              'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for nb in (1, 2, 3, 4, 5, 8):
+        for steps in (1, 2, 7, 8, 9, 40, 41, 43):
+            pending = {}                       # batch -> step whose totals await a reduce
+            reduced = []
+            for j in range(steps):
+                b = j % nb
+                assert b not in pending, (nb, steps, j)      # reduced before reuse
+                pending[b] = j
+                grp = bench.reduce_group_after_step(j, nb)
+                if grp is not None:
+                    for k in range(*grp):
+                        reduced.append(pending.pop(k))
+            grp = bench.reduce_group_at_end(steps, nb)
+            if grp is not None:
+                for k in range(*grp):
+                    reduced.append(pending.pop(k))
+            assert not pending, (nb, steps, pending)
+            assert sorted(reduced) == list(range(steps))
