@@ -207,14 +207,23 @@ def main():
                                      <= 16 * 2 ** 30)):
             batches.append(batch0.clone())
 
-    # RCCL communicator for the data-path reduce
+    # RCCL communicator for the data-path reduce.  librccl announces itself on stdout
+    # ("Librccl path : ..."); stdout is for the one JSON line, so file descriptor 1
+    # points at stderr while the library loads and the communicator is built.
     reduce_kind = 'none'
-    if world > 1:
-        reduce_kind = 'rccl' if init_rccl(ctx, ctl) else 'host-socket-fallback'
-    elif os.environ.get('RAOTEH_BENCH_FORCE_RCCL'):
-        # single-GPU rehearsal of the N > 1 data path: a 1-rank communicator
-        ctx.comm_init(1, 0, device.Context.comm_unique_id())
-        reduce_kind = 'rccl'
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if world > 1:
+            reduce_kind = 'rccl' if init_rccl(ctx, ctl) else 'host-socket-fallback'
+        elif os.environ.get('RAOTEH_BENCH_FORCE_RCCL'):
+            # single-GPU rehearsal of the N > 1 data path: a 1-rank communicator
+            ctx.comm_init(1, 0, device.Context.comm_unique_id())
+            reduce_kind = 'rccl'
+    finally:
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
 
     def step(j):
         b = batches[j % len(batches)]
