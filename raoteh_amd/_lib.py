@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import (POINTER, byref, c_char_p, c_double, c_int, c_int32,
+from ctypes import (POINTER, c_char_p, c_double, c_int, c_int32,
                     c_int64, c_ubyte, c_void_p)
 
 __all__ = ['HipLibraryError', 'RaotehHipError', 'lib', 'check', 'LIB_PATH']

@@ -21,7 +21,7 @@ import networkx as nx
 import numpy as np
 
 from . import _mcy_dense
-from ._tree import TreeArrays, check_square_dense
+from ._tree import check_square_dense
 from .device import TreeModel, get_context
 
 __all__ = ['custom_expm', 'get_expm_augmented_tree', 'get_likelihood',

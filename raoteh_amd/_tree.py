@@ -8,7 +8,6 @@ native passes:
 """
 from __future__ import annotations
 
-import networkx as nx
 import numpy as np
 
 __all__ = ['TreeArrays', 'marshal_tree', 'check_square_dense']

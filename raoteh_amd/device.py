@@ -20,7 +20,7 @@ from ctypes import byref, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p
 import numpy as np
 
 from . import _lib
-from ._tree import TreeArrays, check_square_dense
+from ._tree import TreeArrays
 
 __all__ = ['Context', 'get_context', 'TreeModel', 'SiteBatch', 'device_count']
 
