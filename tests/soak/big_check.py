@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from raoteh_amd import _lib, device, synth       # noqa: E402
 from oracle import oracle_numpy as orc           # noqa: E402  (the checker)
 

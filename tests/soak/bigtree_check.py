@@ -1,7 +1,7 @@
 """Large random binary trees (run on a GPU box): the lane kernel with P through the
 scalar cache (tree too large for LDS), the MFMA kernels with hundreds of steps."""
-import sys, time
-sys.path.insert(0,'/root/repo')
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, networkx as nx
 from raoteh_amd import synth, device, _mjp_dense
 from oracle import oracle_numpy as orc

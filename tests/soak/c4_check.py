@@ -3,7 +3,7 @@
 (125 000 sites, 61 states, 64 leaves) + upload (PCIe-inclusive) timing."""
 import json, sys, time, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from raoteh_amd import synth, device
 from oracle import oracle_numpy as orc
 

@@ -4,7 +4,7 @@ Randomised soak test (run on a GPU box): random trees, state counts, observation
 encodings and batch sizes; every batch through the interpreter kernel and through
 the tree-specialised kernel (random tiles / sites per wave), both compared bit for
 bit with each other and to 1e-10 with the oracle.  Not part of the pytest suite:
-    python tools/soak.py [seconds] [seed]
+    python tests/soak/soak.py [seconds] [seed]
 """
 import os
 import sys
@@ -13,7 +13,7 @@ import time
 import networkx as nx
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 from raoteh_amd import _lib, device, synth           # noqa: E402

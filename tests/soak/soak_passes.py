@@ -6,7 +6,7 @@ Randomised soak test of the remaining device entry points (run on a GPU box):
  * the reference-format passes (pset / set / pmap with and without observation
    likelihoods / distn / joint) against the oracle, bit-exact for the masks;
  * the batched path with state (uint8) and mask (uint64) observation encodings.
-    python tools/soak_passes.py [seconds] [seed]
+    python tests/soak/soak_passes.py [seconds] [seed]
 """
 import os
 import sys
@@ -15,7 +15,7 @@ import time
 import networkx as nx
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 from raoteh_amd import device, synth            # noqa: E402

@@ -857,11 +857,11 @@ def test_tree_specialised_kernel_large_tree(ra):
 
 
 def test_randomised_soak_short(ra, monkeypatch):
-    """A few seconds of tools/soak.py and tools/soak_passes.py (random trees, state
+    """A few seconds of tests/soak/soak.py and tests/soak/soak_passes.py (random trees, state
     counts, encodings, tilings; specialised vs interpreter kernel bit for bit, both
     against the oracle).  The long runs are recorded in DESIGN.md section 5."""
     import importlib.util
-    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools')
+    tools = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'soak')
     for name, seed in (('soak', 4242), ('soak_passes', 4243)):
         spec = importlib.util.spec_from_file_location(name, os.path.join(tools, name + '.py'))
         mod = importlib.util.module_from_spec(spec)
