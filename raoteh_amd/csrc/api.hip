@@ -66,6 +66,7 @@ extern "C" int rt_ctx_create(int device, rt_ctx **out)
     }
     e = hipMalloc((void **)&ctx->d_totals_arena, (size_t)RT_TOTALS_SLOTS * 3 * 8);
     if (e == hipSuccess) e = hipMemset(ctx->d_totals_arena, 0, (size_t)RT_TOTALS_SLOTS * 3 * 8);
+    if (e == hipSuccess) e = hipDeviceSynchronize();    // the memset is asynchronous
     if (e != hipSuccess) {
         hipStreamDestroy(ctx->stream);
         delete ctx;
@@ -1027,8 +1028,12 @@ extern "C" int rt_sites_clone(rt_sites *src, rt_sites **out)
     s->ops = src->ops;
     int rc = sites_alloc(s, src->d_scratch != nullptr);
     if (rc == RT_OK && s->obs_bytes > 0) {
-        hipStreamSynchronize(src->model->ctx->stream);
-        hipError_t e = hipMemcpy(s->d_obs, src->d_obs, s->obs_bytes, hipMemcpyDeviceToDevice);
+        // on the library's stream: a device-to-device hipMemcpy returns before the copy
+        // has run and the (non-blocking) stream of the kernels does not wait for the
+        // null stream -- a launch right after the clone would read a half-copied batch
+        hipError_t e = hipMemcpyAsync(s->d_obs, src->d_obs, s->obs_bytes, hipMemcpyDeviceToDevice,
+                                      src->model->ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(src->model->ctx->stream);
         if (e != hipSuccess) {
             rt_set_error("rt_sites_clone: %s", hipGetErrorString(e));
             rc = RT_ERR_HIP;

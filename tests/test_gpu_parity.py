@@ -650,6 +650,49 @@ def test_underflow_is_reported_not_hidden(ra):
     assert wst.all() and np.all(np.isneginf(ll))
 
 
+@pytest.mark.parametrize('nsites', [100000, 400001, 3000])
+def test_relaunch_and_clone_give_the_same_totals(ra, nsites):
+    """Totals are bitwise reproducible launch after launch, and a clone used the
+    moment rt_sites_clone returns holds the whole batch (its device-to-device
+    copy is ordered on the library's stream -- a null-stream copy was not, and a
+    launch right behind it read a partly copied batch)."""
+    cfg = ra.synth.make_config('c2', nsites=nsites)
+    T, root, n = cfg['T'], cfg['root'], cfg['nstates']
+    dense = ra.synth.leaf_likelihoods(cfg)
+    dense[::97, 3, :] = 0.0              # some structurally impossible sites
+    model = ra.device.TreeModel(T, root, n)
+    model.set_rates(Q_default=cfg['Q_default'])
+    model.set_root_distn(cfg['root_distn'])
+    set_option = ra.lib.lib().rt_set_option
+    got = {}
+    try:
+        for jit in (0, 1):
+            ra.lib.check(set_option(b'jit', jit))
+            batch = model.upload_sites(cfg['leaves'], dense, kind='dense')
+            ll, st = model.log_likelihoods(batch)
+            assert ra.ctx.kernel_time(1)[2].startswith('prune_tree_jit' if jit else 'prune_lane')
+            tots = [model.fetch_totals(batch)]
+            for _ in range(6):
+                model.step(batch)
+                tots.append(model.fetch_totals(batch))
+            for t in tots[1:]:
+                np.testing.assert_array_equal(t, tots[0])
+            twin = batch.clone()
+            ll2, st2 = model.log_likelihoods(twin)
+            np.testing.assert_array_equal(model.fetch_totals(twin), tots[0])
+            np.testing.assert_array_equal(ll2, ll)
+            got[jit] = (ll, st, tots[0])
+    finally:
+        ra.lib.check(set_option(b'jit', -1))
+    np.testing.assert_array_equal(got[0][0], got[1][0])
+    np.testing.assert_array_equal(got[0][1], got[1][1])
+    ll, st, tot = got[1]
+    nz = int(((st & 1) != 0).sum())
+    assert nz == len(range(0, nsites, 97)) and tot[1] == nz and tot[2] == nsites
+    assert tot[0] == pytest.approx(ll[(st & 1) == 0].sum(), rel=1e-12)
+    assert got[0][2][0] == pytest.approx(tot[0], rel=1e-13) and got[0][2][1] == nz
+
+
 # ---------------------------------------------------------------------------
 # full BASELINE sizes: oracle on everything it can finish in seconds +
 # size-independent properties
