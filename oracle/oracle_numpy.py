@@ -439,6 +439,54 @@ def mjp_dense_get_likelihood(T, node_to_allowed_states, root, nstates,
         root_distn=root_distn, P_default=None)
 
 
+def mjp_dense_get_expected_history_statistics(T, node_to_allowed_states, root, nstates,
+                                              root_distn=None, Q_default=None):
+    """Expected dwell time per state, posterior root distribution and expected
+    transition counts of one site: raoteh/sampler/_mjp_dense.py:410-539 (sparse twin
+    _mjp.py:431-595).  Per edge, with J the joint endpoint posterior and P the
+    transition matrix, every state c contributes sum_{a,b: J[a,b] != 0}
+    J[a,b] * L(tQ, t E_cc)[a,b] / P[a,b] to its dwell time and every pair (c, d)
+    with Q[c,d] != 0 (the dense reference includes c == d) the same sum with
+    E_cd, times Q[c,d], to its transition count; L is scipy's expm_frechet, one
+    call per (c, d) as in the reference.  Returns (dwell f64[n], root posterior
+    f64[n], transitions f64[n,n]) -- the reference's dict / nx.DiGraph hold the
+    same numbers."""
+    if root not in T:
+        raise ValueError('the specified root is not in the tree')
+    n = nstates
+    preorder_nodes, indices, indptr, esd = get_expm_augmented_transitions(
+        T, root, n, Q_default=Q_default)
+    mask = define_state_mask(node_to_allowed_states, preorder_nodes, n)
+    _, pmap = esd_get_node_to_pmap(indices, indptr, esd, mask)
+    distn = mc0_esd_get_node_to_distn(indices, indptr, esd, root_distn, pmap)
+    J = mc0_esd_get_joint_endpoint_distn(indices, indptr, esd, pmap, distn)
+    index = dict((v, i) for i, v in enumerate(preorder_nodes))
+    dwell = np.zeros(n)
+    trans = np.zeros((n, n))
+    for na, nb in nx.bfs_edges(T, root):
+        edge = T[na][nb]
+        Q = np.asarray(edge.get('Q', Q_default), dtype=float)
+        check_square_dense(Q)
+        t = edge['weight']
+        Pe, Je = esd[index[nb]], J[index[nb]]
+        live = Je != 0
+        ratio = np.zeros((n, n))
+        ratio[live] = Je[live] / Pe[live]
+        for c in range(n):
+            for d in range(n):
+                if c != d and not Q[c, d]:
+                    continue
+                C = np.zeros((n, n))
+                C[c, d] = 1.0
+                interact = scipy.linalg.expm_frechet(t * Q, t * C, compute_expm=False)
+                total = float(np.sum(ratio[live] * interact[live]))
+                if c == d:
+                    dwell[c] += total
+                if Q[c, d]:
+                    trans[c, d] += Q[c, d] * total
+    return dwell, distn[0], trans
+
+
 # ---------------------------------------------------------------------------
 # batched forms (vectorised over sites) used by the parity tests and the
 # "amortised" CPU baseline

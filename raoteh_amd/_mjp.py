@@ -2,7 +2,7 @@
 Continuous-time front end, SPARSE API: rate matrices are weighted nx.DiGraph
 objects without self loops (the diagonal is implied), as in
 raoteh/sampler/_mjp.py (get_expm_augmented_tree :349-381, get_likelihood
-:384-428) and raoteh/sampler/_linalg.py (sparse_expm :31-39,
+:384-428, get_expected_history_statistics :431-595) and raoteh/sampler/_linalg.py (sparse_expm :31-39,
 sparse_expm_naive :72-90).
 
 Per edge: densify Q over ``sorted(Q)``, diagonal = -row sum (_linalg.py:73-81),
@@ -26,7 +26,8 @@ from . import _mcy
 from ._sparse import digraph_to_dense, dense_to_digraph
 from .device import get_context
 
-__all__ = ['sparse_expm', 'get_expm_augmented_tree', 'get_likelihood']
+__all__ = ['sparse_expm', 'get_expm_augmented_tree', 'get_likelihood',
+           'get_expected_history_statistics']
 
 
 def _dense_rate_matrix(Q):
@@ -96,3 +97,63 @@ def get_likelihood(T, node_to_allowed_states, root, root_distn=None,
     return _mcy.get_likelihood(T_aug, root,
                                node_to_allowed_states=node_to_allowed_states,
                                root_distn=root_distn, P_default=None)
+
+
+def get_expected_history_statistics(T, node_to_allowed_states, root,
+                                    root_distn=None, Q_default=None):
+    """_mjp.py:431-595: (dict state -> expected dwell time, dict state ->
+    posterior root probability, nx.DiGraph of expected transition counts on the
+    edges of the rate matrices).  The state space is the sorted union of the
+    nodes of Q_default and of the edge-specific matrices (:479-487); everything
+    numerical is the dense path (_mjp_dense.get_expected_history_statistics,
+    one Frechet block exponential per edge on the device).  The reference's
+    closed forms for its 3-state "simple" matrices (_linalg.py:92-118, absent
+    pyfelscore) are the same Frechet derivatives."""
+    from . import _mjp_dense
+    if root not in T:
+        raise ValueError('the specified root is not in the tree')
+    full_state_set = set()
+    if Q_default is not None:
+        full_state_set.update(Q_default)
+    for na, nb in nx.bfs_edges(T, root):
+        Q = T[na][nb].get('Q', None)
+        if Q is not None:
+            full_state_set.update(Q)
+    states = sorted(full_state_set)
+    index = dict((s, i) for i, s in enumerate(states))
+    nstates = len(states)
+
+    def densify(Q):
+        D = digraph_to_dense(Q, states)
+        np.fill_diagonal(D, 0.0)
+        return D - np.diag(np.sum(D, axis=1))
+    dense_of = {}
+    T_dense = nx.Graph()
+    T_dense.add_nodes_from(T)
+    for na, nb in nx.bfs_edges(T, root):
+        edge = T[na][nb]
+        Q = edge.get('Q', Q_default)
+        if Q is None:
+            raise ValueError('no rate matrix is available for this edge')
+        if id(Q) not in dense_of:
+            dense_of[id(Q)] = densify(Q)
+        T_dense.add_edge(na, nb, weight=edge['weight'], Q=dense_of[id(Q)])
+    allowed = dict((v, set(index[s] for s in ss if s in index))
+                   for v, ss in node_to_allowed_states.items())
+    for v in T:
+        allowed.setdefault(v, set(range(nstates)))
+    distn = None
+    if root_distn is not None:
+        distn = np.zeros(nstates)
+        for s, p in root_distn.items():
+            if s in index:
+                distn[index[s]] = p
+    dwell, init, trans = _mjp_dense.get_expected_history_statistics(
+        T_dense, allowed, root, nstates, root_distn=distn)
+    expected_transitions = nx.DiGraph()
+    for c, d, dat in trans.edges(data=True):
+        if c != d:                      # sparse rate matrices carry no diagonal
+            expected_transitions.add_edge(states[c], states[d], weight=dat['weight'])
+    return (dict((states[c], x) for c, x in dwell.items()),
+            dict((states[i], float(p)) for i, p in enumerate(init) if p),
+            expected_transitions)

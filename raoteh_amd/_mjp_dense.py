@@ -6,12 +6,16 @@ entry points with the reference's names, argument order and exceptions:
   get_expm_augmented_tree(T, root, Q_default)    raoteh/sampler/_mjp_dense.py:328-359
   get_likelihood(T, node_to_allowed_states, root, nstates, root_distn, Q_default)
                                                  raoteh/sampler/_mjp_dense.py:362-407
+  get_expected_history_statistics(T, node_to_allowed_states, root, nstates,
+                                  root_distn, Q_default)
+                                                 raoteh/sampler/_mjp_dense.py:410-539
 
 plus the batched forms the reference lacks (it loops over sites in Python,
 examples/p53/p53.py:88-100):
 
   get_log_likelihoods(T, root, nstates, obs_nodes, data, kind, ...)
   get_total_log_likelihood(...)
+  get_expected_history_statistics_batch(T, root, nstates, sites, ...)
 
 Everything numerical runs in hand-written HIP kernels behind the C ABI.
 """
@@ -20,11 +24,12 @@ from __future__ import annotations
 import networkx as nx
 import numpy as np
 
-from . import _mcy_dense
-from ._tree import check_square_dense
+from . import _mc0_dense, _mcy_dense
+from ._tree import TreeArrays, check_square_dense
 from .device import TreeModel, get_context
 
 __all__ = ['custom_expm', 'get_expm_augmented_tree', 'get_likelihood',
+           'get_expected_history_statistics', 'get_expected_history_statistics_batch',
            'get_log_likelihoods', 'get_total_log_likelihood',
            'allowed_states_to_masks']
 
@@ -132,3 +137,138 @@ def get_total_log_likelihood(T, root, nstates, obs_nodes, data, kind='dense',
     model, batch = _build(T, root, nstates, obs_nodes, data, kind, root_distn,
                           Q_default, model)
     return model.total_log_likelihood(batch)[0]
+
+
+# ---------------------------------------------------------------------------
+# expected history statistics (reference :410-539)
+# ---------------------------------------------------------------------------
+#
+# The reference calls scipy.linalg.expm_frechet n + nnz(Q) times per edge, once
+# per direction E_cd, and contracts each result with W = J / P (J the joint
+# endpoint posterior, P the transition matrix, over the entries with J != 0).
+# The same numbers come from ONE Frechet derivative per edge, by the adjoint
+# identity <W, L(A, E)> = <L(A^T, W), E>:
+#     M = L(t Q^T, W)      dwell[c] += t M[c, c]      trans[c, d] += t Q[c, d] M[c, d]
+# and L(A, W) is the upper right block of expm([[A, W], [0, A]]) -- a 2n x 2n
+# matrix exponential per edge, all edges in one launch of the expm kernel
+# (csrc/expm.hip), W scaled to unit size first so that it does not drive the
+# scaling-and-squaring of the block.
+
+def _frechet_contractions(ctx, Qs, ts, Ws):
+    """M[e] = L(ts[e] * Qs[e]^T, Ws[e]) for every edge, on the device."""
+    E, n = Ws.shape[0], Ws.shape[1]
+    if 2 * n > 64:
+        raise ValueError('expected history statistics need the expm kernel at order 2n = '
+                         '%d; it covers order <= 64' % (2 * n))
+    scale = np.abs(Ws).reshape(E, -1).max(axis=1)
+    scale[scale == 0] = 1.0
+    blocks = np.zeros((E, 2 * n, 2 * n), dtype=np.float64)
+    for e in range(E):
+        A = ts[e] * Qs[e].T
+        blocks[e, :n, :n] = A
+        blocks[e, n:, n:] = A
+        blocks[e, :n, n:] = Ws[e] / scale[e]
+    out = ctx.expm(blocks, np.ones(E))
+    return out[:, :n, n:] * scale[:, None, None]
+
+
+def _edge_rates(T, root, Q_default):
+    edges = list(nx.bfs_edges(T, root))
+    Qs, ts = [], []
+    for na, nb in edges:
+        Q = T[na][nb].get('Q', Q_default)
+        check_square_dense(Q)
+        Qs.append(np.asarray(Q, dtype=np.float64))
+        ts.append(float(T[na][nb]['weight']))
+    return edges, Qs, np.array(ts)
+
+
+def _accumulate(nstates, Qs, ts, M):
+    dwell = np.zeros(nstates)
+    trans = np.zeros((nstates, nstates))
+    for e, Q in enumerate(Qs):
+        dwell += ts[e] * np.diag(M[e])
+        trans += np.where(Q != 0, ts[e] * Q * M[e], 0.0)
+    return dwell, trans
+
+
+def get_expected_history_statistics(T, node_to_allowed_states, root, nstates,
+                                    root_distn=None, Q_default=None):
+    """One site, as the reference (:410-539): returns (dict state -> expected dwell
+    time, posterior root distribution as a 1d ndarray, nx.DiGraph whose edge
+    (c, d) carries the expected number of c -> d transitions as ``weight`` for
+    every nonzero Q[c, d] of some edge, the diagonal included as in the
+    reference).  expm, the upward passes, the downward pass, the joint endpoint
+    distributions and the Frechet block exponentials run on the device."""
+    if root not in T:
+        raise ValueError('the specified root is not in the tree')
+    T_aug = get_expm_augmented_tree(T, root, Q_default=Q_default)
+    node_to_pmap = _mcy_dense.get_node_to_pmap(
+        T_aug, root, nstates, node_to_allowed_states=node_to_allowed_states)
+    node_to_distn = _mc0_dense.get_node_to_distn(
+        T_aug, root, node_to_pmap, nstates, root_distn=root_distn)
+    T_joint = _mc0_dense.get_joint_endpoint_distn(
+        T_aug, root, node_to_pmap, node_to_distn, nstates)
+    edges, Qs, ts = _edge_rates(T, root, Q_default)
+    Ws = np.zeros((len(edges), nstates, nstates))
+    for e, (na, nb) in enumerate(edges):
+        J, P = T_joint[na][nb]['J'], T_aug[na][nb]['P']
+        live = J != 0
+        Ws[e][live] = J[live] / P[live]
+    dwell, trans = np.zeros(nstates), np.zeros((nstates, nstates))
+    if edges:
+        M = _frechet_contractions(get_context(), Qs, ts, Ws)
+        dwell, trans = _accumulate(nstates, Qs, ts, M)
+    expected_transitions = nx.DiGraph()
+    for Q in Qs:
+        for c, d in zip(*np.nonzero(Q)):
+            if not expected_transitions.has_edge(int(c), int(d)):
+                expected_transitions.add_edge(int(c), int(d), weight=float(trans[c, d]))
+    return (dict((c, float(dwell[c])) for c in range(nstates)),
+            node_to_distn[root], expected_transitions)
+
+
+def get_expected_history_statistics_batch(T, root, nstates, sites, root_distn=None,
+                                          Q_default=None, weights=None):
+    """Sum over sites of the reference's per-site statistics (what an EM step over
+    an alignment needs; the reference loops over sites in Python): ``sites`` is a
+    list of node_to_allowed_states dicts.  Returns (dwell f64[n], summed root
+    posteriors f64[n], transitions f64[n, n]).  The batched passes give every
+    site's joint endpoint posteriors; their site sum enters ONE Frechet block
+    exponential per edge, whatever the number of sites.  ``weights``: optional
+    per-site multiplicities (site patterns)."""
+    if root not in T:
+        raise ValueError('the specified root is not in the tree')
+    ctx = get_context()
+    T_aug = get_expm_augmented_tree(T, root, Q_default=Q_default)
+    ta = TreeArrays(T_aug, root)
+    esd = ta.esd_transitions(nstates)
+    nsites = len(sites)
+    # a node missing from a site's dict is unrestricted there
+    mask = np.ones((nsites, ta.nnodes, nstates), dtype=np.int64)
+    for k, node_to_allowed_states in enumerate(sites):
+        for i, v in enumerate(ta.preorder_nodes):
+            if node_to_allowed_states is not None and v in node_to_allowed_states:
+                allowed = node_to_allowed_states[v]
+                mask[k, i] = [1 if s in allowed else 0 for s in range(nstates)]
+    pmap = np.empty(mask.shape, dtype=np.float64)
+    ctx.passes(ta.indices, ta.indptr, esd, mask, pmap)
+    distn, status = ctx.node_to_distn(ta.indices, ta.indptr, esd, root_distn, pmap)
+    if status.any():
+        from ._util import NumericalZeroProb
+        raise NumericalZeroProb('the denominator is zero (site %d)'
+                                % int(np.nonzero(status)[0][0]))
+    J = ctx.joint_endpoint_distn(ta.indices, ta.indptr, esd, pmap, distn)
+    w = np.ones(nsites) if weights is None else np.asarray(weights, dtype=np.float64)
+    edges, Qs, ts = _edge_rates(T, root, Q_default)
+    Ws = np.zeros((len(edges), nstates, nstates))
+    for e, (na, nb) in enumerate(edges):
+        i = ta.node_to_index[nb]
+        Je, P = J[:, i], esd[i]
+        ratio = np.where(Je != 0, Je / np.where(P != 0, P, 1.0), 0.0)
+        Ws[e] = np.tensordot(w, ratio, axes=(0, 0))
+    dwell, trans = np.zeros(nstates), np.zeros((nstates, nstates))
+    if edges:
+        M = _frechet_contractions(ctx, Qs, ts, Ws)
+        dwell, trans = _accumulate(nstates, Qs, ts, M)
+    return dwell, np.tensordot(w, distn[:, 0], axes=(0, 0)), trans

@@ -57,6 +57,36 @@ def config_from_golden(fx):
     return T, root, n, Q_default, np.array(fx['root_distn']), sites
 
 
+def expectation_cases():
+    """tests/golden/expectations.json -> list of (label, T, allowed, root, nstates,
+    root_distn or None, Q_default, want) with want = dict(dwell, init, trans
+    [, closed_form_dwell]) as produced by the reference (tools/gen_golden.py)."""
+    fx = load_golden('expectations')
+    out = []
+    jc = fx['jukes_cantor']
+    n = jc['nstates']
+    Q = np.array(jc['Q'])
+    for r in jc['rows']:
+        T = tree_from_edges(jc['edges'])
+        allowed = dict((v, set(range(n))) for v in T)
+        allowed[0] = {r['a']}
+        allowed[4] = {r['b']}
+        out.append(('jc a=%d b=%d root=%d' % (r['a'], r['b'], r['root']), T, allowed,
+                    r['root'], n, None, Q, r))
+    for k, c in enumerate(fx['cases']):
+        n = c['nstates']
+        mats = [np.array(m) for m in c['Q']]
+        T = nx.Graph()
+        for a, b, w, q in c['edges']:
+            T.add_edge(int(a), int(b), weight=float(w))
+            if q:
+                T[int(a)][int(b)]['Q'] = mats[q]
+        allowed = dict((int(v), set(ss)) for v, ss in c['allowed'].items())
+        out.append(('case %d' % k, T, allowed, c['root'], n, np.array(c['root_distn']),
+                    mats[0], c))
+    return out
+
+
 @pytest.fixture(scope='session')
 def golden():
     return load_golden

@@ -17,7 +17,7 @@ import networkx as nx
 import numpy as np
 import pytest
 
-from conftest import load_golden, tree_from_edges, config_from_golden
+from conftest import expectation_cases, load_golden, tree_from_edges, config_from_golden
 from oracle import oracle_numpy as orc
 
 pytestmark = pytest.mark.gpu
@@ -648,6 +648,112 @@ def test_underflow_is_reported_not_hidden(ra):
                                           ra.synth.one_hot(states, n), pi)
     np.testing.assert_array_equal(st, wst)
     assert wst.all() and np.all(np.isneginf(ll))
+
+
+def test_expected_history_statistics(ra):
+    """_mjp_dense.get_expected_history_statistics (:410-539) and its sparse twin
+    (_mjp.py:431-595) on the device -- one Frechet block exponential per edge by
+    the adjoint identity -- against the reference's own outputs, the Jukes-Cantor
+    closed form of tests/test_mjp.py:166-237, and the oracle's restatement (which
+    calls scipy's expm_frechet once per direction, as the reference does)."""
+    from raoteh_amd import _mjp, _mjp_dense
+    worst = 0.0
+    for label, T, allowed, root, n, distn, Q, want in expectation_cases():
+        dwell, init, trans = _mjp_dense.get_expected_history_statistics(
+            T, allowed, root, n, root_distn=distn, Q_default=Q)
+        got_dwell = np.array([dwell[c] for c in range(n)])
+        got_trans = np.zeros((n, n))
+        for c, d, dat in trans.edges(data=True):
+            got_trans[c, d] = dat['weight']
+        odwell, oinit, otrans = orc.mjp_dense_get_expected_history_statistics(
+            T, allowed, root, n, root_distn=distn, Q_default=Q)
+        off = ~np.eye(n, dtype=bool)
+        scale = np.abs(odwell).max()
+        np.testing.assert_allclose(got_dwell, want['dwell'], rtol=1e-10, atol=1e-13 * scale,
+                                   err_msg=label)
+        np.testing.assert_allclose(init, want['init'], rtol=1e-12, atol=1e-15, err_msg=label)
+        np.testing.assert_allclose(got_trans[off], np.array(want['trans'])[off], rtol=1e-10,
+                                   atol=1e-13 * scale, err_msg=label)
+        # the diagonal entries (dense reference only) against the oracle
+        np.testing.assert_allclose(got_trans, otrans, rtol=1e-10, atol=1e-13 * scale,
+                                   err_msg=label)
+        np.testing.assert_allclose(got_dwell, odwell, rtol=1e-10, atol=1e-13 * scale,
+                                   err_msg=label)
+        if 'closed_form_dwell' in want:
+            np.testing.assert_allclose(got_dwell, want['closed_form_dwell'], rtol=1e-10,
+                                       atol=1e-13 * scale, err_msg=label)
+        assert got_dwell.sum() == pytest.approx(
+            sum(d['weight'] for _, _, d in T.edges(data=True)), rel=1e-10)
+        worst = max(worst, float(np.max(np.abs(got_dwell - odwell) / scale)))
+    assert worst < 1e-11
+
+    # sparse API: rate matrices as loop-free digraphs over arbitrary labels
+    labels = [7, 3, 40, 11, 25, 2]
+    for label, T, allowed, root, n, distn, Q, want in expectation_cases()[48:]:
+        lab = sorted(labels[:n])
+
+        def to_digraph(D):
+            G = nx.DiGraph()
+            G.add_nodes_from(lab)
+            for i in range(n):
+                for j in range(n):
+                    if i != j and D[i, j]:
+                        G.add_edge(lab[i], lab[j], weight=float(D[i, j]))
+            return G
+        graphs = {}
+        Ts = nx.Graph()
+        for a, b, d in T.edges(data=True):
+            Ts.add_edge(a, b, weight=d['weight'])
+            if 'Q' in d:
+                graphs.setdefault(id(d['Q']), to_digraph(d['Q']))
+                Ts[a][b]['Q'] = graphs[id(d['Q'])]
+        sdwell, sinit, strans = _mjp.get_expected_history_statistics(
+            Ts, dict((v, set(lab[s] for s in ss)) for v, ss in allowed.items()), root,
+            root_distn=dict((lab[i], float(p)) for i, p in enumerate(distn)),
+            Q_default=to_digraph(Q))
+        np.testing.assert_allclose([sdwell[lab[c]] for c in range(n)], want['dwell'],
+                                   rtol=1e-10, err_msg=label)
+        np.testing.assert_allclose([sinit.get(lab[c], 0.0) for c in range(n)], want['init'],
+                                   rtol=1e-12, atol=1e-15, err_msg=label)
+        wt = np.array(want['trans'])
+        for c in range(n):
+            for d in range(n):
+                if c != d and wt[c, d]:
+                    assert strans[lab[c]][lab[d]]['weight'] == pytest.approx(wt[c, d], rel=1e-10)
+        assert strans.number_of_edges() == int(np.count_nonzero(wt))
+
+
+def test_expected_history_statistics_batch(ra):
+    """The batched form: the site sum of the reference's per-site statistics from
+    ONE Frechet block exponential per edge, with site-pattern weights."""
+    from raoteh_amd import _mjp_dense
+    rng = np.random.RandomState(8)
+    cfg = ra.synth.make_config('c2', nsites=12)
+    T, root, n = cfg['T'], cfg['root'], cfg['nstates']
+    sites = []
+    for row in cfg['leaf_states']:
+        d = dict((leaf, {int(s)}) for leaf, s in zip(cfg['leaves'], row))
+        sites.append(d)
+    sites[3][cfg['leaves'][5]] = {0, 2}              # an ambiguous leaf
+    w = rng.randint(1, 4, size=len(sites)).astype(float)
+    dwell, init, trans = _mjp_dense.get_expected_history_statistics_batch(
+        T, root, n, sites, root_distn=cfg['root_distn'], Q_default=cfg['Q_default'],
+        weights=w)
+    want_d, want_i, want_t = np.zeros(n), np.zeros(n), np.zeros((n, n))
+    full = [dict((v, set(range(n))) for v in T) for _ in sites]
+    for f, s in zip(full, sites):
+        f.update(s)
+    for k, f in enumerate(full):
+        od, oi, ot = orc.mjp_dense_get_expected_history_statistics(
+            T, f, root, n, root_distn=cfg['root_distn'], Q_default=cfg['Q_default'])
+        want_d += w[k] * od
+        want_i += w[k] * oi
+        want_t += w[k] * ot
+    np.testing.assert_allclose(dwell, want_d, rtol=1e-10)
+    np.testing.assert_allclose(init, want_i, rtol=1e-12)
+    np.testing.assert_allclose(trans, want_t, rtol=1e-10, atol=1e-12)
+    total = sum(d['weight'] for _, _, d in T.edges(data=True))
+    assert dwell.sum() == pytest.approx(total * w.sum(), rel=1e-10)
 
 
 @pytest.mark.parametrize('nsites', [100000, 400001, 3000])

@@ -10,7 +10,7 @@ import networkx as nx
 import numpy as np
 import pytest
 
-from conftest import load_golden, tree_from_edges, config_from_golden
+from conftest import load_golden, tree_from_edges, config_from_golden, expectation_cases
 from oracle import oracle_numpy as orc
 
 RTOL = 1e-12
@@ -191,3 +191,28 @@ def test_single_node_tree_and_errors():
         orc.mjp_dense_get_likelihood(T, {7: set()}, 7, 2, None, Q)
     with pytest.raises(ValueError):
         orc.mjp_dense_get_likelihood(T, {7: {0}}, 8, 2, None, Q)
+
+
+def test_expected_history_statistics():
+    """_mjp_dense.get_expected_history_statistics (:410-539) restated in the oracle
+    against the reference's own outputs (its sparse twin, _mjp.py:431-595, which
+    tests/test_mjp.py:166-237 pins the dense one to) and against the Jukes-Cantor
+    closed form that test uses as the known answer."""
+    cases = expectation_cases()
+    assert len(cases) >= 50
+    for label, T, allowed, root, n, distn, Q, want in cases:
+        dwell, init, trans = orc.mjp_dense_get_expected_history_statistics(
+            T, allowed, root, n, root_distn=distn, Q_default=Q)
+        np.testing.assert_allclose(dwell, want['dwell'], rtol=1e-10, atol=1e-14,
+                                   err_msg=label)
+        np.testing.assert_allclose(init, want['init'], rtol=1e-12, atol=1e-15,
+                                   err_msg=label)
+        off = ~np.eye(n, dtype=bool)
+        np.testing.assert_allclose(trans[off], np.array(want['trans'])[off], rtol=1e-10,
+                                   atol=1e-14, err_msg=label)
+        if 'closed_form_dwell' in want:
+            np.testing.assert_allclose(dwell, want['closed_form_dwell'], rtol=1e-10,
+                                       atol=1e-14, err_msg=label)
+        # dwell times add up to the tree length whatever the data
+        assert dwell.sum() == pytest.approx(
+            sum(d['weight'] for _, _, d in T.edges(data=True)), rel=1e-10)

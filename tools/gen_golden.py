@@ -453,6 +453,145 @@ def fixture_sparse_api(mods, ncases=16):
     return dict(cases=cases)
 
 
+def _reference_mjp(mods):
+    """raoteh.sampler._mjp with the two harness adaptations the other fixtures use:
+    _linalg's nx.all_pairs_shortest_path_length returns a dict (networkx >= 2
+    hands back an iterator), and _mcy.get_node_to_pmap -- whose published body
+    calls the absent pyfelscore -- is the reference's own unaccelerated twins
+    (ref_type_y: _mcy.py:396-470, _mc0.py:89-138, _mcy.py:611-682)."""
+    _linalg = importlib.import_module('raoteh.sampler._linalg')
+    real_apspl = nx.all_pairs_shortest_path_length
+
+    class _NxShim(object):
+        def __getattr__(self, name):
+            return getattr(nx, name)
+        @staticmethod
+        def all_pairs_shortest_path_length(G):
+            return dict(real_apspl(G))
+    _linalg.nx = _NxShim()
+    _mjp = importlib.import_module('raoteh.sampler._mjp')
+
+    class _McyTwins(object):
+        def __getattr__(self, name):
+            return getattr(mods['_mcy'], name)
+        @staticmethod
+        def get_node_to_pmap(T, root, node_to_allowed_states=None,
+                             P_default=None, node_to_set=None):
+            return ref_type_y(mods, T, root, node_to_allowed_states)[2]
+    _mjp._mcy = _McyTwins()
+    return _mjp
+
+
+def _expectation_record(info, n):
+    dwell, init, trans = info
+    M = np.zeros((n, n))
+    for sa, sb, dat in trans.edges(data=True):
+        M[sa, sb] = dat['weight']
+    return dict(dwell=[float(dwell.get(s, 0.0)) for s in range(n)],
+                init=[float(init.get(s, 0.0)) for s in range(n)],
+                trans=M.tolist())
+
+
+def fixture_expectations(mods, ncases=10):
+    """Expected history statistics (dwell time per state, posterior root
+    distribution, expected transition counts) from the reference's
+    _mjp.get_expected_history_statistics (raoteh/sampler/_mjp.py:431-595; the
+    dense twin _mjp_dense.py:410-539 is pinned to it by tests/test_mjp.py:166-237).
+     * 'jukes_cantor': the known-answer case of tests/test_mjp.py:166-237 -- a
+       5-node path, end states (a, b), every root; expected dwell times from the
+       closed form _conditional_expectation.py:25-47;
+     * 'cases': random trees, random (sparse-ish) rate matrices with two
+       edge-specific ones, allowed-state sets at the leaves, random root prior."""
+    ce = mods['_conditional_expectation']
+    _mjp = _reference_mjp(mods)
+    n = 4
+    t = 0.5
+    T = nx.Graph()
+    for k, f in enumerate((0.1, 0.2, 0.3, 0.4)):
+        T.add_edge(k, k + 1, weight=f * t)
+    Q = ce.get_jukes_cantor_rate_matrix(n)
+    jc = []
+    for a in range(n):
+        for b in range(n):
+            allowed = dict((v, set(range(n))) for v in T)
+            allowed[0] = {a}
+            allowed[4] = {b}
+            closed = [ce.get_jukes_cantor_interaction(a, b, i, i, t, n) /
+                      ce.get_jukes_cantor_probability(a, b, t, n) for i in range(n)]
+            for root in (0, 2, 4):
+                info = _mjp.get_expected_history_statistics(
+                    T, allowed, root, Q_default=Q)
+                rec = _expectation_record(info, n)
+                rec.update(a=a, b=b, root=root, closed_form_dwell=closed)
+                jc.append(rec)
+    Qd = np.zeros((n, n))
+    for sa, sb, dat in Q.edges(data=True):
+        Qd[sa, sb] = dat['weight']
+    Qd -= np.diag(Qd.sum(axis=1))
+    jukes = dict(nstates=n, t=t, edges=edges_in_insertion_order(T), Q=Qd.tolist(),
+                 rows=jc)
+
+    rng = np.random.RandomState(97531)
+    cases = []
+    for case in range(ncases):
+        n = int(rng.randint(4, 7))
+        nnodes = int(rng.randint(4, 10))
+        T = nx.Graph()
+        T.add_node(0)
+        for k in range(1, nnodes):
+            T.add_edge(int(rng.randint(k)), k, weight=float(rng.uniform(0.05, 1.2)))
+        root = int(rng.randint(nnodes))
+
+        def random_rates():
+            R = rng.exponential(size=(n, n))
+            R[rng.uniform(size=(n, n)) < 0.2] = 0.0
+            np.fill_diagonal(R, 0.0)
+            for i in range(n):                   # a cycle keeps every state reachable
+                if R[i, (i + 1) % n] == 0:
+                    R[i, (i + 1) % n] = float(rng.uniform(0.2, 1.0))
+            return R
+        mats = [random_rates(), random_rates()]
+
+        def to_digraph(R):
+            G = nx.DiGraph()
+            G.add_nodes_from(range(n))
+            for i in range(n):
+                for j in range(n):
+                    if R[i, j]:
+                        G.add_edge(i, j, weight=float(R[i, j]))
+            return G
+        graphs = [to_digraph(R) for R in mats]
+        edge_q = {}
+        for na, nb in T.edges():
+            if rng.uniform() < 0.3:
+                T[na][nb]['Q'] = graphs[1]
+                edge_q[(na, nb)] = 1
+            else:
+                edge_q[(na, nb)] = 0
+        allowed = dict((v, set(range(n))) for v in T)
+        for v in T:
+            if T.degree(v) == 1 or rng.uniform() < 0.15:
+                k = int(rng.randint(1, 3))
+                allowed[v] = set(int(x) for x in rng.permutation(n)[:k])
+        w = rng.exponential(size=n)
+        w /= w.sum()
+        distn = dict((i, float(p)) for i, p in enumerate(w))
+        info = _mjp.get_expected_history_statistics(
+            T, allowed, root, root_distn=distn, Q_default=graphs[0])
+        rec = _expectation_record(info, n)
+        dense = []
+        for R in mats:
+            D = R.copy()
+            D -= np.diag(D.sum(axis=1))
+            dense.append(D.tolist())
+        rec.update(nstates=n, root=root, root_distn=w.tolist(),
+                   edges=[[int(a), int(b), float(d['weight']), edge_q[(a, b)]]
+                          for a, b, d in T.edges(data=True)],
+                   Q=dense, allowed=set_json(allowed))
+        cases.append(rec)
+    return dict(jukes_cantor=jukes, cases=cases)
+
+
 def fixture_p53_mg94(mods):
     """The MG94 codon rate matrix the reference's p53 example builds
     (examples/p53/create_mg94.py:23-142 called as examples/p53/p53.py:44-47) on the
@@ -584,6 +723,7 @@ def main():
         random_sparse=fixture_random_sparse(mods),
         sparse_api=fixture_sparse_api(mods),
         p53_mg94=fixture_p53_mg94(mods),
+        expectations=fixture_expectations(mods),
         expm=fixture_expm(mods),
         config_c1=fixture_config(mods, 'c1', 4, with_pmap=True),
         config_c2=fixture_config(mods, 'c2', 6),
