@@ -228,29 +228,51 @@ def get_expected_history_statistics(T, node_to_allowed_states, root, nstates,
             node_to_distn[root], expected_transitions)
 
 
-def get_expected_history_statistics_batch(T, root, nstates, sites, root_distn=None,
-                                          Q_default=None, weights=None):
+def get_expected_history_statistics_batch(T, root, nstates, sites=None, root_distn=None,
+                                          Q_default=None, weights=None,
+                                          obs_nodes=None, data=None, kind='state'):
     """Sum over sites of the reference's per-site statistics (what an EM step over
     an alignment needs; the reference loops over sites in Python): ``sites`` is a
     list of node_to_allowed_states dicts.  Returns (dwell f64[n], summed root
     posteriors f64[n], transitions f64[n, n]).  The batched passes give every
     site's joint endpoint posteriors; their site sum enters ONE Frechet block
     exponential per edge, whatever the number of sites.  ``weights``: optional
-    per-site multiplicities (site patterns)."""
+    per-site multiplicities (site patterns).  Instead of ``sites``, the array form
+    of get_log_likelihoods: ``obs_nodes`` + ``data`` [nsites, len(obs_nodes)] of
+    states (kind='state', a value >= nstates = unobserved) or allowed-set bit masks
+    (kind='mask')."""
     if root not in T:
         raise ValueError('the specified root is not in the tree')
     ctx = get_context()
     T_aug = get_expm_augmented_tree(T, root, Q_default=Q_default)
     ta = TreeArrays(T_aug, root)
     esd = ta.esd_transitions(nstates)
-    nsites = len(sites)
-    # a node missing from a site's dict is unrestricted there
-    mask = np.ones((nsites, ta.nnodes, nstates), dtype=np.int64)
-    for k, node_to_allowed_states in enumerate(sites):
-        for i, v in enumerate(ta.preorder_nodes):
-            if node_to_allowed_states is not None and v in node_to_allowed_states:
-                allowed = node_to_allowed_states[v]
-                mask[k, i] = [1 if s in allowed else 0 for s in range(nstates)]
+    if sites is not None:
+        nsites = len(sites)
+        # a node missing from a site's dict is unrestricted there
+        mask = np.ones((nsites, ta.nnodes, nstates), dtype=np.int64)
+        for k, node_to_allowed_states in enumerate(sites):
+            for i, v in enumerate(ta.preorder_nodes):
+                if node_to_allowed_states is not None and v in node_to_allowed_states:
+                    allowed = node_to_allowed_states[v]
+                    mask[k, i] = [1 if s in allowed else 0 for s in range(nstates)]
+    else:
+        data = np.asarray(data)
+        if data.ndim != 2 or data.shape[1] != len(obs_nodes):
+            raise ValueError('data must be [nsites, len(obs_nodes)]')
+        nsites = data.shape[0]
+        mask = np.ones((nsites, ta.nnodes, nstates), dtype=np.int64)
+        cols = [ta.node_to_index[v] for v in obs_nodes]
+        states = np.arange(nstates)
+        if kind == 'state':
+            d = data.astype(np.int64)[:, :, None]
+            mask[:, cols, :] = (d == states) | (d >= nstates)
+        elif kind == 'mask':
+            if nstates > 62:
+                raise ValueError('bit masks hold at most 62 states')
+            mask[:, cols, :] = (data.astype(np.int64)[:, :, None] >> states) & 1
+        else:
+            raise ValueError("kind must be 'state' or 'mask'")
     pmap = np.empty(mask.shape, dtype=np.float64)
     ctx.passes(ta.indices, ta.indptr, esd, mask, pmap)
     distn, status = ctx.node_to_distn(ta.indices, ta.indptr, esd, root_distn, pmap)

@@ -754,6 +754,23 @@ def test_expected_history_statistics_batch(ra):
     np.testing.assert_allclose(trans, want_t, rtol=1e-10, atol=1e-12)
     total = sum(d['weight'] for _, _, d in T.edges(data=True))
     assert dwell.sum() == pytest.approx(total * w.sum(), rel=1e-10)
+    # the array form of the same batch (allowed-set bit masks per leaf)
+    masks = (1 << cfg['leaf_states'].astype(np.int64))
+    masks[3, 5] = 0b0101
+    d2, i2, t2 = _mjp_dense.get_expected_history_statistics_batch(
+        T, root, n, root_distn=cfg['root_distn'], Q_default=cfg['Q_default'], weights=w,
+        obs_nodes=cfg['leaves'], data=masks, kind='mask')
+    np.testing.assert_array_equal(d2, dwell)
+    np.testing.assert_array_equal(i2, init)
+    np.testing.assert_array_equal(t2, trans)
+    states = cfg['leaf_states'].copy()
+    d3, _, _ = _mjp_dense.get_expected_history_statistics_batch(
+        T, root, n, root_distn=cfg['root_distn'], Q_default=cfg['Q_default'],
+        obs_nodes=cfg['leaves'], data=states, kind='state')
+    sites[3][cfg['leaves'][5]] = {int(states[3, 5])}
+    d4, _, _ = _mjp_dense.get_expected_history_statistics_batch(
+        T, root, n, sites, root_distn=cfg['root_distn'], Q_default=cfg['Q_default'])
+    np.testing.assert_array_equal(d3, d4)
 
 
 @pytest.mark.parametrize('nsites', [100000, 400001, 3000])
