@@ -160,6 +160,21 @@ int rt_mc0_esd_get_joint_endpoint_distn(rt_ctx *ctx, int64_t nnodes, int64_t n,
             const double *subtree_probability, const double *node_to_distn_array,
             double *joint_distns);
 
+/* Site sums for _mjp_dense.get_expected_history_statistics (_mjp_dense.py:458-475,
+ * 497-533): the upward passes (:261-291 of _mcy_dense.py), the downward pass
+ * (mc0_esd_get_node_to_distn) and, per edge, the site sum of J / P over the nonzero
+ * entries of the joint endpoint posterior J (what the reference contracts with its
+ * Frechet derivatives, one site at a time) in one call; only n*n numbers per edge
+ * leave the device.  state_mask int64[nsites][nnodes][n] as for the passes (input
+ * only), site_weights f64[nsites] or NULL (= ones), root_distn f64[n] or NULL.
+ * edge_weights f64[nnodes][n][n] out, keyed by the child index; slot 0 carries the
+ * weighted sum of the root posteriors in its column 0.  status as above.        */
+int rt_mjp_esd_expectation_weights(rt_ctx *ctx, int64_t nnodes, int64_t n,
+            int64_t nsites, const int64_t *tree_csr_indices,
+            const int64_t *tree_csr_indptr, const double *esd_transitions,
+            const double *root_distn, const int64_t *state_mask,
+            const double *site_weights, double *edge_weights, int32_t *status);
+
 /* ---- 2. batched, device-resident hot path --------------------------------
  * _mjp_dense.get_likelihood (_mjp_dense.py:362-407) for many sites:
  *   rt_model_create        tree (same CSR as above) -> device, schedule built

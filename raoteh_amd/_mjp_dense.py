@@ -235,8 +235,9 @@ def get_expected_history_statistics_batch(T, root, nstates, sites=None, root_dis
     an alignment needs; the reference loops over sites in Python): ``sites`` is a
     list of node_to_allowed_states dicts.  Returns (dwell f64[n], summed root
     posteriors f64[n], transitions f64[n, n]).  The batched passes give every
-    site's joint endpoint posteriors; their site sum enters ONE Frechet block
-    exponential per edge, whatever the number of sites.  ``weights``: optional
+    site's joint endpoint posteriors; their site sum (taken on the device,
+    rt_mjp_esd_expectation_weights) enters ONE Frechet block exponential per edge,
+    whatever the number of sites.  ``weights``: optional
     per-site multiplicities (site patterns).  Instead of ``sites``, the array form
     of get_log_likelihoods: ``obs_nodes`` + ``data`` [nsites, len(obs_nodes)] of
     states (kind='state', a value >= nstates = unobserved) or allowed-set bit masks
@@ -273,24 +274,21 @@ def get_expected_history_statistics_batch(T, root, nstates, sites=None, root_dis
             mask[:, cols, :] = (data.astype(np.int64)[:, :, None] >> states) & 1
         else:
             raise ValueError("kind must be 'state' or 'mask'")
-    pmap = np.empty(mask.shape, dtype=np.float64)
-    ctx.passes(ta.indices, ta.indptr, esd, mask, pmap)
-    distn, status = ctx.node_to_distn(ta.indices, ta.indptr, esd, root_distn, pmap)
+    w = None if weights is None else np.asarray(weights, dtype=np.float64)
+    # upward passes, downward pass and the per-edge site sums of J / P in one call;
+    # n*n numbers per edge come back, whatever the number of sites
+    W, root_post, status = ctx.expectation_weights(ta.indices, ta.indptr, esd, root_distn,
+                                                   mask, site_weights=w)
     if status.any():
         from ._util import NumericalZeroProb
         raise NumericalZeroProb('the denominator is zero (site %d)'
                                 % int(np.nonzero(status)[0][0]))
-    J = ctx.joint_endpoint_distn(ta.indices, ta.indptr, esd, pmap, distn)
-    w = np.ones(nsites) if weights is None else np.asarray(weights, dtype=np.float64)
     edges, Qs, ts = _edge_rates(T, root, Q_default)
     Ws = np.zeros((len(edges), nstates, nstates))
     for e, (na, nb) in enumerate(edges):
-        i = ta.node_to_index[nb]
-        Je, P = J[:, i], esd[i]
-        ratio = np.where(Je != 0, Je / np.where(P != 0, P, 1.0), 0.0)
-        Ws[e] = np.tensordot(w, ratio, axes=(0, 0))
+        Ws[e] = W[ta.node_to_index[nb]]
     dwell, trans = np.zeros(nstates), np.zeros((nstates, nstates))
     if edges:
         M = _frechet_contractions(ctx, Qs, ts, Ws)
         dwell, trans = _accumulate(nstates, Qs, ts, M)
-    return dwell, np.tensordot(w, distn[:, 0], axes=(0, 0)), trans
+    return dwell, root_post, trans

@@ -449,3 +449,154 @@ extern "C" int rt_mc0_esd_get_joint_endpoint_distn(rt_ctx *ctx, int64_t nnodes, 
                       subtree_probability, const_cast<double *>(node_to_distn_array),
                       joint_distns, nullptr);
 }
+
+// ---------------------------------------------------------------------------
+// Site sums for the expected history statistics (_mjp_dense.py:410-539).
+// Per edge (a -> b) the reference contracts J / P (J the joint endpoint posterior,
+// over its nonzero entries) with Frechet derivatives; with the quantities of the
+// downward pass
+//   J[sa,sb] / P[sa,sb] = (distn[a,sa] / den[sa]) * pmap[b,sb]        where P[sa,sb] != 0
+// an outer product per site, so the site sum W_b = sum_s w_s u_s (x) p_s (masked by
+// the pattern of P_b) is all that has to leave the device: n*n numbers per edge
+// instead of n*n per edge AND site.  upward passes -> downward pass -> these sums
+// run back to back on the arrays of one upload.
+// ---------------------------------------------------------------------------
+
+namespace {
+
+// grid (nnodes, G): block (c, g) adds the sites g, g + G, ... of edge (parent[c] -> c)
+// in that order; slot c = 0 carries the summed root posterior in its column 0
+__global__ void __launch_bounds__(256)
+ratio_sum_kernel(int nnodes, int n, int nsites, const int *__restrict__ parent,
+                 const double *__restrict__ esd, const double *__restrict__ pmap_all,
+                 const double *__restrict__ distn_all, const double *__restrict__ weights,
+                 double *__restrict__ part)
+{
+    __shared__ double Ps[RT_MAX_STATES * RT_MAX_STATES];
+    __shared__ double p[RT_MAX_STATES], u[RT_MAX_STATES];
+    const int c = blockIdx.x, g = blockIdx.y, G = gridDim.y, t = threadIdx.x;
+    const int nn = n * n;
+    constexpr int PER = RT_MAX_STATES * RT_MAX_STATES / 256;
+    double acc[PER];
+    int ea[PER], eb[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        acc[k] = 0.0;
+        const int e = t + 256 * k;
+        ea[k] = e < nn ? e / n : 0;
+        eb[k] = e < nn ? e % n : 0;
+    }
+    double *out = part + ((size_t)g * nnodes + c) * nn;
+    if (c == 0) {
+        double r = 0.0;
+        for (int s = g; s < nsites; s += G)
+            if (t < n) r = fma(weights ? weights[s] : 1.0, distn_all[(size_t)s * nnodes * n + t], r);
+        for (int e = t; e < nn; e += 256) out[e] = 0.0;
+        __syncthreads();
+        if (t < n) out[(size_t)t * n] = r;
+        return;
+    }
+    for (int e = t; e < nn; e += 256) Ps[e] = esd[(size_t)c * nn + e];
+    const int par = parent[c];
+    __syncthreads();
+    for (int s = g; s < nsites; s += G) {
+        const size_t base = (size_t)s * nnodes * n;
+        if (t < n) p[t] = pmap_all[base + (size_t)c * n + t];
+        __syncthreads();
+        if (t < n) {
+            const double pa = distn_all[base + (size_t)par * n + t];
+            double den = 0.0;
+            for (int b = 0; b < n; ++b) den = fma(Ps[t * n + b], p[b], den);
+            u[t] = (pa != 0.0 && den > 0.0) ? (weights ? weights[s] : 1.0) * pa / den : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PER; ++k) acc[k] = fma(u[ea[k]], p[eb[k]], acc[k]);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int e = t + 256 * k;
+        if (e < nn) out[e] = Ps[e] != 0.0 ? acc[k] : 0.0;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+sum_parts_kernel(int G, long count, const double *__restrict__ part, double *__restrict__ out)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    double s = 0.0;
+    for (int g = 0; g < G; ++g) s += part[(size_t)g * count + i];
+    out[i] = s;
+}
+
+}  // namespace
+
+extern "C" int rt_mjp_esd_expectation_weights(rt_ctx *ctx, int64_t nnodes, int64_t n,
+        int64_t nsites, const int64_t *idx, const int64_t *ptr, const double *esd,
+        const double *root_distn, const int64_t *state_mask, const double *site_weights,
+        double *edge_weights, int32_t *status)
+{
+    RT_REQUIRE(ctx, "null context");
+    RT_TRY(check_tree(nnodes, n, nsites, idx, ptr, esd));
+    RT_REQUIRE(edge_weights && (state_mask || nsites == 0), "null array");
+    RT_HIP(hipSetDevice(ctx->device));
+    const size_t nn = (size_t)n * n, wcount = (size_t)nnodes * nn;
+    if (nsites == 0) {
+        memset(edge_weights, 0, wcount * 8);
+        return RT_OK;
+    }
+    std::vector<int> parent((size_t)nnodes, 0);
+    for (int64_t v = 0; v < nnodes; ++v)
+        for (int64_t e = ptr[v]; e < ptr[v + 1]; ++e) parent[(size_t)idx[e]] = (int)v;
+    const int G = (int)std::min<int64_t>(nsites, 64);
+    const size_t bytes = (size_t)nsites * nnodes * n * 8;
+    const size_t ni = (size_t)(nnodes > 1 ? nnodes - 1 : 1);
+    scratch_plan plan;
+    const size_t o_idx = plan.take(ni * 8), o_ptr = plan.take((size_t)(nnodes + 1) * 8);
+    const size_t o_esd = plan.take(wcount * 8), o_par = plan.take((size_t)nnodes * 4);
+    const size_t o_mask = plan.take(bytes), o_pmap = plan.take(bytes), o_distn = plan.take(bytes);
+    const size_t o_root = plan.take((size_t)n * 8), o_w = plan.take((size_t)nsites * 8);
+    const size_t o_st = plan.take((size_t)nsites * 4);
+    const size_t o_part = plan.take((size_t)G * wcount * 8), o_out = plan.take(wcount * 8);
+    RT_TRY(scratch_reserve(ctx, plan.total));
+    unsigned char *base = ctx->d_scratch;
+    long *d_idx = (long *)(base + o_idx), *d_ptr = (long *)(base + o_ptr);
+    double *d_esd = (double *)(base + o_esd);
+    int *d_par = (int *)(base + o_par), *d_st = (int *)(base + o_st);
+    long *d_mask = (long *)(base + o_mask);
+    double *d_pmap = (double *)(base + o_pmap), *d_distn = (double *)(base + o_distn);
+    double *d_root = root_distn ? (double *)(base + o_root) : nullptr;
+    double *d_w = site_weights ? (double *)(base + o_w) : nullptr;
+    double *d_part = (double *)(base + o_part), *d_out = (double *)(base + o_out);
+    hipStream_t st = ctx->stream;
+    if (nnodes > 1)
+        RT_HIP(hipMemcpyAsync(d_idx, idx, (size_t)(nnodes - 1) * 8, hipMemcpyHostToDevice, st));
+    RT_HIP(hipMemcpyAsync(d_ptr, ptr, (size_t)(nnodes + 1) * 8, hipMemcpyHostToDevice, st));
+    RT_HIP(hipMemcpyAsync(d_esd, esd, wcount * 8, hipMemcpyHostToDevice, st));
+    RT_HIP(hipMemcpyAsync(d_par, parent.data(), (size_t)nnodes * 4, hipMemcpyHostToDevice, st));
+    RT_HIP(hipMemcpyAsync(d_mask, state_mask, bytes, hipMemcpyHostToDevice, st));
+    if (d_root) RT_HIP(hipMemcpyAsync(d_root, root_distn, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    if (d_w) RT_HIP(hipMemcpyAsync(d_w, site_weights, (size_t)nsites * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(pset_kernel, dim3((unsigned)nsites), dim3(64), 0, st, (int)nnodes,
+                       (int)n, d_idx, d_ptr, d_esd, d_mask);
+    hipLaunchKernelGGL(set_kernel, dim3((unsigned)nsites), dim3(64), 0, st, (int)nnodes,
+                       (int)n, d_idx, d_ptr, d_esd, d_mask);
+    hipLaunchKernelGGL(pmap_kernel, dim3((unsigned)nsites), dim3(64), 0, st, (int)nnodes,
+                       (int)n, d_idx, d_ptr, d_esd, d_mask, (const double *)nullptr, d_pmap);
+    hipLaunchKernelGGL(distn_kernel<false>, dim3((unsigned)nsites), dim3(64), 0, st,
+                       (int)nnodes, (int)n, d_idx, d_ptr, d_esd, d_root, d_pmap, d_distn,
+                       (double *)nullptr, d_st);
+    hipLaunchKernelGGL(ratio_sum_kernel, dim3((unsigned)nnodes, (unsigned)G), dim3(256), 0, st,
+                       (int)nnodes, (int)n, (int)nsites, d_par, d_esd, d_pmap, d_distn, d_w,
+                       d_part);
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((wcount + 255) / 256)), dim3(256), 0,
+                       st, G, (long)wcount, d_part, d_out);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipMemcpyAsync(edge_weights, d_out, wcount * 8, hipMemcpyDeviceToHost, st));
+    if (status) RT_HIP(hipMemcpyAsync(status, d_st, (size_t)nsites * 4, hipMemcpyDeviceToHost, st));
+    // parent.data() and the caller's arrays must outlive the copies
+    RT_HIP(hipStreamSynchronize(st));
+    return RT_OK;
+}

@@ -215,6 +215,31 @@ class Context(object):
             _ptr(out, c_double)))
         return out
 
+    def expectation_weights(self, indices, indptr, esd, root_distn, state_mask,
+                            site_weights=None):
+        """rt_mjp_esd_expectation_weights: upward passes + downward pass + per-edge
+        site sums of J / P on the device.  Returns (W f64[nnodes, n, n] keyed by the
+        child index, summed root posteriors f64[n], status int32[nsites])."""
+        state_mask = _i64(state_mask)
+        indices, indptr, esd, nnodes, n, nsites = self._pass_args(
+            indices, indptr, esd, state_mask)
+        rd = None if root_distn is None else _f64(root_distn)
+        if rd is not None and rd.shape != (n,):
+            raise ValueError('inconsistent root distribution')
+        w = None if site_weights is None else _f64(site_weights)
+        if w is not None and w.shape != (nsites,):
+            raise ValueError('one weight per site expected')
+        W = np.empty((nnodes, n, n), dtype=np.float64)
+        status = np.zeros(nsites, dtype=np.int32)
+        _lib.check(_lib.lib().rt_mjp_esd_expectation_weights(
+            self._h, nnodes, n, nsites, _ptr(indices, c_int64), _ptr(indptr, c_int64),
+            _ptr(esd, c_double), None if rd is None else _ptr(rd, c_double),
+            _ptr(state_mask, c_int64), None if w is None else _ptr(w, c_double),
+            _ptr(W, c_double), _ptr(status, c_int32)))
+        root_post = W[0, :, 0].copy()
+        W[0] = 0.0
+        return W, root_post, status
+
     # ---- multi-GPU ---------------------------------------------------------
 
     @staticmethod

@@ -763,6 +763,33 @@ def test_expected_history_statistics_batch(ra):
     np.testing.assert_array_equal(d2, dwell)
     np.testing.assert_array_equal(i2, init)
     np.testing.assert_array_equal(t2, trans)
+    # more sites than site chunks (the per-edge sums are taken by 64 chunks of sites):
+    # the device sums against J / P assembled on the host from the joint endpoint
+    # distributions of the reference-format pass (itself checked against the oracle)
+    from raoteh_amd._tree import TreeArrays
+    big = ra.synth.make_config('c2', nsites=333)
+    bmask = 1 << big['leaf_states'].astype(np.int64)
+    bmask[::7, 2] = 0b1010
+    bw = rng.uniform(0.5, 2.0, size=333)
+    T_aug = _mjp_dense.get_expm_augmented_tree(T, root, Q_default=cfg['Q_default'])
+    ta = TreeArrays(T_aug, root)
+    esd = ta.esd_transitions(n)
+    m3 = np.ones((333, ta.nnodes, n), dtype=np.int64)
+    cols = [ta.node_to_index[v] for v in big['leaves']]
+    m3[:, cols, :] = (bmask[:, :, None] >> np.arange(n)) & 1
+    W, rp, st = ra.ctx.expectation_weights(ta.indices, ta.indptr, esd, cfg['root_distn'],
+                                           m3.copy(), site_weights=bw)
+    assert not st.any()
+    pm = np.empty(m3.shape)
+    ra.ctx.passes(ta.indices, ta.indptr, esd, m3.copy(), pm)
+    dn, _ = ra.ctx.node_to_distn(ta.indices, ta.indptr, esd, cfg['root_distn'], pm)
+    J = ra.ctx.joint_endpoint_distn(ta.indices, ta.indptr, esd, pm, dn)
+    for i in range(1, ta.nnodes):
+        ratio = np.where(J[:, i] != 0, J[:, i] / np.where(esd[i] != 0, esd[i], 1.0), 0.0)
+        np.testing.assert_allclose(W[i], np.tensordot(bw, ratio, axes=(0, 0)), rtol=1e-12,
+                                   atol=1e-13)
+    np.testing.assert_allclose(rp, np.tensordot(bw, dn[:, 0], axes=(0, 0)), rtol=1e-13)
+    assert not W[0].any()
     states = cfg['leaf_states'].copy()
     d3, _, _ = _mjp_dense.get_expected_history_statistics_batch(
         T, root, n, root_distn=cfg['root_distn'], Q_default=cfg['Q_default'],
