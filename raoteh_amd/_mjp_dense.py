@@ -157,9 +157,9 @@ def get_total_log_likelihood(T, root, nstates, obs_nodes, data, kind='dense',
 def _frechet_contractions(ctx, Qs, ts, Ws):
     """M[e] = L(ts[e] * Qs[e]^T, Ws[e]) for every edge, on the device."""
     E, n = Ws.shape[0], Ws.shape[1]
-    if 2 * n > 64:
+    if 2 * n > 62:                      # RT_MAX_EXPM_STATES
         raise ValueError('expected history statistics need the expm kernel at order 2n = '
-                         '%d; it covers order <= 64' % (2 * n))
+                         '%d; it covers order <= 62' % (2 * n))
     scale = np.abs(Ws).reshape(E, -1).max(axis=1)
     scale[scale == 0] = 1.0
     blocks = np.zeros((E, 2 * n, 2 * n), dtype=np.float64)
