@@ -175,6 +175,18 @@ int rt_mjp_esd_expectation_weights(rt_ctx *ctx, int64_t nnodes, int64_t n,
             const double *root_distn, const int64_t *state_mask,
             const double *site_weights, double *edge_weights, int32_t *status);
 
+/* The same with the observations in the compact encodings of rt_sites_create instead
+ * of the reference's int64 mask array (8 n bytes per site and NODE): kind RT_OBS_STATE,
+ * data uint8[nsites][nobs] (a value >= n = unobserved), or RT_OBS_MASK, data
+ * uint64[nsites][nobs]; obs_nodes int64[nobs] are preorder indices, every other node
+ * is unrestricted.  The mask array is built on the device.                      */
+int rt_mjp_esd_expectation_weights_obs(rt_ctx *ctx, int64_t nnodes, int64_t n,
+            int64_t nsites, const int64_t *tree_csr_indices,
+            const int64_t *tree_csr_indptr, const double *esd_transitions,
+            const double *root_distn, int64_t nobs, const int64_t *obs_nodes, int kind,
+            const void *data, const double *site_weights, double *edge_weights,
+            int32_t *status);
+
 /* ---- 2. batched, device-resident hot path --------------------------------
  * _mjp_dense.get_likelihood (_mjp_dense.py:362-407) for many sites:
  *   rt_model_create        tree (same CSR as above) -> device, schedule built

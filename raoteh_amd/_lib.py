@@ -81,6 +81,10 @@ SIGNATURES = {
     'rt_mjp_esd_expectation_weights': (c_int, [c_void_p, c_int64, c_int64, c_int64,
                                                _p_i64, _p_i64, _p_f64, _p_f64, _p_i64,
                                                _p_f64, _p_f64, _p_i32]),
+    'rt_mjp_esd_expectation_weights_obs': (c_int, [c_void_p, c_int64, c_int64, c_int64,
+                                                   _p_i64, _p_i64, _p_f64, _p_f64, c_int64,
+                                                   _p_i64, c_int, c_void_p, _p_f64, _p_f64,
+                                                   _p_i32]),
     'rt_model_create': (c_int, [c_void_p, c_int64, c_int64, _p_i64, _p_i64,
                                 POINTER(c_void_p)]),
     'rt_model_destroy': (c_int, [c_void_p]),

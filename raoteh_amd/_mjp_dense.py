@@ -248,6 +248,9 @@ def get_expected_history_statistics_batch(T, root, nstates, sites=None, root_dis
     T_aug = get_expm_augmented_tree(T, root, Q_default=Q_default)
     ta = TreeArrays(T_aug, root)
     esd = ta.esd_transitions(nstates)
+    w = None if weights is None else np.asarray(weights, dtype=np.float64)
+    # upward passes, downward pass and the per-edge site sums of J / P in one call;
+    # n*n numbers per edge come back, whatever the number of sites
     if sites is not None:
         nsites = len(sites)
         # a node missing from a site's dict is unrestricted there
@@ -257,28 +260,21 @@ def get_expected_history_statistics_batch(T, root, nstates, sites=None, root_dis
                 if node_to_allowed_states is not None and v in node_to_allowed_states:
                     allowed = node_to_allowed_states[v]
                     mask[k, i] = [1 if s in allowed else 0 for s in range(nstates)]
+        W, root_post, status = ctx.expectation_weights(
+            ta.indices, ta.indptr, esd, root_distn, mask, site_weights=w)
     else:
+        # compact observations: one byte / one 64-bit set per site and observed node;
+        # the reference-format mask array is built on the device
         data = np.asarray(data)
         if data.ndim != 2 or data.shape[1] != len(obs_nodes):
             raise ValueError('data must be [nsites, len(obs_nodes)]')
-        nsites = data.shape[0]
-        mask = np.ones((nsites, ta.nnodes, nstates), dtype=np.int64)
-        cols = [ta.node_to_index[v] for v in obs_nodes]
-        states = np.arange(nstates)
         if kind == 'state':
-            d = data.astype(np.int64)[:, :, None]
-            mask[:, cols, :] = (d == states) | (d >= nstates)
-        elif kind == 'mask':
-            if nstates > 62:
-                raise ValueError('bit masks hold at most 62 states')
-            mask[:, cols, :] = (data.astype(np.int64)[:, :, None] >> states) & 1
-        else:
-            raise ValueError("kind must be 'state' or 'mask'")
-    w = None if weights is None else np.asarray(weights, dtype=np.float64)
-    # upward passes, downward pass and the per-edge site sums of J / P in one call;
-    # n*n numbers per edge come back, whatever the number of sites
-    W, root_post, status = ctx.expectation_weights(ta.indices, ta.indptr, esd, root_distn,
-                                                   mask, site_weights=w)
+            data = np.where((data < 0) | (data >= min(nstates, 255)), 255, data).astype(np.uint8)
+            if nstates > 255:
+                raise ValueError("kind='state' holds at most 255 states")
+        cols = [ta.node_to_index[v] for v in obs_nodes]
+        W, root_post, status = ctx.expectation_weights_obs(
+            ta.indices, ta.indptr, esd, root_distn, cols, data, kind, site_weights=w)
     if status.any():
         from ._util import NumericalZeroProb
         raise NumericalZeroProb('the denominator is zero (site %d)'

@@ -521,6 +521,61 @@ ratio_sum_kernel(int nnodes, int n, int nsites, const int *__restrict__ parent,
     }
 }
 
+// n*n <= 128: 256 / (n*n) sites per iteration, one (site slot, a, b) per thread -- the
+// loop above is bound by the latency of its two dependent global loads and three
+// barriers per site, which this divides by the number of slots (n = 4: 16)
+__global__ void __launch_bounds__(256)
+ratio_sum_small_kernel(int nnodes, int n, int nsites, const int *__restrict__ parent,
+                       const double *__restrict__ esd, const double *__restrict__ pmap_all,
+                       const double *__restrict__ distn_all, const double *__restrict__ weights,
+                       double *__restrict__ part)
+{
+    __shared__ double Ps[128];
+    __shared__ double p[256], u[256], red[256];
+    const int c = blockIdx.x, g = blockIdx.y, G = gridDim.y, t = threadIdx.x;
+    const int nn = n * n, slots = 256 / nn;
+    double *out = part + ((size_t)g * nnodes + c) * nn;
+    if (c == 0) {
+        double r = 0.0;
+        for (int s = g; s < nsites; s += G)
+            if (t < n) r = fma(weights ? weights[s] : 1.0, distn_all[(size_t)s * nnodes * n + t], r);
+        for (int e = t; e < nn; e += 256) out[e] = 0.0;
+        __syncthreads();
+        if (t < n) out[(size_t)t * n] = r;
+        return;
+    }
+    if (t < nn) Ps[t] = esd[(size_t)c * nn + t];
+    const int par = parent[c];
+    const int q1 = t / n, j1 = t % n;               // loader role: slot, state
+    const int q = t / nn, e = t % nn, a = e / n, b = e % n;
+    const bool loader = t < slots * n, worker = t < slots * nn;
+    double acc = 0.0;
+    __syncthreads();
+    for (long s0 = (long)g * slots; s0 < nsites; s0 += (long)G * slots) {
+        const long site = s0 + q1;
+        const bool live = loader && site < nsites;
+        const size_t base = (size_t)site * nnodes * n;
+        if (loader) p[t] = live ? pmap_all[base + (size_t)c * n + j1] : 0.0;
+        const double pa = live ? distn_all[base + (size_t)par * n + j1] : 0.0;
+        __syncthreads();
+        if (loader) {
+            double den = 0.0;
+            for (int k = 0; k < n; ++k) den = fma(Ps[j1 * n + k], p[q1 * n + k], den);
+            u[t] = (pa != 0.0 && den > 0.0) ? (weights ? weights[site] : 1.0) * pa / den : 0.0;
+        }
+        __syncthreads();
+        if (worker) acc = fma(u[q * n + a], p[q * n + b], acc);
+        __syncthreads();
+    }
+    red[t] = worker ? acc : 0.0;
+    __syncthreads();
+    if (t < nn) {
+        double sum = 0.0;
+        for (int k = 0; k < slots; ++k) sum += red[k * nn + t];
+        out[t] = Ps[t] != 0.0 ? sum : 0.0;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 sum_parts_kernel(int G, long count, const double *__restrict__ part, double *__restrict__ out)
 {
@@ -533,14 +588,62 @@ sum_parts_kernel(int G, long count, const double *__restrict__ part, double *__r
 
 }  // namespace
 
-extern "C" int rt_mjp_esd_expectation_weights(rt_ctx *ctx, int64_t nnodes, int64_t n,
-        int64_t nsites, const int64_t *idx, const int64_t *ptr, const double *esd,
-        const double *root_distn, const int64_t *state_mask, const double *site_weights,
-        double *edge_weights, int32_t *status)
+namespace {
+
+// state_mask[site][node][state] from one byte / one 64-bit set per (site, observed node):
+// every other node is unrestricted (RT_OBS_STATE: a value >= n is "unobserved")
+__global__ void __launch_bounds__(256)
+expand_obs_kernel(int nnodes, int n, long nsites, int nobs, const int *__restrict__ obs_nodes,
+                  int kind, const void *__restrict__ data, long *__restrict__ mask)
+{
+    const long total = nsites * nnodes * n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256)
+        mask[i] = 1;            // the observed rows are written by the next launch
+}
+
+__global__ void __launch_bounds__(256)
+apply_obs_kernel(int nnodes, int n, long nsites, int nobs, const int *__restrict__ obs_nodes,
+                 int kind, const void *__restrict__ data, long *__restrict__ mask)
+{
+    const long total = nsites * nobs * n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int s = (int)(i % n);
+        const long so = i / n;                  // site * nobs + j
+        const int j = (int)(so % nobs);
+        const long site = so / nobs;
+        long allowed;
+        if (kind == RT_OBS_STATE) {
+            const unsigned v = ((const unsigned char *)data)[so];
+            allowed = (v >= (unsigned)n || v == (unsigned)s) ? 1 : 0;
+        } else {
+            allowed = (long)((((const unsigned long long *)data)[so] >> s) & 1ull);
+        }
+        mask[(site * nnodes + obs_nodes[j]) * n + s] = allowed;
+    }
+}
+
+int expectation_weights_impl(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t nsites,
+        const int64_t *idx, const int64_t *ptr, const double *esd, const double *root_distn,
+        const int64_t *state_mask, int64_t nobs, const int64_t *obs_nodes, int kind,
+        const void *data, const double *site_weights, double *edge_weights, int32_t *status)
 {
     RT_REQUIRE(ctx, "null context");
     RT_TRY(check_tree(nnodes, n, nsites, idx, ptr, esd));
-    RT_REQUIRE(edge_weights && (state_mask || nsites == 0), "null array");
+    RT_REQUIRE(edge_weights && (state_mask || data || nobs == 0 || nsites == 0), "null array");
+    std::vector<int> obs_idx;
+    if (!state_mask) {
+        RT_REQUIRE(kind == RT_OBS_STATE || kind == RT_OBS_MASK,
+                   "kind must be RT_OBS_STATE or RT_OBS_MASK");
+        RT_REQUIRE(nobs >= 0 && (obs_nodes || nobs == 0), "bad observation list");
+        std::vector<char> seen((size_t)nnodes, 0);
+        for (int64_t j = 0; j < nobs; ++j) {
+            RT_REQUIRE(obs_nodes[j] >= 0 && obs_nodes[j] < nnodes, "obs_nodes out of range");
+            RT_REQUIRE(!seen[(size_t)obs_nodes[j]], "node %lld observed twice",
+                       (long long)obs_nodes[j]);
+            seen[(size_t)obs_nodes[j]] = 1;
+            obs_idx.push_back((int)obs_nodes[j]);
+        }
+    }
     RT_HIP(hipSetDevice(ctx->device));
     const size_t nn = (size_t)n * n, wcount = (size_t)nnodes * nn;
     if (nsites == 0) {
@@ -560,6 +663,9 @@ extern "C" int rt_mjp_esd_expectation_weights(rt_ctx *ctx, int64_t nnodes, int64
     const size_t o_root = plan.take((size_t)n * 8), o_w = plan.take((size_t)nsites * 8);
     const size_t o_st = plan.take((size_t)nsites * 4);
     const size_t o_part = plan.take((size_t)G * wcount * 8), o_out = plan.take(wcount * 8);
+    const size_t data_bytes = state_mask ? 0 : (size_t)nsites * nobs * (kind == RT_OBS_STATE ? 1 : 8);
+    const size_t o_data = plan.take(std::max<size_t>(data_bytes, 8));
+    const size_t o_obsn = plan.take(std::max<size_t>((size_t)nobs * 4, 8));
     RT_TRY(scratch_reserve(ctx, plan.total));
     unsigned char *base = ctx->d_scratch;
     long *d_idx = (long *)(base + o_idx), *d_ptr = (long *)(base + o_ptr);
@@ -576,7 +682,20 @@ extern "C" int rt_mjp_esd_expectation_weights(rt_ctx *ctx, int64_t nnodes, int64
     RT_HIP(hipMemcpyAsync(d_ptr, ptr, (size_t)(nnodes + 1) * 8, hipMemcpyHostToDevice, st));
     RT_HIP(hipMemcpyAsync(d_esd, esd, wcount * 8, hipMemcpyHostToDevice, st));
     RT_HIP(hipMemcpyAsync(d_par, parent.data(), (size_t)nnodes * 4, hipMemcpyHostToDevice, st));
-    RT_HIP(hipMemcpyAsync(d_mask, state_mask, bytes, hipMemcpyHostToDevice, st));
+    if (state_mask) {
+        RT_HIP(hipMemcpyAsync(d_mask, state_mask, bytes, hipMemcpyHostToDevice, st));
+    } else {
+        void *d_data = base + o_data;
+        int *d_obsn = (int *)(base + o_obsn);
+        if (data_bytes) RT_HIP(hipMemcpyAsync(d_data, data, data_bytes, hipMemcpyHostToDevice, st));
+        if (nobs)
+            RT_HIP(hipMemcpyAsync(d_obsn, obs_idx.data(), (size_t)nobs * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(expand_obs_kernel, dim3(2048), dim3(256), 0, st, (int)nnodes, (int)n,
+                           (long)nsites, (int)nobs, d_obsn, kind, d_data, d_mask);
+        if (nobs)
+            hipLaunchKernelGGL(apply_obs_kernel, dim3(2048), dim3(256), 0, st, (int)nnodes,
+                               (int)n, (long)nsites, (int)nobs, d_obsn, kind, d_data, d_mask);
+    }
     if (d_root) RT_HIP(hipMemcpyAsync(d_root, root_distn, (size_t)n * 8, hipMemcpyHostToDevice, st));
     if (d_w) RT_HIP(hipMemcpyAsync(d_w, site_weights, (size_t)nsites * 8, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(pset_kernel, dim3((unsigned)nsites), dim3(64), 0, st, (int)nnodes,
@@ -588,15 +707,44 @@ extern "C" int rt_mjp_esd_expectation_weights(rt_ctx *ctx, int64_t nnodes, int64
     hipLaunchKernelGGL(distn_kernel<false>, dim3((unsigned)nsites), dim3(64), 0, st,
                        (int)nnodes, (int)n, d_idx, d_ptr, d_esd, d_root, d_pmap, d_distn,
                        (double *)nullptr, d_st);
-    hipLaunchKernelGGL(ratio_sum_kernel, dim3((unsigned)nnodes, (unsigned)G), dim3(256), 0, st,
-                       (int)nnodes, (int)n, (int)nsites, d_par, d_esd, d_pmap, d_distn, d_w,
-                       d_part);
+    if (nn <= 128)
+        hipLaunchKernelGGL(ratio_sum_small_kernel, dim3((unsigned)nnodes, (unsigned)G), dim3(256),
+                           0, st, (int)nnodes, (int)n, (int)nsites, d_par, d_esd, d_pmap, d_distn,
+                           d_w, d_part);
+    else
+        hipLaunchKernelGGL(ratio_sum_kernel, dim3((unsigned)nnodes, (unsigned)G), dim3(256), 0,
+                           st, (int)nnodes, (int)n, (int)nsites, d_par, d_esd, d_pmap, d_distn,
+                           d_w, d_part);
     hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((wcount + 255) / 256)), dim3(256), 0,
                        st, G, (long)wcount, d_part, d_out);
     RT_HIP(hipGetLastError());
     RT_HIP(hipMemcpyAsync(edge_weights, d_out, wcount * 8, hipMemcpyDeviceToHost, st));
     if (status) RT_HIP(hipMemcpyAsync(status, d_st, (size_t)nsites * 4, hipMemcpyDeviceToHost, st));
-    // parent.data() and the caller's arrays must outlive the copies
+    // parent.data(), obs_idx.data() and the caller's arrays must outlive the copies
     RT_HIP(hipStreamSynchronize(st));
     return RT_OK;
+}
+
+}  // namespace
+
+extern "C" int rt_mjp_esd_expectation_weights(rt_ctx *ctx, int64_t nnodes, int64_t n,
+        int64_t nsites, const int64_t *idx, const int64_t *ptr, const double *esd,
+        const double *root_distn, const int64_t *state_mask, const double *site_weights,
+        double *edge_weights, int32_t *status)
+{
+    RT_REQUIRE(state_mask || nsites == 0, "null array");
+    return expectation_weights_impl(ctx, nnodes, n, nsites, idx, ptr, esd, root_distn, state_mask,
+                                    0, nullptr, RT_OBS_MASK, nullptr, site_weights, edge_weights,
+                                    status);
+}
+
+extern "C" int rt_mjp_esd_expectation_weights_obs(rt_ctx *ctx, int64_t nnodes, int64_t n,
+        int64_t nsites, const int64_t *idx, const int64_t *ptr, const double *esd,
+        const double *root_distn, int64_t nobs, const int64_t *obs_nodes, int kind,
+        const void *data, const double *site_weights, double *edge_weights, int32_t *status)
+{
+    RT_REQUIRE(data || nobs == 0 || nsites == 0, "null array");
+    return expectation_weights_impl(ctx, nnodes, n, nsites, idx, ptr, esd, root_distn, nullptr,
+                                    nobs, obs_nodes, kind, data, site_weights, edge_weights,
+                                    status);
 }

@@ -240,6 +240,43 @@ class Context(object):
         W[0] = 0.0
         return W, root_post, status
 
+    def expectation_weights_obs(self, indices, indptr, esd, root_distn, obs_nodes, data,
+                                kind, site_weights=None):
+        """rt_mjp_esd_expectation_weights_obs: as expectation_weights, from compact
+        observations -- ``data`` [nsites, len(obs_nodes)] uint8 states (kind='state')
+        or uint64 allowed-set masks (kind='mask'); obs_nodes are preorder indices."""
+        indices, indptr, esd = _i64(indices), _i64(indptr), _f64(esd)
+        nnodes, n = esd.shape[0], esd.shape[1]
+        obs_nodes = _i64(obs_nodes)
+        if kind == 'state':
+            data = np.ascontiguousarray(data, dtype=np.uint8)
+            code = _lib.RT_OBS_STATE
+        elif kind == 'mask':
+            data = np.ascontiguousarray(data, dtype=np.uint64)
+            code = _lib.RT_OBS_MASK
+        else:
+            raise ValueError("kind must be 'state' or 'mask'")
+        if data.ndim != 2 or data.shape[1] != obs_nodes.shape[0]:
+            raise ValueError('data must be [nsites, len(obs_nodes)]')
+        nsites = data.shape[0]
+        rd = None if root_distn is None else _f64(root_distn)
+        if rd is not None and rd.shape != (n,):
+            raise ValueError('inconsistent root distribution')
+        w = None if site_weights is None else _f64(site_weights)
+        if w is not None and w.shape != (nsites,):
+            raise ValueError('one weight per site expected')
+        W = np.empty((nnodes, n, n), dtype=np.float64)
+        status = np.zeros(nsites, dtype=np.int32)
+        _lib.check(_lib.lib().rt_mjp_esd_expectation_weights_obs(
+            self._h, nnodes, n, nsites, _ptr(indices, c_int64), _ptr(indptr, c_int64),
+            _ptr(esd, c_double), None if rd is None else _ptr(rd, c_double),
+            obs_nodes.shape[0], _ptr(obs_nodes, c_int64), code,
+            data.ctypes.data_as(c_void_p), None if w is None else _ptr(w, c_double),
+            _ptr(W, c_double), _ptr(status, c_int32)))
+        root_post = W[0, :, 0].copy()
+        W[0] = 0.0
+        return W, root_post, status
+
     # ---- multi-GPU ---------------------------------------------------------
 
     @staticmethod

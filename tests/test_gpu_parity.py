@@ -767,29 +767,49 @@ def test_expected_history_statistics_batch(ra):
     # the device sums against J / P assembled on the host from the joint endpoint
     # distributions of the reference-format pass (itself checked against the oracle)
     from raoteh_amd._tree import TreeArrays
-    big = ra.synth.make_config('c2', nsites=333)
-    bmask = 1 << big['leaf_states'].astype(np.int64)
-    bmask[::7, 2] = 0b1010
-    bw = rng.uniform(0.5, 2.0, size=333)
-    T_aug = _mjp_dense.get_expm_augmented_tree(T, root, Q_default=cfg['Q_default'])
-    ta = TreeArrays(T_aug, root)
-    esd = ta.esd_transitions(n)
-    m3 = np.ones((333, ta.nnodes, n), dtype=np.int64)
-    cols = [ta.node_to_index[v] for v in big['leaves']]
-    m3[:, cols, :] = (bmask[:, :, None] >> np.arange(n)) & 1
-    W, rp, st = ra.ctx.expectation_weights(ta.indices, ta.indptr, esd, cfg['root_distn'],
-                                           m3.copy(), site_weights=bw)
-    assert not st.any()
-    pm = np.empty(m3.shape)
-    ra.ctx.passes(ta.indices, ta.indptr, esd, m3.copy(), pm)
-    dn, _ = ra.ctx.node_to_distn(ta.indices, ta.indptr, esd, cfg['root_distn'], pm)
-    J = ra.ctx.joint_endpoint_distn(ta.indices, ta.indptr, esd, pm, dn)
-    for i in range(1, ta.nnodes):
-        ratio = np.where(J[:, i] != 0, J[:, i] / np.where(esd[i] != 0, esd[i], 1.0), 0.0)
-        np.testing.assert_allclose(W[i], np.tensordot(bw, ratio, axes=(0, 0)), rtol=1e-12,
-                                   atol=1e-13)
-    np.testing.assert_allclose(rp, np.tensordot(bw, dn[:, 0], axes=(0, 0)), rtol=1e-13)
-    assert not W[0].any()
+    def random_config(n, nleaves, nb):
+        rT, rroot, rleaves = ra.synth.balanced_tree(nleaves, seed=3)
+        R = rng.exponential(size=(n, n))
+        np.fill_diagonal(R, 0.0)
+        return dict(T=rT, root=rroot, nstates=n, leaves=rleaves, obs_kind='state',
+                    leaf_states=rng.randint(n, size=(nb, nleaves)),
+                    root_distn=np.full(n, 1.0 / n), Q_default=R - np.diag(R.sum(axis=1)))
+    for name, nb in (('c2', 333), ('c5', 70), ('c1', 90), (9, 150), (11, 67), (12, 66)):
+        big = (ra.synth.make_config(name, nsites=nb) if isinstance(name, str)
+               else random_config(name, 16, nb))
+        bT, broot, bn = big['T'], big['root'], big['nstates']
+        if big['obs_kind'] == 'state':
+            bmask = 1 << big['leaf_states'].astype(np.int64)
+            bmask[::7, 2] = 0b1010
+        else:
+            table = np.array([sum(1 << x for x in ss) for ss in big['leaf_allowed']],
+                             dtype=np.int64)
+            bmask = table[big['leaf_states']]
+        bw = rng.uniform(0.5, 2.0, size=nb)
+        T_aug = _mjp_dense.get_expm_augmented_tree(bT, broot, Q_default=big.get('Q_default'))
+        ta = TreeArrays(T_aug, broot)
+        esd = ta.esd_transitions(bn)
+        m3 = np.ones((nb, ta.nnodes, bn), dtype=np.int64)
+        cols = [ta.node_to_index[v] for v in big['leaves']]
+        m3[:, cols, :] = (bmask[:, :, None] >> np.arange(bn)) & 1
+        W, rp, st = ra.ctx.expectation_weights(ta.indices, ta.indptr, esd, big['root_distn'],
+                                               m3.copy(), site_weights=bw)
+        assert not st.any()
+        W2, rp2, st2 = ra.ctx.expectation_weights_obs(
+            ta.indices, ta.indptr, esd, big['root_distn'], cols, bmask, 'mask', site_weights=bw)
+        np.testing.assert_array_equal(W2, W)
+        np.testing.assert_array_equal(rp2, rp)
+        pm = np.empty(m3.shape)
+        ra.ctx.passes(ta.indices, ta.indptr, esd, m3.copy(), pm)
+        dn, _ = ra.ctx.node_to_distn(ta.indices, ta.indptr, esd, big['root_distn'], pm)
+        J = ra.ctx.joint_endpoint_distn(ta.indices, ta.indptr, esd, pm, dn)
+        for i in range(1, ta.nnodes):
+            ratio = np.where(J[:, i] != 0, J[:, i] / np.where(esd[i] != 0, esd[i], 1.0), 0.0)
+            want = np.tensordot(bw, ratio, axes=(0, 0))
+            np.testing.assert_allclose(W[i], want, rtol=1e-12, atol=1e-13 * np.abs(want).max(),
+                                       err_msg='%s node %d' % (name, i))
+        np.testing.assert_allclose(rp, np.tensordot(bw, dn[:, 0], axes=(0, 0)), rtol=1e-13)
+        assert not W[0].any()
     states = cfg['leaf_states'].copy()
     d3, _, _ = _mjp_dense.get_expected_history_statistics_batch(
         T, root, n, root_distn=cfg['root_distn'], Q_default=cfg['Q_default'],
