@@ -810,6 +810,19 @@ def test_expected_history_statistics_batch(ra):
                                        err_msg='%s node %d' % (name, i))
         np.testing.assert_allclose(rp, np.tensordot(bw, dn[:, 0], axes=(0, 0)), rtol=1e-13)
         assert not W[0].any()
+    # an infeasible site: the reference's normaliser raises NumericalZeroProb
+    # (_util.py:164-165, reached from _mc0_dense.get_node_to_distn)
+    bad = masks.copy()
+    bad[7, 0] = 0
+    with pytest.raises(ra.pkg.NumericalZeroProb):
+        _mjp_dense.get_expected_history_statistics_batch(
+            T, root, n, root_distn=cfg['root_distn'], Q_default=cfg['Q_default'],
+            obs_nodes=cfg['leaves'], data=bad, kind='mask')
+    with pytest.raises(ra.pkg.NumericalZeroProb):
+        impossible = dict((v, set(range(n))) for v in T)
+        impossible[cfg['leaves'][0]] = set()
+        _mjp_dense.get_expected_history_statistics(
+            T, impossible, root, n, root_distn=cfg['root_distn'], Q_default=cfg['Q_default'])
     states = cfg['leaf_states'].copy()
     d3, _, _ = _mjp_dense.get_expected_history_statistics_batch(
         T, root, n, root_distn=cfg['root_distn'], Q_default=cfg['Q_default'],
