@@ -15,7 +15,6 @@ import os
 import sys
 import time
 
-import networkx as nx
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
