@@ -16,15 +16,43 @@
 
 namespace {
 
+// One 64-lane workgroup holds 64 / n sites (n <= 32; one site above): lane =
+// (site slot, state).  The sites of a workgroup never exchange anything, so the
+// arithmetic of a site is the same in every packing; at n = 4 a wave carries 16
+// sites instead of one with 60 idle lanes.
+struct site_lane {
+    int s;          // state
+    long site;      // site of this lane, -1 = idle lane
+    int slot;
+};
+
+__device__ inline site_lane lane_site(int n, long nsites)
+{
+    const int per = n <= 32 ? 64 / n : 1;
+    site_lane L;
+    L.slot = (int)threadIdx.x / n;
+    L.s = (int)threadIdx.x % n;
+    const long site = (long)blockIdx.x * per + L.slot;
+    L.site = (L.slot < per && site < nsites) ? site : -1;
+    return L;
+}
+
+inline unsigned pass_grid(int64_t nsites, int64_t n)
+{
+    const int64_t per = n <= 32 ? 64 / n : 1;
+    return (unsigned)((nsites + per - 1) / per);
+}
+
 __global__ void __launch_bounds__(64)
-pset_kernel(int nnodes, int n, const long *__restrict__ idx,
+pset_kernel(int nnodes, int n, long nsites, const long *__restrict__ idx,
             const long *__restrict__ ptr, const double *__restrict__ esd,
             long *__restrict__ mask)
 {
-    const int s = threadIdx.x;
-    long *mk = mask + (size_t)blockIdx.x * nnodes * n;
+    const site_lane L = lane_site(n, nsites);
+    const int s = L.s;
+    long *mk = mask + (size_t)(L.site < 0 ? 0 : L.site) * nnodes * n;
     for (int v = nnodes - 1; v >= 0; --v) {
-        if (s < n) {
+        if (L.site >= 0) {
             long keep = mk[(size_t)v * n + s] != 0;
             for (long e = ptr[v]; e < ptr[v + 1]; ++e) {
                 const long c = idx[e];
@@ -42,16 +70,17 @@ pset_kernel(int nnodes, int n, const long *__restrict__ idx,
 }
 
 __global__ void __launch_bounds__(64)
-set_kernel(int nnodes, int n, const long *__restrict__ idx,
+set_kernel(int nnodes, int n, long nsites, const long *__restrict__ idx,
            const long *__restrict__ ptr, const double *__restrict__ esd,
            long *__restrict__ mask)
 {
-    const int sp = threadIdx.x;     // child state
-    long *mk = mask + (size_t)blockIdx.x * nnodes * n;
+    const site_lane L = lane_site(n, nsites);
+    const int sp = L.s;             // child state
+    long *mk = mask + (size_t)(L.site < 0 ? 0 : L.site) * nnodes * n;
     for (int v = 0; v < nnodes; ++v) {
         for (long e = ptr[v]; e < ptr[v + 1]; ++e) {
             const long c = idx[e];
-            if (sp < n) {
+            if (L.site >= 0) {
                 const double *Pc = esd + (size_t)c * n * n;
                 const long *mv = mk + (size_t)v * n;
                 long any = 0;
@@ -65,17 +94,18 @@ set_kernel(int nnodes, int n, const long *__restrict__ idx,
 }
 
 __global__ void __launch_bounds__(64)
-pmap_kernel(int nnodes, int n, const long *__restrict__ idx,
+pmap_kernel(int nnodes, int n, long nsites, const long *__restrict__ idx,
             const long *__restrict__ ptr, const double *__restrict__ esd,
             const long *__restrict__ mask, const double *__restrict__ obs,
             double *__restrict__ out)
 {
-    const int s = threadIdx.x;
-    const size_t base = (size_t)blockIdx.x * nnodes * n;
+    const site_lane L = lane_site(n, nsites);
+    const int s = L.s;
+    const size_t base = (size_t)(L.site < 0 ? 0 : L.site) * nnodes * n;
     const long *mk = mask + base;
     double *o = out + base;
     for (int v = nnodes - 1; v >= 0; --v) {
-        if (s < n) {
+        if (L.site >= 0) {
             double acc = 1.0;
             for (long e = ptr[v]; e < ptr[v + 1]; ++e) {
                 const long c = idx[e];
@@ -151,11 +181,11 @@ int mask_pass(rt_ctx *ctx, bool forward, int64_t nnodes, int64_t n, int64_t nsit
                                   ctx->stream);
     if (e == hipSuccess) {
         if (forward)
-            hipLaunchKernelGGL(set_kernel, dim3((unsigned)nsites), dim3(64), 0,
-                               ctx->stream, (int)nnodes, (int)n, d.idx, d.ptr, d.esd, dm);
+            hipLaunchKernelGGL(set_kernel, dim3(pass_grid(nsites, n)), dim3(64), 0, ctx->stream, (int)nnodes, (int)n,
+                       (long)nsites, d.idx, d.ptr, d.esd, dm);
         else
-            hipLaunchKernelGGL(pset_kernel, dim3((unsigned)nsites), dim3(64), 0,
-                               ctx->stream, (int)nnodes, (int)n, d.idx, d.ptr, d.esd, dm);
+            hipLaunchKernelGGL(pset_kernel, dim3(pass_grid(nsites, n)), dim3(64), 0, ctx->stream, (int)nnodes, (int)n,
+                       (long)nsites, d.idx, d.ptr, d.esd, dm);
         e = hipGetLastError();
     }
     if (e == hipSuccess)
@@ -229,12 +259,12 @@ extern "C" int rt_mcy_esd_passes(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t
     RT_HIP(hipMemcpyAsync(d_esd, esd, (size_t)nnodes * n * n * 8, hipMemcpyHostToDevice, st));
     RT_HIP(hipMemcpyAsync(d_mask, state_mask, bytes, hipMemcpyHostToDevice, st));
     if (d_obs) RT_HIP(hipMemcpyAsync(d_obs, obs_likelihood, bytes, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(pset_kernel, dim3((unsigned)nsites), dim3(64), 0, st, (int)nnodes,
-                       (int)n, d_idx, d_ptr, d_esd, d_mask);
-    hipLaunchKernelGGL(set_kernel, dim3((unsigned)nsites), dim3(64), 0, st, (int)nnodes,
-                       (int)n, d_idx, d_ptr, d_esd, d_mask);
-    hipLaunchKernelGGL(pmap_kernel, dim3((unsigned)nsites), dim3(64), 0, st, (int)nnodes,
-                       (int)n, d_idx, d_ptr, d_esd, d_mask, d_obs, d_out);
+    hipLaunchKernelGGL(pset_kernel, dim3(pass_grid(nsites, n)), dim3(64), 0, st, (int)nnodes, (int)n,
+                       (long)nsites, d_idx, d_ptr, d_esd, d_mask);
+    hipLaunchKernelGGL(set_kernel, dim3(pass_grid(nsites, n)), dim3(64), 0, st, (int)nnodes, (int)n,
+                       (long)nsites, d_idx, d_ptr, d_esd, d_mask);
+    hipLaunchKernelGGL(pmap_kernel, dim3(pass_grid(nsites, n)), dim3(64), 0, st, (int)nnodes, (int)n,
+                       (long)nsites, d_idx, d_ptr, d_esd, d_mask, d_obs, d_out);
     RT_HIP(hipGetLastError());
     RT_HIP(hipMemcpyAsync(state_mask, d_mask, bytes, hipMemcpyDeviceToHost, st));
     RT_HIP(hipMemcpyAsync(subtree_probability, d_out, bytes, hipMemcpyDeviceToHost, st));
@@ -280,8 +310,8 @@ extern "C" int rt_mcy_esd_get_node_to_pmap(rt_ctx *ctx, int64_t nnodes, int64_t 
         e = hipMemcpyAsync(dobs, obs_likelihood, bytes, hipMemcpyHostToDevice,
                            ctx->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(pmap_kernel, dim3((unsigned)nsites), dim3(64), 0, ctx->stream,
-                           (int)nnodes, (int)n, d.idx, d.ptr, d.esd, dm, dobs, dout);
+        hipLaunchKernelGGL(pmap_kernel, dim3(pass_grid(nsites, n)), dim3(64), 0, ctx->stream, (int)nnodes, (int)n,
+                       (long)nsites, d.idx, d.ptr, d.esd, dm, dobs, dout);
         e = hipGetLastError();
     }
     if (e == hipSuccess)
@@ -318,29 +348,37 @@ namespace {
 
 template <bool JOINT>
 __global__ void __launch_bounds__(64)
-distn_kernel(int nnodes, int n, const long *__restrict__ idx, const long *__restrict__ ptr,
-             const double *__restrict__ esd, const double *__restrict__ root_distn,
-             const double *__restrict__ pmap_all, double *__restrict__ distn_all,
-             double *__restrict__ joint_all, int *__restrict__ status)
+distn_kernel(int nnodes, int n, long nsites, const long *__restrict__ idx,
+             const long *__restrict__ ptr, const double *__restrict__ esd,
+             const double *__restrict__ root_distn, const double *__restrict__ pmap_all,
+             double *__restrict__ distn_all, double *__restrict__ joint_all,
+             int *__restrict__ status)
 {
     __shared__ double wbuf[64];
-    __shared__ int bad;
-    const int s = threadIdx.x;
-    const size_t base = (size_t)blockIdx.x * nnodes * n;
+    __shared__ int bad[64];
+    const site_lane L = lane_site(n, nsites);
+    const int s = L.s, lane0 = L.slot * n;         // first lane of this site
+    const bool on = L.site >= 0;
+    const size_t base = (size_t)(on ? L.site : 0) * nnodes * n;
     const double *pm = pmap_all + base;
     double *dn = distn_all + base;
     double *jt = JOINT ? joint_all + base * n : nullptr;
-    if (s == 0) bad = 0;
+    if (threadIdx.x < 64) bad[threadIdx.x] = 0;
+    __syncthreads();
     if (!JOINT) {
-        // root: normalised pmap * prior (_mc0_dense.py:458-459)
+        // root: normalised pmap * prior (_mc0_dense.py:458-459); the sum runs over the
+        // site's states in lane order
         double w = 0.0;
-        if (s < n) w = pm[s] * (root_distn ? root_distn[s] : 1.0);
-        double tot = w;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
-        if (!(tot > 0.0) && s == 0) bad = 1;
-        if (s < n) dn[s] = tot > 0.0 ? w / tot : 0.0;
-    } else if (s < n) {
+        if (on) w = pm[s] * (root_distn ? root_distn[s] : 1.0);
+        wbuf[threadIdx.x] = w;
+        __syncthreads();
+        if (on) {
+            double tot = 0.0;
+            for (int k = 0; k < n; ++k) tot += wbuf[lane0 + k];
+            if (!(tot > 0.0)) bad[L.slot] = 1;
+            dn[s] = tot > 0.0 ? w / tot : 0.0;
+        }
+    } else if (on) {
         for (int sa = 0; sa < n; ++sa) jt[(size_t)sa * n + s] = 0.0;   // root slot
     }
     __syncthreads();
@@ -349,33 +387,35 @@ distn_kernel(int nnodes, int n, const long *__restrict__ idx, const long *__rest
             const long c = idx[e];
             const double *Pc = esd + (size_t)c * n * n;
             const double *Lc = pm + (size_t)c * n;
-            if (s < n) {
+            if (on) {
                 const double pa = dn[(size_t)v * n + s];
                 double den = 0.0;
                 for (int sp = 0; sp < n; ++sp) den = fma(Pc[(size_t)s * n + sp], Lc[sp], den);
                 double w = 0.0;
                 if (pa != 0.0) {
                     if (den > 0.0) w = pa / den;
-                    else bad = 1;
+                    else bad[L.slot] = 1;
                 }
-                wbuf[s] = w;
+                wbuf[threadIdx.x] = w;
             }
             __syncthreads();
-            if (s < n) {
+            if (on) {
                 const double lb = Lc[s];
                 if (JOINT) {
                     for (int sa = 0; sa < n; ++sa)
-                        jt[((size_t)c * n + sa) * n + s] = wbuf[sa] * Pc[(size_t)sa * n + s] * lb;
+                        jt[((size_t)c * n + sa) * n + s] =
+                            wbuf[lane0 + sa] * Pc[(size_t)sa * n + s] * lb;
                 } else {
                     double acc = 0.0;
-                    for (int sa = 0; sa < n; ++sa) acc = fma(wbuf[sa], Pc[(size_t)sa * n + s], acc);
+                    for (int sa = 0; sa < n; ++sa)
+                        acc = fma(wbuf[lane0 + sa], Pc[(size_t)sa * n + s], acc);
                     dn[(size_t)c * n + s] = acc * lb;
                 }
             }
             __syncthreads();
         }
     }
-    if (status && s == 0) status[blockIdx.x] = bad ? 2 : 0;
+    if (status && on && s == 0) status[L.site] = bad[L.slot] ? 2 : 0;
 }
 
 int distn_pass(rt_ctx *ctx, bool joint, int64_t nnodes, int64_t n, int64_t nsites,
@@ -405,12 +445,12 @@ int distn_pass(rt_ctx *ctx, bool joint, int64_t nnodes, int64_t n, int64_t nsite
         e = hipMemcpyAsync(dr, root_distn, n * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
         if (joint)
-            hipLaunchKernelGGL(distn_kernel<true>, dim3((unsigned)nsites), dim3(64), 0,
-                               ctx->stream, (int)nnodes, (int)n, d.idx, d.ptr, d.esd, dr, dp,
+            hipLaunchKernelGGL(distn_kernel<true>, dim3(pass_grid(nsites, n)), dim3(64), 0, ctx->stream, (int)nnodes, (int)n,
+                       (long)nsites, d.idx, d.ptr, d.esd, dr, dp,
                                dd, dj, ds);
         else
-            hipLaunchKernelGGL(distn_kernel<false>, dim3((unsigned)nsites), dim3(64), 0,
-                               ctx->stream, (int)nnodes, (int)n, d.idx, d.ptr, d.esd, dr, dp,
+            hipLaunchKernelGGL(distn_kernel<false>, dim3(pass_grid(nsites, n)), dim3(64), 0, ctx->stream, (int)nnodes, (int)n,
+                       (long)nsites, d.idx, d.ptr, d.esd, dr, dp,
                                dd, dj, ds);
         e = hipGetLastError();
     }
@@ -698,14 +738,14 @@ int expectation_weights_impl(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t nsi
     }
     if (d_root) RT_HIP(hipMemcpyAsync(d_root, root_distn, (size_t)n * 8, hipMemcpyHostToDevice, st));
     if (d_w) RT_HIP(hipMemcpyAsync(d_w, site_weights, (size_t)nsites * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(pset_kernel, dim3((unsigned)nsites), dim3(64), 0, st, (int)nnodes,
-                       (int)n, d_idx, d_ptr, d_esd, d_mask);
-    hipLaunchKernelGGL(set_kernel, dim3((unsigned)nsites), dim3(64), 0, st, (int)nnodes,
-                       (int)n, d_idx, d_ptr, d_esd, d_mask);
-    hipLaunchKernelGGL(pmap_kernel, dim3((unsigned)nsites), dim3(64), 0, st, (int)nnodes,
-                       (int)n, d_idx, d_ptr, d_esd, d_mask, (const double *)nullptr, d_pmap);
-    hipLaunchKernelGGL(distn_kernel<false>, dim3((unsigned)nsites), dim3(64), 0, st,
-                       (int)nnodes, (int)n, d_idx, d_ptr, d_esd, d_root, d_pmap, d_distn,
+    hipLaunchKernelGGL(pset_kernel, dim3(pass_grid(nsites, n)), dim3(64), 0, st, (int)nnodes, (int)n,
+                       (long)nsites, d_idx, d_ptr, d_esd, d_mask);
+    hipLaunchKernelGGL(set_kernel, dim3(pass_grid(nsites, n)), dim3(64), 0, st, (int)nnodes, (int)n,
+                       (long)nsites, d_idx, d_ptr, d_esd, d_mask);
+    hipLaunchKernelGGL(pmap_kernel, dim3(pass_grid(nsites, n)), dim3(64), 0, st, (int)nnodes, (int)n,
+                       (long)nsites, d_idx, d_ptr, d_esd, d_mask, (const double *)nullptr, d_pmap);
+    hipLaunchKernelGGL(distn_kernel<false>, dim3(pass_grid(nsites, n)), dim3(64), 0, st, (int)nnodes, (int)n,
+                       (long)nsites, d_idx, d_ptr, d_esd, d_root, d_pmap, d_distn,
                        (double *)nullptr, d_st);
     if (nn <= 128)
         hipLaunchKernelGGL(ratio_sum_small_kernel, dim3((unsigned)nnodes, (unsigned)G), dim3(256),
