@@ -237,3 +237,45 @@ def test_tree_specialised_mfma_source_is_generated_on_the_host(monkeypatch):
         ta.nnodes, ta.indices.ctypes.data_as(p64), ta.indptr.ctypes.data_as(p64),
         65, len(obs), obs.ctypes.data_as(p64), 2, buf, len(buf))
     assert rc < 0
+
+
+def test_frechet_block_assembly_is_the_adjoint_of_expm_frechet():
+    """Host logic of the expected history statistics (raoteh_amd/_mjp_dense.py): the
+    2n x 2n blocks handed to the device expm, with scipy standing in for the device
+    here, give M = L(t Q^T, W), and <W, L(tQ, E_cd)> = M[c, d] for every direction
+    E_cd -- the n + nnz(Q) expm_frechet calls of _mjp_dense.py:483-533 in one
+    exponential; W of any size (it is scaled before it enters the block)."""
+    import scipy.linalg
+    from raoteh_amd import _mjp_dense
+
+    class ScipyExpm(object):
+        @staticmethod
+        def expm(Q, t):
+            return np.stack([scipy.linalg.expm(q * x) for q, x in zip(Q, t)])
+
+    rng = np.random.RandomState(5)
+    for n in (2, 3, 5, 8):
+        Qs, Ws = [], []
+        ts = rng.uniform(0.05, 2.0, size=3)
+        for e in range(3):
+            R = rng.exponential(size=(n, n))
+            R[rng.uniform(size=(n, n)) < 0.3] = 0.0
+            np.fill_diagonal(R, 0.0)
+            Qs.append(R - np.diag(R.sum(axis=1)))
+            Ws.append(rng.exponential(size=(n, n)) * 10.0 ** rng.randint(-6, 7))
+        Ws[1][:] = 0.0                                   # an edge nothing was seen on
+        M = _mjp_dense._frechet_contractions(ScipyExpm(), Qs, ts, np.stack(Ws))
+        assert not M[1].any()
+        for e in (0, 2):
+            for c in range(n):
+                for d in range(n):
+                    C = np.zeros((n, n))
+                    C[c, d] = 1.0
+                    L = scipy.linalg.expm_frechet(ts[e] * Qs[e], C, compute_expm=False)
+                    assert M[e][c, d] == pytest.approx(np.sum(Ws[e] * L), rel=1e-11)
+        dwell, trans = _mjp_dense._accumulate(n, Qs, ts, M)
+        np.testing.assert_allclose(dwell, sum(ts[e] * np.diag(M[e]) for e in range(3)))
+        assert not trans[(Qs[0] == 0) & (Qs[1] == 0) & (Qs[2] == 0)].any()
+    with pytest.raises(ValueError):
+        _mjp_dense._frechet_contractions(ScipyExpm(), [np.zeros((32, 32))], [1.0],
+                                         np.zeros((1, 32, 32)))
