@@ -175,6 +175,20 @@ def reduce_totals(local_totals, control):
     return control.allreduce(np.asarray(local_totals, dtype=np.float64), np.sum)
 
 
+def reduce_history_statistics(stats, control):
+    """Sum over ranks of the (dwell f64[n], root posteriors f64[n], transitions
+    f64[n, n]) triple each rank got from
+    _mjp_dense.get_expected_history_statistics_batch on ITS shard of the sites
+    (shard_range): the statistics are sums over sites, so the shards add.  3 small
+    arrays per iteration: they go over the control plane, not RCCL."""
+    dwell, init, trans = (np.asarray(a, dtype=np.float64) for a in stats)
+    n = dwell.shape[0]
+    if init.shape != (n,) or trans.shape != (n, n):
+        raise ValueError('expected (f64[n], f64[n], f64[n, n])')
+    flat = control.allreduce(np.concatenate([dwell, init, trans.ravel()]), np.sum)
+    return flat[:n], flat[n:2 * n], flat[2 * n:].reshape(n, n)
+
+
 def init_rccl(ctx, control):
     """Create the RCCL communicator of ``ctx`` across the ranks of ``control``.
     Returns True on every rank or False on every rank (never mixed)."""

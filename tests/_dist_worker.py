@@ -17,7 +17,7 @@ import torch.distributed as dist                      # noqa: E402
 from oracle import oracle_numpy as orc                # noqa: E402
 from raoteh_amd import synth                          # noqa: E402
 from raoteh_amd.dist import (SocketControl, TorchControl, env_rank_world,  # noqa: E402
-                             reduce_totals, shard_range)
+                             reduce_history_statistics, reduce_totals, shard_range)
 
 
 def main():
@@ -42,7 +42,26 @@ def main():
     tc.barrier()
     gathered = tc.allgather(np.array([lo, hi], dtype=np.int64).tobytes())
     results['ranges'] = [np.frombuffer(g, dtype=np.int64).tolist() for g in gathered]
+    # expected history statistics of a sharded alignment: per-shard sums add
+    small = synth.make_config('c1', nsites=7)
+    sT, sroot, sn = small['T'], small['root'], small['nstates']
+
+    def shard_statistics(a, b):
+        d, i, t = np.zeros(sn), np.zeros(sn), np.zeros((sn, sn))
+        for k in range(a, b):
+            od, oi, ot = orc.mjp_dense_get_expected_history_statistics(
+                sT, synth.site_node_to_allowed_states(small, k), sroot, sn,
+                root_distn=small['root_distn'], Q_default=small['Q_default'])
+            d, i, t = d + od, i + oi, t + ot
+        return d, i, t
+    slo, shi = shard_range(7, rank, world)
+    got = reduce_history_statistics(shard_statistics(slo, shi), tc)
+    results['expect_gloo'] = [a.tolist() for a in got]
     sc = SocketControl(rank, world)
+    got = reduce_history_statistics(shard_statistics(slo, shi), sc)
+    results['expect_socket'] = [a.tolist() for a in got]
+    if rank == 0:
+        results['expect_want'] = [a.tolist() for a in shard_statistics(0, 7)]
     results['socket'] = reduce_totals(local, sc).tolist()
     results['max_rank'] = float(sc.allreduce([float(rank)], np.max)[0])
     sc.barrier()

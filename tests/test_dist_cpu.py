@@ -62,6 +62,10 @@ def test_sharded_reduce_matches_single_process(tmp_path, world):
         assert got[1:] == want[1:]
         assert got[0] == pytest.approx(want[0], rel=1e-13)
     assert res['max_rank'] == world - 1
+    # expected history statistics: shard sums reduced over both control planes
+    for key in ('expect_gloo', 'expect_socket'):
+        for got_arr, want_arr in zip(res[key], res['expect_want']):
+            np.testing.assert_allclose(got_arr, want_arr, rtol=1e-13, atol=1e-15)
     ranges = res['ranges']
     assert ranges[0][0] == 0 and ranges[-1][1] == 1003
     for a, b in zip(ranges, ranges[1:]):
