@@ -9,7 +9,18 @@ the device) -> fragment repack -> Felsenstein upward pass + root reduce + log
 HBM before the timed region starts.  Batches rotate through several HBM copies
 so the 256 MiB Infinity Cache cannot hold the working set.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c5|c4]
+                    [--also c2,c5,c4]
+
+The headline (`value`, `roofline`, `cpu_baseline` at the top level) is the
+61-state codon configuration C3 (BASELINE.json configs[2]: the largest
+single-GPU configuration and the one the >= 100x target is stated on): 10 000
+sites per GPU, weak scaling -- at N > 1 the global batch has N x 10 000 sites
+(one seed) and rank r uploads dist.shard_range(...) of it.  The other
+configurations ride in the same JSON line under "workloads" (each with its own
+value / ms_per_step / roofline / cpu_baseline): C2 and C5 the same way, and C4
+as STRONG scaling: the one 1 000 000-site codon batch (seed 3), rank r uploads
+shard_range(1 000 000, r, N) -- at N = 1 the whole million on one GPU.
 
 N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N ...`
 (one rank per GPU; RANK / LOCAL_RANK / WORLD_SIZE from the environment).  The
@@ -34,15 +45,33 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-F64_MFMA_PEAK_TFLOPS = 78.6    # MI355X datasheet dense FP64 matrix
+F64_MFMA_DATASHEET_TFLOPS = 78.6    # MI355X datasheet dense FP64 matrix
+ROOFLINE_LAUNCHES = 32         # event-timed launches per kernel after the timed region
+
+
+def f64_mfma_peak():
+    """(TFLOP/s, source): the rate measured on an MI355X by tools/micro/mfma_f64_peak.hip
+    (profiles/r02_mfma_f64_peak.json) when that file is present, else the datasheet."""
+    path = os.path.join(ROOT, 'profiles', 'r02_mfma_f64_peak.json')
+    try:
+        v = float(json.load(open(path))['f64_mfma_16x16x4_peak_tflops'])
+        if v > 0:
+            return v, 'measured: profiles/r02_mfma_f64_peak.json (tools/micro/mfma_f64_peak.hip)'
+    except Exception:
+        pass
+    return F64_MFMA_DATASHEET_TFLOPS, 'MI355X datasheet'
+
 
 WORKLOADS = {
     'c2': dict(desc='4-state HKY85, 64-leaf balanced tree, 100000 sites/GPU, '
-                    'dense f64 leaf likelihood vectors', bound='hbm'),
+                    'dense f64 leaf likelihood vectors', bound='hbm', scaling='weak'),
     'c3': dict(desc='61-state MG94 codon, 64-leaf balanced tree, 10000 sites/GPU, '
-                    'dense f64 leaf likelihood vectors', bound='mfma'),
+                    'dense f64 leaf likelihood vectors', bound='mfma', scaling='weak'),
+    'c4': dict(desc='61-state MG94 codon, 64-leaf balanced tree, ONE batch of 1000000 sites '
+                    'sharded over the GPUs (dist.shard_range), dense f64 leaf likelihood '
+                    'vectors', bound='mfma', scaling='strong'),
     'c5': dict(desc='20-state blinking compound process, 32-leaf tree, per-edge Q, '
-                    '50000 sites/GPU, dense f64 0/1 leaf masks', bound='hbm'),
+                    '50000 sites/GPU, dense f64 0/1 leaf masks', bound='hbm', scaling='weak'),
 }
 
 
@@ -110,6 +139,7 @@ def cpu_baseline(cfg, gpu_ll, budget_s):
             np.max(np.abs(lla - gpu_ll[:m]) / np.abs(lla))))
     except Exception as e:                       # the C port is optional here
         out['c_port_error'] = str(e)
+    out['host_cpu_count'] = os.cpu_count()
     return out
 
 
@@ -141,20 +171,266 @@ def reduce_group_at_end(steps, nb):
     return None
 
 
+def shard_config(name, rank, world, sites):
+    """(config of THIS rank's block of sites, global site count).  Weak workloads:
+    the global batch has world x (configuration size) sites from the configuration's
+    seed and the rank takes dist.shard_range of it; c4: the one million-site batch."""
+    from raoteh_amd import synth
+    from raoteh_amd.dist import shard_range
+    if name == 'c4':
+        total = synth.C4_NSITES if sites is None else sites
+        lo, hi = shard_range(total, rank, world)
+        return synth.make_config('c4', site_range=(lo, hi)), total
+    per = {'c2': 100000, 'c3': 10000, 'c5': 50000}[name] if sites is None else sites
+    total = per * world
+    cfg = synth.make_config(name, nsites=total)
+    lo, hi = shard_range(total, rank, world)
+    cfg['leaf_states'] = cfg['leaf_states'][lo:hi]
+    return cfg, total
+
+
+def run_workload(name, ctx, ctl, rank, world, reduce_kind, steps, warmup, args,
+                 cpu_seconds, interpreter=True):
+    """Run one workload; every rank takes part, rank 0 gets the result dict."""
+    from raoteh_amd import synth, device, _lib
+    wl = WORKLOADS[name]
+    cfg, total_sites = shard_config(name, rank, world, args.sites if name == args.workload
+                                    else None)
+    nsites = cfg['leaf_states'].shape[0]
+    T, root, n = cfg['T'], cfg['root'], cfg['nstates']
+    nleaves = len(cfg['leaves'])
+    nedges = T.number_of_edges()
+
+    model = device.TreeModel(T, root, n, ctx=ctx)
+    model.set_rates(Q_default=cfg['Q_default'])
+    model.set_root_distn(cfg['root_distn'])
+    encoding = args.encoding if name == args.workload else 'dense'
+    t_up = time.perf_counter()
+    if name == 'c4' or encoding == 'state':
+        # uint8 states cross PCIe; for n > 4 the pack kernel expands them on the device to
+        # the same dense f64 resident layout a dense upload gives (31 GB for the million
+        # codon sites: never materialised on the host).  For n <= 4 a state upload stays
+        # one byte per leaf on the device (the compact encoding, --encoding state).
+        if cfg['obs_kind'] != 'state':
+            raise SystemExit('--encoding state: the leaves of this workload are allowed-state '
+                             'sets, not states')
+        batch0 = model.upload_sites(cfg['leaves'], cfg['leaf_states'].astype(np.uint8),
+                                    kind='state')
+    else:
+        dense = synth.leaf_likelihoods(cfg)
+        batch0 = model.upload_sites(cfg['leaves'], dense, kind='dense')
+        del dense
+    upload_s = time.perf_counter() - t_up
+    batches = [batch0]
+    if not args.no_rotate:
+        # >= 640 MB of distinct HBM copies; with RCCL a ring of 8 so that the totals of
+        # one half are all-reduced while the other half is being computed
+        while len(batches) < 8 and (sum(b.device_bytes for b in batches) < 640 * 2 ** 20 or
+                                    (reduce_kind == 'rccl' and
+                                     batch0.device_bytes * (len(batches) + 1) <= 16 * 2 ** 30)):
+            batches.append(batch0.clone())
+
+    def step(j):
+        b = batches[j % len(batches)]
+        model.step(b)          # expm of every edge + prune + reduce (rt_step)
+        # RCCL: one all-reduce per HALF rotation of the batch ring, carrying the totals
+        # of its steps (3 doubles each) while the other half is being computed: the
+        # stream bookkeeping around a collective costs ~11 us of GPU time per call
+        # whatever the payload, a quarter of a C2 step
+        if reduce_kind == 'rccl':
+            grp = reduce_group_after_step(j, len(batches))
+            if grp is not None:
+                model.allreduce_group(batches[grp[0]:grp[1]])
+        return b
+
+    for j in range(warmup):
+        step(j)
+    ctx.sync()
+    ll0, st0 = model.fetch_log_likelihoods(batch0)
+    # inside the timed region: HIP events stamped with each kernel's own begin / end
+    # (hipExtLaunchKernelGGL, on the library's stream) on every 8th launch of each kernel
+    # (timing every launch would cost ~20 us per step)
+    ctx.set_timing(0 if os.environ.get('RAOTEH_BENCH_NO_EVENTS') else 8)
+    ctx.reset_timing()
+
+    ctl.barrier()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for j in range(steps):
+        last = step(j)
+    if reduce_kind == 'rccl':
+        grp = reduce_group_at_end(steps, len(batches))     # the incomplete group
+        if grp is not None:
+            model.allreduce_group(batches[grp[0]:grp[1]])
+    t_enq = time.perf_counter()      # all steps enqueued (the launches are asynchronous)
+    ctx.sync()
+    ctl.barrier()
+    t1 = time.perf_counter()
+    elapsed = float(ctl.allreduce([t1 - t0], np.max)[0])
+
+    totals = model.fetch_totals(last)
+    if reduce_kind == 'host-socket-fallback':
+        totals = ctl.allreduce(totals, np.sum)
+    if reduce_kind == 'none':
+        assert totals[2] == nsites
+    else:
+        assert totals[2] == total_sites, (totals, total_sites)
+    assert np.isfinite(totals[0]) and totals[1] == 0, totals
+    sampled = {}
+    for key, kid in (('expm', _lib.RT_K_EXPM), ('prune', _lib.RT_K_PRUNE),
+                     ('reduce', _lib.RT_K_REDUCE)):
+        ms, cnt, _ = ctx.kernel_time(kid)
+        sampled[key] = dict(avg_us=(ms / cnt * 1e3) if cnt else None, launches=cnt)
+
+    # ---- roofline sample, decoupled from --steps: ROOFLINE_LAUNCHES more steps of the
+    # same loop with EVERY launch event-timed (the step rate is no longer measured here)
+    ctx.set_timing(1)
+    ctx.reset_timing()
+    for j in range(ROOFLINE_LAUNCHES):
+        model.step(batches[j % len(batches)])
+    ctx.sync()
+    prune_ms, prune_cnt, prune_name = ctx.kernel_time(_lib.RT_K_PRUNE)
+    expm_ms, expm_cnt, expm_name = ctx.kernel_time(_lib.RT_K_EXPM)
+    red_ms, red_cnt, _ = ctx.kernel_time(_lib.RT_K_REDUCE)
+    ctx.set_timing(0)
+
+    # ---- the interpreter kernel a fresh topology gets before (or without) its
+    # tree-specialised kernel: the same batch created with jit = 0
+    interp = None
+    if interpreter and rank == 0 and name != 'c4' and batch0.jit_compile_seconds >= 0 and \
+            batch0.kernel_name.startswith('prune_tree_jit'):
+        ctx.set_option('jit', 0)
+        try:
+            dense = synth.leaf_likelihoods(cfg)
+            ib = model.upload_sites(cfg['leaves'], dense, kind='dense')
+            del dense
+            for _ in range(3):
+                model.prune(ib)
+            ctx.set_timing(1)
+            ctx.reset_timing()
+            for _ in range(16):
+                model.prune(ib)
+            ctx.sync()
+            ims, icnt, iname = ctx.kernel_time(_lib.RT_K_PRUNE)
+            ctx.set_timing(0)
+            ill, _ = model.fetch_log_likelihoods(ib)
+            interp = dict(kernel=iname, avg_kernel_us=ims / max(icnt, 1) * 1e3,
+                          launches_timed=icnt,
+                          bit_identical_to_specialised=bool(np.array_equal(ill, ll0)))
+            ib.close()
+        finally:
+            ctx.set_option('jit', None)
+
+    jit_compile_s = batch0.jit_compile_seconds
+    for b in batches[1:]:
+        b.close()
+
+    if rank != 0:
+        batch0.close()
+        model.close()
+        return None
+
+    alg_bytes = nsites * (8.0 * n * nleaves + 8.0)
+    if encoding == 'state' and batch0.device_bytes < nsites * 8 * n * nleaves / 4:
+        # the batch really is resident as states (SURVEY 8d: bytes/site drop to L; the
+        # kernel is then bound by instruction issue, not by HBM)
+        alg_bytes = nsites * (1.0 * nleaves + 8.0)
+    alg_flops = nsites * (2.0 * n * n * nedges + n * nedges + 2.0 * n)
+    avg_prune_s = prune_ms / max(prune_cnt, 1) * 1e-3
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'traffic_%s.json' % name)
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
+        except Exception:
+            traffic = None
+    if wl['bound'] == 'hbm':
+        achieved = alg_bytes / avg_prune_s / 1e9
+        roof = dict(bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
+                    frac=achieved / HBM_PEAK_GBS, traffic=traffic)
+        peak_for = lambda s: alg_bytes / s / 1e9 / HBM_PEAK_GBS
+    else:
+        peak, peak_src = f64_mfma_peak()
+        achieved = alg_flops / avg_prune_s / 1e12
+        roof = dict(bound='mfma', achieved=achieved, peak=peak, unit='TFLOP/s',
+                    frac=achieved / peak, traffic=traffic, peak_source=peak_src,
+                    frac_of_datasheet_78_6=achieved / F64_MFMA_DATASHEET_TFLOPS)
+        peak_for = lambda s: alg_flops / s / 1e12 / peak
+    roof.update(kernel=prune_name, avg_kernel_us=avg_prune_s * 1e6,
+                launches_timed=prune_cnt,
+                sampled_in_timed_region=sampled['prune'],
+                algorithmic_bytes_per_launch=alg_bytes,
+                algorithmic_flops_per_launch=alg_flops,
+                hbm_gbs=alg_bytes / avg_prune_s / 1e9,
+                step_level_frac=peak_for(elapsed / steps))
+    if interp is not None:
+        interp['frac'] = peak_for(interp['avg_kernel_us'] * 1e-6)
+
+    out = {
+        'value': total_sites * steps / elapsed if wl['scaling'] == 'strong'
+                 else nsites * world * steps / elapsed,
+        'unit': 'sites/s',
+        'steps': steps,
+        'warmup': warmup,
+        'ms_per_step': elapsed / steps * 1e3,
+        'host_enqueue_us_per_step': (t_enq - t0) / steps * 1e6,
+        'scaling': wl['scaling'],
+        'dtype': 'f64',
+        'config': {'workload': '%s: %s' % (
+                       name, wl['desc'] if encoding == 'dense' else
+                       wl['desc'].replace('dense f64 leaf likelihood vectors',
+                                          'uint8 leaf states (compact encoding)')),
+                   'encoding': encoding,
+                   'sites_per_gpu': nsites, 'sites_total': total_sites if wl['scaling'] == 'strong'
+                   else nsites * world,
+                   'states': n, 'leaves': nleaves,
+                   'edges': nedges, 'batches_rotated': len(batches),
+                   'reduce': reduce_kind,
+                   # hiprtc compile of the tree-specialised kernel: once per distinct
+                   # (tree, observed nodes) and context, in rt_sites_create, OUTSIDE the
+                   # timed region; `interpreter_kernel` is what the same batch runs at
+                   # until / without it (an MCMC over topologies lives there)
+                   'jit_compile_s': jit_compile_s,
+                   'upload_and_pack_s': upload_s,
+                   'interpreter_kernel': interp},
+        'roofline': roof,
+        'kernels_us': {'expm': expm_ms / max(expm_cnt, 1) * 1e3,
+                       'prune': avg_prune_s * 1e6,
+                       'reduce': red_ms / max(red_cnt, 1) * 1e3,
+                       'expm_kernel': expm_name,
+                       'launches_timed': prune_cnt,
+                       'sampled_in_timed_region': sampled},
+        'total_log_likelihood': float(totals[0]),
+    }
+    if world == 1 and cpu_seconds > 0 and name != 'c4':
+        out['cpu_baseline'] = cpu_baseline(cfg, ll0, cpu_seconds)
+        out['speedup_vs_reference_faithful_cpu'] = out['value'] / out['cpu_baseline']['value']
+    else:
+        out['cpu_baseline'] = None
+    batch0.close()
+    model.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=400)
-    ap.add_argument('--warmup', type=int, default=40)
-    ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS),
+                    help='the headline workload (top-level value / roofline / cpu_baseline)')
+    ap.add_argument('--also', default=None,
+                    help="comma-separated workloads carried under 'workloads' (default: the "
+                         "other ones of c2, c3, c5, plus c4; '' = none)")
     ap.add_argument('--sites', type=int, default=None,
-                    help='sites per GPU (default: the configuration size)')
+                    help='sites per GPU of the headline workload (c4: total sites; default: '
+                         'the configuration size)')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-rotate', action='store_true')
     ap.add_argument('--encoding', default='dense', choices=('dense', 'state'),
-                    help="resident observation encoding: 'dense' f64 leaf vectors (the "
-                         "headline, 8*n bytes per leaf) or 'state' (uint8 per leaf; "
+                    help="resident observation encoding of the headline workload: 'dense' f64 "
+                         "leaf vectors (8*n bytes per leaf) or 'state' (uint8 per leaf; "
                          "workloads whose leaves are observed states)")
     args = ap.parse_args()
 
@@ -167,45 +443,20 @@ def main():
                      '--nproc-per-node %d bench.py --gpus %d' % (args.gpus, args.gpus))
         args.gpus = world
 
-    from raoteh_amd import synth, device, _lib     # fails loudly without the .so
+    from raoteh_amd import device, _lib     # fails loudly without the .so
     from raoteh_amd.dist import SocketControl, init_rccl
     ctl = SocketControl(rank, world)
     ctx = device.Context(local_rank)
 
-    wl = WORKLOADS[args.workload]
-    cfg = synth.make_config(args.workload, nsites=args.sites)
-    nsites = cfg['leaf_states'].shape[0]
-    T, root, n = cfg['T'], cfg['root'], cfg['nstates']
-    nleaves = len(cfg['leaves'])
-    nedges = T.number_of_edges()
-    if world > 1:
-        # every rank owns a different block of sites (weak scaling: the
-        # configuration's site count per GPU), same tree and rates
-        rng = np.random.RandomState(1000 + rank)
-        cfg['leaf_states'] = cfg['leaf_states'][rng.permutation(nsites)]
-
-    model = device.TreeModel(T, root, n, ctx=ctx)
-    model.set_rates(Q_default=cfg['Q_default'])
-    model.set_root_distn(cfg['root_distn'])
-    if args.encoding == 'state':
-        if cfg['obs_kind'] != 'state':
-            raise SystemExit('--encoding state: the leaves of this workload are allowed-state '
-                             'sets, not states')
-        batch0 = model.upload_sites(cfg['leaves'], cfg['leaf_states'].astype(np.uint8),
-                                    kind='state')
+    if args.also is None:
+        also = [w for w in ('c2', 'c5', 'c4') if w != args.workload]
+        if args.workload != 'c3':
+            also.insert(0, 'c3')
     else:
-        dense = synth.leaf_likelihoods(cfg)
-        batch0 = model.upload_sites(cfg['leaves'], dense, kind='dense')
-        del dense
-    batches = [batch0]
-    uses_rccl = world > 1 or bool(os.environ.get('RAOTEH_BENCH_FORCE_RCCL'))
-    if not args.no_rotate:
-        # >= 640 MB of distinct HBM copies; with RCCL a ring of 8 so that the totals of
-        # one half are all-reduced while the other half is being computed
-        while len(batches) < 8 and (sum(b.device_bytes for b in batches) < 640 * 2 ** 20 or
-                                    (uses_rccl and batch0.device_bytes * (len(batches) + 1)
-                                     <= 16 * 2 ** 30)):
-            batches.append(batch0.clone())
+        also = [w for w in args.also.split(',') if w]
+        for w in also:
+            if w not in WORKLOADS:
+                sys.exit('unknown workload %r in --also' % w)
 
     # RCCL communicator for the data-path reduce.  librccl announces itself on stdout
     # ("Librccl path : ..."); stdout is for the one JSON line, so file descriptor 1
@@ -225,128 +476,43 @@ def main():
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
 
-    def step(j):
-        b = batches[j % len(batches)]
-        model.step(b)          # expm of every edge + prune + reduce (rt_step)
-        # RCCL: one all-reduce per HALF rotation of the batch ring, carrying the totals
-        # of its steps (3 doubles each) while the other half is being computed: the
-        # stream bookkeeping around a collective costs ~11 us of GPU time per call
-        # whatever the payload, a quarter of a C2 step
-        if reduce_kind == 'rccl':
-            grp = reduce_group_after_step(j, len(batches))
-            if grp is not None:
-                model.allreduce_group(batches[grp[0]:grp[1]])
-        return b
-
-    for j in range(args.warmup):
-        step(j)
-    ctx.sync()
-    ll0, st0 = model.fetch_log_likelihoods(batch0)
-    # HIP events stamped with each kernel's own begin / end (hipExtLaunchKernelGGL,
-    # on the library's stream), sampled: every 16th launch of each kernel, every
-    # 8th in short runs (timing every launch would cost ~20 us per step)
-    period = 16 if args.steps >= 160 else 8
-    ctx.set_timing(0 if os.environ.get('RAOTEH_BENCH_NO_EVENTS') else period)
-    ctx.reset_timing()
-
-    ctl.barrier()
-    ctx.sync()
-    t0 = time.perf_counter()
-    for j in range(args.steps):
-        last = step(j)
-    if reduce_kind == 'rccl':
-        grp = reduce_group_at_end(args.steps, len(batches))     # the incomplete group
-        if grp is not None:
-            model.allreduce_group(batches[grp[0]:grp[1]])
-    t_enq = time.perf_counter()      # all steps enqueued (the launches are asynchronous)
-    ctx.sync()
-    ctl.barrier()
-    t1 = time.perf_counter()
-    elapsed = float(ctl.allreduce([t1 - t0], np.max)[0])
-
-    totals = model.fetch_totals(last)
-    if reduce_kind == 'host-socket-fallback':
-        totals = ctl.allreduce(totals, np.sum)
-    if reduce_kind == 'none':
-        assert totals[2] == nsites
-    else:
-        assert totals[2] == nsites * world, totals
-    assert np.isfinite(totals[0]) and totals[1] == 0, totals
-
-    prune_ms, prune_cnt, prune_name = ctx.kernel_time(_lib.RT_K_PRUNE)
-    expm_ms, expm_cnt, expm_name = ctx.kernel_time(_lib.RT_K_EXPM)
-    red_ms, red_cnt, _ = ctx.kernel_time(_lib.RT_K_REDUCE)
-    ctx.set_timing(False)
-
+    cpu_s = 0.0 if args.no_cpu_baseline else args.cpu_seconds
+    head = run_workload(args.workload, ctx, ctl, rank, world, reduce_kind, args.steps,
+                        args.warmup, args, cpu_s)
+    extra = {}
+    for w in also:
+        # the carried workloads use their own short fixed step counts (c4: a step is
+        # ~20 ms per million sites) so that the default run still finishes in minutes
+        ksteps, kwarm = {'c2': (200, 20), 'c3': (100, 10), 'c5': (100, 10),
+                         'c4': (10, 2)}[w]
+        extra[w] = run_workload(w, ctx, ctl, rank, world, reduce_kind, ksteps, kwarm, args,
+                                min(cpu_s, 8.0))
     if rank != 0:
         return
 
-    alg_bytes = nsites * (8.0 * n * nleaves + 8.0)
-    if args.encoding == 'state' and batch0.device_bytes < nsites * 8 * n * nleaves / 4:
-        # the batch really is resident as states (bytes/site drop to L; the
-        # kernel is then bound by instruction issue, not by HBM)
-        alg_bytes = nsites * (1.0 * nleaves + 8.0)
-    alg_flops = nsites * (2.0 * n * n * nedges + n * nedges + 2.0 * n)
-    avg_prune_s = prune_ms / max(prune_cnt, 1) * 1e-3
-    if prune_cnt == 0:          # events disabled (overhead experiment only)
-        avg_prune_s = float('nan')
-    traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'traffic_%s.json' % args.workload)
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
-        except Exception:
-            traffic = None
-    if wl['bound'] == 'hbm':
-        achieved = alg_bytes / avg_prune_s / 1e9
-        roof = dict(bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
-                    frac=achieved / HBM_PEAK_GBS, traffic=traffic)
-    else:
-        achieved = alg_flops / avg_prune_s / 1e12
-        roof = dict(bound='mfma', achieved=achieved, peak=F64_MFMA_PEAK_TFLOPS,
-                    unit='TFLOP/s', frac=achieved / F64_MFMA_PEAK_TFLOPS,
-                    traffic=traffic)
-    roof.update(kernel=prune_name, avg_kernel_us=avg_prune_s * 1e6,
-                launches_timed=prune_cnt, algorithmic_bytes_per_launch=alg_bytes,
-                algorithmic_flops_per_launch=alg_flops,
-                hbm_gbs=alg_bytes / avg_prune_s / 1e9)
-
     out = {
         'metric': 'site log-likelihoods/sec (batched tree pruning)',
-        'value': nsites * world * args.steps / elapsed,
+        'value': head['value'],
         'unit': 'sites/s',
         'n_gpus': world,
         'steps': args.steps,
         'warmup': args.warmup,
-        'ms_per_step': elapsed / args.steps * 1e3,
-        'host_enqueue_us_per_step': (t_enq - t0) / args.steps * 1e6,
+        'ms_per_step': head['ms_per_step'],
+        'host_enqueue_us_per_step': head['host_enqueue_us_per_step'],
         'higher_is_better': True,
-        'scaling': 'weak',
+        'scaling': head['scaling'],
         'vs_baseline': None,
         'dtype': 'f64',
         'data': 'synthetic',
-        'config': {'workload': '%s: %s' % (
-                       args.workload, wl['desc'] if args.encoding == 'dense' else
-                       wl['desc'].replace('dense f64 leaf likelihood vectors',
-                                          'uint8 leaf states (compact encoding)')),
-                   'encoding': args.encoding,
-                   'sites_per_gpu': nsites, 'states': n, 'leaves': nleaves,
-                   'edges': nedges, 'batches_rotated': len(batches),
-                   'reduce': reduce_kind},
-        'roofline': roof,
-        'kernels_us': {'expm': expm_ms / max(expm_cnt, 1) * 1e3,
-                       'prune': avg_prune_s * 1e6,
-                       'reduce': red_ms / max(red_cnt, 1) * 1e3,
-                       'expm_kernel': expm_name},
-        'total_log_likelihood': float(totals[0]),
+        'config': head['config'],
+        'roofline': head['roofline'],
+        'kernels_us': head['kernels_us'],
+        'total_log_likelihood': head['total_log_likelihood'],
+        'cpu_baseline': head['cpu_baseline'],
     }
-    if world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(cfg, ll0, args.cpu_seconds)
-        out['cpu_baseline']['host_cpu_count'] = os.cpu_count()
-        out['speedup_vs_reference_faithful_cpu'] = (out['value'] /
-                                                    out['cpu_baseline']['value'])
-    else:
-        out['cpu_baseline'] = None
+    if head.get('speedup_vs_reference_faithful_cpu') is not None:
+        out['speedup_vs_reference_faithful_cpu'] = head['speedup_vs_reference_faithful_cpu']
+    out['workloads'] = extra
     print(json.dumps(out))
 
 

@@ -240,6 +240,10 @@ int rt_build_schedule(int64_t nnodes, const int64_t *tree_csr_indices,
  * bit-identical with and without it.  "jit_block_sites" (0 automatic, 1..64):
  * sites per wave of those kernels (automatic balances the waves over the CUs). */
 int rt_set_option(const char *key, int64_t value);
+/* The same options for ONE context (they take precedence over the process-wide
+ * defaults above; value -2 = back to the default): two contexts on two threads can
+ * then run with different settings without sharing mutable state.              */
+int rt_ctx_set_option(rt_ctx *ctx, const char *key, int64_t value);
 /* Diagnostics, host only: the HIP source rt_sites_create would compile for this
  * tree (n <= 32; MFMA family for n > 4), observation stream and prefetch distance. */
 int rt_jit_source(int64_t nnodes, const int64_t *tree_csr_indices,
@@ -256,6 +260,11 @@ int rt_sites_create(rt_model *model, int64_t nsites, int kind, int64_t nobs,
 int rt_sites_clone(rt_sites *sites, rt_sites **clone);
 int rt_sites_destroy(rt_sites *sites);
 int64_t rt_sites_device_bytes(const rt_sites *sites);
+/* Seconds rt_sites_create spent in hiprtc for this batch's tree-specialised kernel
+ * (0: none, or the kernel came from the cache), and the name of the pruning kernel
+ * variant the batch last ran (owned by the batch; "" before the first rt_prune). */
+double rt_sites_jit_compile_seconds(const rt_sites *sites);
+const char *rt_sites_kernel_name(const rt_sites *sites);
 
 int rt_prune(rt_model *model, rt_sites *sites);
 /* One evaluation of the repeated-evaluation loop (optimiser / MCMC iteration) in
@@ -273,6 +282,10 @@ int rt_sites_get_totals(rt_sites *sites, double totals[3]);
 
 /* rank 0 calls rt_comm_unique_id and ships the 128 bytes to the other ranks
  * by any host channel; then every rank calls rt_comm_init.                  */
+/* rt_comm_available: RT_OK iff librccl loads (dlopen + symbols only, no GPU, no
+ * network) -- the ranks agree on it over their host channel BEFORE any rank enters
+ * rt_comm_init, where a missing peer would be a hang.                        */
+int rt_comm_available(void);
 int rt_comm_unique_id(unsigned char id[128]);
 int rt_comm_init(rt_ctx *ctx, int nranks, int rank, const unsigned char id[128]);
 int rt_comm_destroy(rt_ctx *ctx);

@@ -98,6 +98,9 @@ SIGNATURES = {
     'rt_model_get_schedule': (c_int, [c_void_p, _p_i32, c_int64, _p_i64]),
     'rt_build_schedule': (c_int, [c_int64, _p_i64, _p_i64, _p_i32, _p_i32]),
     'rt_set_option': (c_int, [c_char_p, c_int64]),
+    'rt_ctx_set_option': (c_int, [c_void_p, c_char_p, c_int64]),
+    'rt_sites_jit_compile_seconds': (c_double, [c_void_p]),
+    'rt_sites_kernel_name': (c_char_p, [c_void_p]),
     'rt_jit_source': (c_int, [c_int64, _p_i64, _p_i64, c_int64, c_int64, _p_i64, c_int64,
                               c_char_p, c_int64]),
     'rt_sites_create': (c_int, [c_void_p, c_int64, c_int, c_int64, _p_i64,
@@ -109,6 +112,7 @@ SIGNATURES = {
     'rt_step': (c_int, [c_void_p, c_void_p, c_int]),
     'rt_sites_get_logliks': (c_int, [c_void_p, _p_f64, _p_i32]),
     'rt_sites_get_totals': (c_int, [c_void_p, _p_f64]),
+    'rt_comm_available': (c_int, []),
     'rt_comm_unique_id': (c_int, [POINTER(c_ubyte)]),
     'rt_comm_init': (c_int, [c_void_p, c_int, c_int, POINTER(c_ubyte)]),
     'rt_comm_destroy': (c_int, [c_void_p]),

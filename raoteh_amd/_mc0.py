@@ -11,20 +11,25 @@ __all__ = ['get_likelihood']
 
 
 def get_likelihood(root_pmap, root_distn=None):
-    if (root_distn is not None) and not root_distn:
+    """Likelihood from the root's subtree likelihoods {state: value} and optional root
+    weights {state: weight} (absent = weights of one, not a uniform prior).  Same
+    checks, in the same order, with the same exception classes as the reference
+    (_mc0.py:222-243): an empty prior, a missing / empty pmap, then no state common
+    to both all mean the likelihood is zero by sparsity."""
+    have_prior = root_distn is not None
+    if have_prior and len(root_distn) == 0:
         raise StructuralZeroProb('no root state has nonzero prior likelihood')
     if root_pmap is None:
         raise ValueError('root_pmap is None')
-    if not root_pmap:
+    if len(root_pmap) == 0:
         raise StructuralZeroProb(
             'all root states give a subtree likelihood of zero')
-    feasible_rstates = set(root_pmap)
-    if root_distn is not None:
-        feasible_rstates.intersection_update(set(root_distn))
-    if not feasible_rstates:
+    if not have_prior:
+        return sum(root_pmap.values())
+    terms = [value * root_distn[state] for state, value in root_pmap.items()
+             if state in root_distn]
+    if not terms:
         raise StructuralZeroProb(
             'all root states have either zero prior likelihood '
             'or give a subtree likelihood of zero')
-    if root_distn is not None:
-        return sum(root_pmap[s] * root_distn[s] for s in feasible_rstates)
-    return sum(root_pmap.values())
+    return sum(terms)

@@ -23,34 +23,38 @@ __all__ = ['get_likelihood', 'get_node_to_distn', 'get_node_to_distn_esd',
 
 
 def get_likelihood(root_pmap, root_distn=None):
+    """Root reduction with the reference's error protocol (_mc0_dense.py:167-212):
+    shape mismatch -> ValueError; an all-zero prior, an all-zero pmap, or no state
+    with both a positive weight and a positive subtree likelihood ->
+    StructuralZeroProb (in that order); negative pmap entries are reported and
+    clamped.  ``root_distn`` None = weights of one (_mjp_dense.py:389-393)."""
+    weights = None
     if root_distn is not None:
-        if root_pmap.shape != root_distn.shape:
-            raise ValueError('root shape mismatch: '
-                             '%s %s' % (root_pmap.shape, root_distn.shape))
-        prior_feasible_rstates = set(s for s, p in enumerate(root_distn) if p)
-        if not prior_feasible_rstates:
-            raise StructuralZeroProb(
-                'no root state has nonzero prior likelihood')
+        weights = np.asarray(root_distn)
+        if np.shape(root_pmap) != weights.shape:
+            raise ValueError('root shape mismatch: %s %s' % (np.shape(root_pmap),
+                                                             weights.shape))
+        if not np.any(weights != 0):
+            raise StructuralZeroProb('no root state has nonzero prior likelihood')
     if root_pmap is None:
         raise ValueError('root_pmap is None')
-    root_pmap_min = root_pmap.min()
-    if root_pmap_min < 0:
+    pmap = np.asarray(root_pmap)
+    lowest = pmap.min()
+    if lowest < 0:
         warnings.warn('root_pmap should have non-negative entries '
-                      'but found minimum entry %s' % root_pmap_min)
-        root_pmap = np.maximum(root_pmap, 0)
-    if not root_pmap.sum():
+                      'but found minimum entry %s' % lowest)
+        pmap = pmap.clip(min=0)
+    support = pmap != 0                       # states the data allow at the root
+    if not support.any():
         raise StructuralZeroProb(
             'all root states give a subtree likelihood of zero')
-    feasible_rstates = set(s for s, p in enumerate(root_pmap) if p)
-    if root_distn is not None:
-        feasible_rstates.intersection_update(prior_feasible_rstates)
-    if not feasible_rstates:
+    if weights is not None:
+        support = support & (weights != 0)    # ... that the prior allows as well
+    if not support.any():
         raise StructuralZeroProb(
             'all root states have either zero prior likelihood '
             'or give a subtree likelihood of zero')
-    if root_distn is not None:
-        return root_distn.dot(root_pmap)
-    return root_pmap.sum()
+    return pmap.sum() if weights is None else weights.dot(pmap)
 
 
 def get_node_to_distn(T, root, node_to_pmap, nstates, root_distn=None,

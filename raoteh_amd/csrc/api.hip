@@ -4,6 +4,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <atomic>
 #include <functional>
 #include <cmath>
 #include <cstdlib>
@@ -178,7 +179,7 @@ void rt_time_begin(rt_ctx *ctx, int kernel, const char *name, hipEvent_t *start)
     *start = nullptr;
     ctx->ev_start = ctx->ev_stop = nullptr;
     rt_timing_slot &s = ctx->slots[kernel];
-    if (name && name[0]) s.name = name;
+    if (name && name[0]) snprintf(s.name, sizeof(s.name), "%s", name);
     if (!ctx->timing) return;
     if ((s.seen++ % ctx->timing_period) != 0) return;
     hipEvent_t a = slot_event(s), b = slot_event(s);
@@ -552,25 +553,61 @@ extern "C" int rt_model_schedule_depth(const rt_model *m)
 // ---- sites ------------------------------------------------------------------------------------
 
 static const int RT_FAST_MAX_DEPTH = 16;   // LDS accumulator stack of the fast kernels
-static int g_force_generic = 0;
+// Process-wide defaults (rt_set_option); a context's own value (rt_ctx_set_option)
+// takes precedence.  Atomics: two threads with a context each may create batches
+// while a third changes a default.
+static std::atomic<int> g_force_generic{0};
 // tree-specialised kernels (jit.hip): -1 = automatic (batches of at least
 // RT_JIT_MIN_WORK site-states), 0 = never, 1 = always
-static int g_jit = -1;
+static std::atomic<int> g_jit{-1};
 static const int64_t RT_JIT_MIN_WORK = 65536;
-static int g_jit_block_sites = 0;    // 0 = automatic (see sites_jit)
+static std::atomic<int> g_jit_block_sites{0};    // 0 = automatic (see sites_jit)
 
-extern "C" int rt_set_option(const char *key, int64_t value)
+static int parse_option(const char *key, int64_t value, int *which, int *out)
 {
     RT_REQUIRE(key, "null key");
-    if (strcmp(key, "force_generic") == 0) { g_force_generic = value != 0; return RT_OK; }
-    if (strcmp(key, "jit") == 0) { g_jit = value < 0 ? -1 : value != 0; return RT_OK; }
+    if (strcmp(key, "force_generic") == 0) { *which = 0; *out = value != 0; return RT_OK; }
+    if (strcmp(key, "jit") == 0) { *which = 1; *out = value < 0 ? -1 : value != 0; return RT_OK; }
     if (strcmp(key, "jit_block_sites") == 0) {
         RT_REQUIRE(value >= 0 && value <= 64, "jit_block_sites must be 0 (automatic) .. 64");
-        g_jit_block_sites = (int)value;
+        *which = 2;
+        *out = (int)value;
         return RT_OK;
     }
     rt_set_error("unknown option %s", key);
     return RT_ERR_INVALID;
+}
+
+extern "C" int rt_set_option(const char *key, int64_t value)
+{
+    int which = 0, v = 0;
+    RT_TRY(parse_option(key, value, &which, &v));
+    (which == 0 ? g_force_generic : which == 1 ? g_jit : g_jit_block_sites).store(v);
+    return RT_OK;
+}
+
+extern "C" int rt_ctx_set_option(rt_ctx *ctx, const char *key, int64_t value)
+{
+    RT_REQUIRE(ctx, "null context");
+    int which = 0, v = 0;
+    if (key && value == RT_OPT_UNSET) {          // back to the process-wide default
+        RT_TRY(parse_option(key, 0, &which, &v));
+        v = RT_OPT_UNSET;
+    } else {
+        RT_TRY(parse_option(key, value, &which, &v));
+    }
+    (which == 0 ? ctx->opt_force_generic : which == 1 ? ctx->opt_jit : ctx->opt_jit_block_sites) = v;
+    return RT_OK;
+}
+
+static int opt_force_generic(const rt_ctx *c)
+{
+    return c->opt_force_generic != RT_OPT_UNSET ? c->opt_force_generic : g_force_generic.load();
+}
+static int opt_jit(const rt_ctx *c) { return c->opt_jit != RT_OPT_UNSET ? c->opt_jit : g_jit.load(); }
+static int opt_jit_block_sites(const rt_ctx *c)
+{
+    return c->opt_jit_block_sites != RT_OPT_UNSET ? c->opt_jit_block_sites : g_jit_block_sites.load();
 }
 
 extern "C" int rt_sites_destroy(rt_sites *s)
@@ -765,7 +802,7 @@ static int sites_alloc(rt_sites *s, bool generic)
 // schedule, compiled once per distinct (tree, observed nodes) and device.
 static int sites_jit(rt_sites *s, bool generic, int kind)
 {
-    int want = g_jit;
+    int want = opt_jit(s->model->ctx);
     if (const char *v = getenv("RAOTEH_JIT")) want = atoi(v);
     const bool forced = want > 0;
     // automatic: enough work per batch to be worth a second or two of compilation
@@ -795,7 +832,7 @@ static int sites_jit(rt_sites *s, bool generic, int kind)
             for (; T >= 1 && rc == RT_ERR_UNSUPPORTED; --T) {     // fewer tiles if it spills
                 const std::string src =
                     rt_jit_mfma_split_source(s->ops, (int)s->model->n, (int)s->nobs, T, D, LA);
-                rc = rt_jit_get(s->model->ctx, src, &s->jit_fn, true);
+                rc = rt_jit_get(s->model->ctx, src, &s->jit_fn, true, &s->jit_compile_s);
             }
             ++T;
             if (rc != RT_OK && (!forced || rc == RT_ERR_UNSUPPORTED)) {
@@ -828,7 +865,7 @@ static int sites_jit(rt_sites *s, bool generic, int kind)
         for (; T >= 1 && rc == RT_ERR_UNSUPPORTED; --T) {         // fewer tiles if it spills
             const std::string src =
                 rt_jit_mfma_source(s->ops, (int)s->model->n, (int)s->nobs, T, D, LA);
-            rc = rt_jit_get(s->model->ctx, src, &s->jit_fn, true);
+            rc = rt_jit_get(s->model->ctx, src, &s->jit_fn, true, &s->jit_compile_s);
         }
         ++T;
         if (rc != RT_OK && (!forced || rc == RT_ERR_UNSUPPORTED)) {
@@ -880,7 +917,7 @@ static int sites_jit(rt_sites *s, bool generic, int kind)
     } else {
         while (WG < 8 && (8 / WG) * tables > 150 * 1024) WG *= 2;
     }
-    if (g_jit_block_sites > 0) S = g_jit_block_sites;
+    if (opt_jit_block_sites(s->model->ctx) > 0) S = opt_jit_block_sites(s->model->ctx);
     if (const char *v = getenv("RAOTEH_JIT_BLOCK_SITES")) S = atoi(v);
     if (const char *v = getenv("RAOTEH_JIT_WAVES")) WG = atoi(v);
     S = std::min(64, std::max(1, S));
@@ -888,7 +925,7 @@ static int sites_jit(rt_sites *s, bool generic, int kind)
     const std::string src =
         rt_jit_lane_source(s->ops, (int)s->model->n, (int)s->nobs, D, LA, S, WG, states);
     s->jit_prefetch = D;
-    const int rc = rt_jit_get(s->model->ctx, src, &s->jit_fn);
+    const int rc = rt_jit_get(s->model->ctx, src, &s->jit_fn, false, &s->jit_compile_s);
     if (rc != RT_OK && (!forced || rc == RT_ERR_UNSUPPORTED)) {
         // the interpreter kernel (prune.hip) computes the same numbers;
         // rt_last_error() keeps the compiler's message / the rejection
@@ -976,7 +1013,7 @@ extern "C" int rt_sites_create(rt_model *m, int64_t nsites, int kind, int64_t no
             src_of_k.push_back(j);
         }
     }
-    const bool generic = g_force_generic || m->max_depth > RT_FAST_MAX_DEPTH;
+    const bool generic = opt_force_generic(m->ctx) || m->max_depth > RT_FAST_MAX_DEPTH;
     s->layout = (generic || m->n <= 4) ? RT_LAYOUT_LANE : RT_LAYOUT_MFMA;
     // tuning knobs of the lane family (A/B measurements)
     // Default: leaf vectors through the LDS-DMA ring (3 slots) when two 4-wave
@@ -1050,6 +1087,16 @@ extern "C" int rt_sites_clone(rt_sites *src, rt_sites **out)
 extern "C" int64_t rt_sites_device_bytes(const rt_sites *s)
 {
     return s ? s->obs_bytes : 0;
+}
+
+extern "C" double rt_sites_jit_compile_seconds(const rt_sites *s)
+{
+    return s ? s->jit_compile_s : 0.0;
+}
+
+extern "C" const char *rt_sites_kernel_name(const rt_sites *s)
+{
+    return s ? s->kernel_name : "";
 }
 
 extern "C" int rt_prune(rt_model *m, rt_sites *s)

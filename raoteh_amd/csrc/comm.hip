@@ -63,6 +63,14 @@ int rccl_fail(const char *what, int code)
 
 }  // namespace
 
+// RT_OK iff librccl can be loaded and exports what rt_comm_init needs.  Touches no
+// GPU and no network: the ranks agree on this BEFORE any of them enters
+// ncclCommInitRank (raoteh_amd/dist.py init_rccl), where a missing peer is a hang.
+extern "C" int rt_comm_available(void)
+{
+    return load_rccl();
+}
+
 extern "C" int rt_comm_unique_id(unsigned char id[128])
 {
     RT_REQUIRE(id, "null id");

@@ -50,7 +50,7 @@ struct rt_timing_slot {
     double total_ms = 0.0;
     int64_t launches = 0;
     int64_t seen = 0;
-    const char *name = "";
+    char name[64] = "";        // variant that ran last (owned by the slot: no statics)
 };
 
 static const int RT_TOTALS_SLOTS = 4096;   // site batches per context sharing the arena
@@ -78,7 +78,15 @@ struct rt_ctx {
     void *comm = nullptr;          // ncclComm_t
     hipStream_t comm_stream = nullptr;   // collectives overlap the next step's kernels
     void *rccl = nullptr;          // dlopen handle
+    // options snapshotted by rt_sites_create (rt_ctx_set_option); RT_OPT_UNSET = the
+    // process-wide default of rt_set_option applies
+    int opt_force_generic = -2;
+    int opt_jit = -2;
+    int opt_jit_block_sites = -2;
+    size_t expm_attr_lds = 0;      // dynamic-LDS attribute already granted to expm_kernel
+    size_t expm_ts_attr_lds = 0;   // ... to the Taylor kernels
 };
+static const int RT_OPT_UNSET = -2;
 
 // One schedule step of the fast pruning kernels: a node of the tree visited in
 // post-order.  For a non-root node v the step forms L_v (pop its accumulator if
@@ -158,6 +166,8 @@ struct rt_sites {
                                     // as one byte per leaf: 1 = uint8 states, 2 = allowed-set masks
     double *d_scratch = nullptr;    // generic kernel message stack
     int64_t scratch_bytes = 0;
+    char kernel_name[64] = "";      // the pruning kernel variant of this batch
+    double jit_compile_s = 0.0;     // hiprtc time spent for this batch (0: cache hit / none)
 };
 
 // ---- internal entry points ---------------------------------------------------------
@@ -188,7 +198,8 @@ std::string rt_jit_lane_source(const std::vector<rt_op> &ops, int n, int K, int 
 std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int T, int D, int LA);
 std::string rt_jit_mfma_split_source(const std::vector<rt_op> &ops, int n, int K, int T, int D,
                                      int LA);
-int rt_jit_get(rt_ctx *ctx, const std::string &src, void **fn, bool mfma = false);
+int rt_jit_get(rt_ctx *ctx, const std::string &src, void **fn, bool mfma = false,
+               double *compile_s = nullptr);
 void rt_jit_ref(const rt_ctx *ctx, void *fn, int delta);
 void rt_jit_release(const rt_ctx *ctx);
 int rt_launch_prune_jit(rt_model *m, rt_sites *s);

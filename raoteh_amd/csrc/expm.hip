@@ -649,7 +649,7 @@ int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
     if (count <= 0) return RT_OK;
     const int ld = (int)n | 1;
     const size_t lds = (size_t)5 * n * ld * 8 + (128 + 128 + 64) * 8 + (8 + 64) * 4;
-    static size_t attr_lds = 0;
+    size_t &attr_lds = ctx->expm_attr_lds;
     if (lds > attr_lds) {
         RT_HIP(hipFuncSetAttribute((const void *)expm_kernel,
                                    hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -1356,7 +1356,6 @@ static int launch_lane_dma(rt_model *m, rt_sites *s)
 template <int N>
 static int launch_lane(rt_model *m, rt_sites *s, const char **name)
 {
-    static char buf[5][64];
     int R = s->lane_ring;
     int B = 1, W = 4;
     int rc;
@@ -1396,11 +1395,11 @@ static int launch_lane(rt_model *m, rt_sites *s, const char **name)
         }
     }
     if (s->lane_dma)
-        snprintf(buf[N], sizeof(buf[N]), "prune_lane<%d,dma,R%d,B%d,W%d>", N, R, B, W);
+        snprintf(s->kernel_name, sizeof(s->kernel_name), "prune_lane<%d,dma,R%d,B%d,W%d>", N, R, B, W);
     else
-        snprintf(buf[N], sizeof(buf[N]), "prune_lane<%d,%s,R%d>", N,
+        snprintf(s->kernel_name, sizeof(s->kernel_name), "prune_lane<%d,%s,R%d>", N,
                  plds ? "reg+ldsP" : "reg", R);
-    *name = buf[N];
+    *name = s->kernel_name;
     return rc;
 }
 
@@ -1439,11 +1438,10 @@ static int launch_mfma_inst(rt_model *m, rt_sites *s)
 
 static int launch_mfma(rt_model *m, rt_sites *s, const char **name)
 {
-    static char buf[17][32];
     const int ks = ks_of(m->n);
-    snprintf(buf[ks], sizeof(buf[ks]), "prune_mfma%s<%d,%d>", s->mfma_solo ? "_solo" : "",
-             nt_of(m->n), ks);
-    *name = buf[ks];
+    snprintf(s->kernel_name, sizeof(s->kernel_name), "prune_mfma%s<%d,%d>",
+             s->mfma_solo ? "_solo" : "", nt_of(m->n), ks);
+    *name = s->kernel_name;
     switch (ks) {
     case 2: return launch_mfma_inst<1, 2>(m, s);
     case 3: return launch_mfma_inst<1, 3>(m, s);
@@ -1495,16 +1493,16 @@ int rt_launch_prune(rt_model *m, rt_sites *s)
     if (!generic) RT_TRY(rt_launch_pfrag(m));
     rt_time_begin(ctx, RT_K_PRUNE, "", &ev);
     int rc;
-    static char jit_name[48];
+    char *jit_name = s->kernel_name;
     if (generic) rc = launch_generic(m, s, &name);
     else if (s->jit_fn) {
         rc = rt_launch_prune_jit(m, s);
         if (s->layout == RT_LAYOUT_LANE)
-            snprintf(jit_name, sizeof(jit_name), "prune_tree_jit<%d,D%d%s>", (int)m->n,
+            snprintf(jit_name, sizeof(s->kernel_name), "prune_tree_jit<%d,D%d%s>", (int)m->n,
                      s->jit_prefetch, s->compact_states == 1 ? ",states"
                                       : s->compact_states == 2 ? ",masks" : "");
         else
-            snprintf(jit_name, sizeof(jit_name), "prune_tree_jit_mfma<%d,T%d>", (int)m->n,
+            snprintf(jit_name, sizeof(s->kernel_name), "prune_tree_jit_mfma<%d,T%d>", (int)m->n,
                      s->jit_tiles);
         name = jit_name;
     } else if (s->layout == RT_LAYOUT_LANE) {
@@ -1517,7 +1515,8 @@ int rt_launch_prune(rt_model *m, rt_sites *s)
     } else rc = launch_mfma(m, s, &name);
     if (rc != RT_OK) return rc;
     RT_HIP(hipGetLastError());
-    ctx->slots[RT_K_PRUNE].name = name;
+    snprintf(ctx->slots[RT_K_PRUNE].name, sizeof(ctx->slots[RT_K_PRUNE].name), "%s", name);
+    if (name != s->kernel_name) snprintf(s->kernel_name, sizeof(s->kernel_name), "%s", name);
     rt_time_end(ctx, RT_K_PRUNE, ev);
 
     if (s->comm_pending) {

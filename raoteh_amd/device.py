@@ -46,6 +46,24 @@ def _ptr(a, ctype):
     return a.ctypes.data_as(ctypes.POINTER(ctype))
 
 
+def _as_uint8_states(data, nstates):
+    """Observed states -> uint8 (255 = unobserved).  A plain cast would wrap a state
+    >= 256 (or a negative one) onto another state silently; anything that is neither a
+    state in [0, nstates) nor the 255 / -1 'unobserved' marker is an error."""
+    a = np.asarray(data)
+    if a.dtype == np.uint8:
+        bad = (a >= nstates) & (a != 255)
+    else:
+        if not np.issubdtype(a.dtype, np.integer):
+            raise ValueError('observed states must be integers')
+        bad = ((a < 0) | (a >= nstates)) & (a != 255) & (a != -1)
+        a = np.where(a == -1, 255, a)
+    if nstates > 255 or bad.any():
+        raise ValueError('observed state outside [0, %d) (255 or -1 = unobserved)'
+                         % nstates)
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
 def device_count():
     n = c_int(0)
     _lib.check(_lib.lib().rt_device_count(byref(n)))
@@ -73,6 +91,12 @@ class Context(object):
 
     def sync(self):
         _lib.check(_lib.lib().rt_ctx_sync(self._h))
+
+    def set_option(self, key, value):
+        """Per-context option (rt_ctx_set_option): 'jit' (-1 automatic / 0 / 1),
+        'force_generic', 'jit_block_sites'; value None = back to the process default."""
+        _lib.check(_lib.lib().rt_ctx_set_option(
+            self._h, key.encode(), -2 if value is None else int(value)))
 
     def set_timing(self, enabled):
         """False/0: off; True/1: every launch; N > 1: every N-th launch of each
@@ -249,7 +273,7 @@ class Context(object):
         nnodes, n = esd.shape[0], esd.shape[1]
         obs_nodes = _i64(obs_nodes)
         if kind == 'state':
-            data = np.ascontiguousarray(data, dtype=np.uint8)
+            data = _as_uint8_states(data, n)
             code = _lib.RT_OBS_STATE
         elif kind == 'mask':
             data = np.ascontiguousarray(data, dtype=np.uint64)
@@ -278,6 +302,11 @@ class Context(object):
         return W, root_post, status
 
     # ---- multi-GPU ---------------------------------------------------------
+
+    @staticmethod
+    def comm_available():
+        """True iff librccl can be loaded (no GPU / network touched)."""
+        return _lib.lib().rt_comm_available() == _lib.RT_OK
 
     @staticmethod
     def comm_unique_id():
@@ -317,6 +346,16 @@ class SiteBatch(object):
     @property
     def device_bytes(self):
         return _lib.lib().rt_sites_device_bytes(self._h)
+
+    @property
+    def jit_compile_seconds(self):
+        """hiprtc seconds spent for this batch's tree-specialised kernel (0: none
+        compiled, or it came from the cache)."""
+        return _lib.lib().rt_sites_jit_compile_seconds(self._h)
+
+    @property
+    def kernel_name(self):
+        return (_lib.lib().rt_sites_kernel_name(self._h) or b'').decode()
 
     def close(self):
         if self._h and not _shutting_down:
@@ -423,7 +462,7 @@ class TreeModel(object):
             data = _f64(data)
             ok = data.ndim == 3 and data.shape[2] == self.nstates
         elif kind == 'state':
-            data = np.ascontiguousarray(data, dtype=np.uint8)
+            data = _as_uint8_states(data, self.nstates)
             ok = data.ndim == 2
         else:
             data = np.ascontiguousarray(data, dtype=np.uint64)

@@ -191,20 +191,62 @@ def reduce_history_statistics(stats, control):
 
 def init_rccl(ctx, control):
     """Create the RCCL communicator of ``ctx`` across the ranks of ``control``.
-    Returns True on every rank or False on every rank (never mixed)."""
-    ok = 1.0
-    if control.world > 1:
+    Returns True on every rank or False on every rank (never mixed).
+
+    Every rank takes part in every control-plane collective below, whatever failed
+    locally, so the byte streams of the control plane never desynchronise:
+
+    1. min-reduce "librccl loads here" (``ctx.comm_available()``: dlopen only).  If any
+       rank lacks it, nobody enters ``ncclCommInitRank`` -- a rank waiting there for a
+       peer that never comes would hang.
+    2. rank 0 creates the unique id; ALL ranks all-gather (flag byte + 128 id bytes).
+       A failed id creation is a cleared flag, not a skipped collective.
+    3. every rank calls ``ctx.comm_init``; min-reduce the outcome; on disagreement the
+       ranks that did get a communicator destroy it again.
+    (A rank dying INSIDE ncclCommInitRank is RCCL's to time out; the host side cannot
+    see it.)"""
+    if control.world <= 1:
+        return True
+    import sys
+
+    def note(msg):
+        sys.stderr.write('rank %d: RCCL unavailable: %s\n' % (control.rank, msg))
+
+    try:
+        avail = 1.0 if ctx.comm_available() else 0.0
+    except Exception as e:
+        note(e)
+        avail = 0.0
+    if float(control.allreduce([avail], np.min)[0]) < 1.0:
+        if avail:
+            note('another rank cannot load librccl')
+        return False
+    payload = bytes(129)
+    if control.rank == 0:
         try:
-            from .device import Context
-            uid = Context.comm_unique_id() if control.rank == 0 else bytes(128)
-            uid = control.allgather(uid)[0]
-            ctx.comm_init(control.world, control.rank, uid)
-        except Exception as e:                      # keep the job alive
-            import sys
-            sys.stderr.write('rank %d: RCCL unavailable: %s\n' % (control.rank, e))
-            ok = 0.0
-        ok = float(control.allreduce([ok], np.min)[0])
-    return ok >= 1.0
+            payload = b'\x01' + bytes(ctx.comm_unique_id())
+            if len(payload) != 129:
+                raise RuntimeError('unique id has %d bytes' % (len(payload) - 1))
+        except Exception as e:
+            note(e)
+            payload = bytes(129)
+    head = control.allgather(payload)[0]
+    if head[:1] != b'\x01':
+        return False
+    ok = 1.0
+    try:
+        ctx.comm_init(control.world, control.rank, head[1:])
+    except Exception as e:
+        note(e)
+        ok = 0.0
+    if float(control.allreduce([ok], np.min)[0]) < 1.0:
+        if ok:
+            try:
+                ctx.comm_destroy()
+            except Exception as e:
+                note(e)
+        return False
+    return True
 
 
 class ShardedLikelihood(object):

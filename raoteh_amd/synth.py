@@ -214,8 +214,21 @@ def blinking_allowed_states(primary_state, nprimary, primary_to_part):
 # ---------------------------------------------------------------------------
 
 def _expm(Q, t):
-    import scipy.linalg
-    return scipy.linalg.expm(np.asarray(Q) * t)
+    """exp(Q t) for SIMULATING data on the host (numpy only; the product's expm is
+    the device kernel): scaling and squaring around a degree-18 Taylor polynomial,
+    ||A / 2^s||_1 <= 0.5 (truncation error < 1e-21 there)."""
+    A = np.asarray(Q, dtype=float) * float(t)
+    nrm = np.abs(A).sum(axis=0).max() if A.size else 0.0
+    s = max(0, int(np.ceil(np.log2(nrm / 0.5)))) if nrm > 0.5 else 0
+    A = A / (2.0 ** s)
+    X = np.eye(A.shape[0])
+    term = np.eye(A.shape[0])
+    for k in range(1, 19):
+        term = term.dot(A) / k
+        X = X + term
+    for _ in range(s):
+        X = X.dot(X)
+    return X
 
 
 def simulate_states(T, root, node_to_P, root_distn, nsites, seed):
@@ -233,9 +246,14 @@ def simulate_states(T, root, node_to_P, root_distn, nsites, seed):
         cdf = np.cumsum(np.maximum(P, 0.0), axis=1)
         cdf /= cdf[:, -1:]
         u = rng.uniform(size=nsites)
-        rows = cdf[out[na]]
-        s = (u[:, None] >= rows).sum(axis=1)
-        out[nb] = np.minimum(s, P.shape[0] - 1).astype(np.int64)
+        # child state = #{j: u >= cdf[parent, j]}: one searchsorted per parent state
+        # (a [nsites, n] gather of cdf rows would be 0.5 GB per edge at 10^6 codon sites)
+        parent = out[na]
+        s = np.empty(nsites, dtype=np.int64)
+        for a in np.unique(parent):
+            sel = np.flatnonzero(parent == a)
+            s[sel] = np.searchsorted(cdf[a], u[sel], side='right')
+        out[nb] = np.minimum(s, P.shape[0] - 1)
     return out
 
 
@@ -247,8 +265,38 @@ def one_hot(states, nstates):
     return out
 
 
-def make_config(name, nsites=None):
+C4_NSITES = 1000000
+C4_CHUNK = 15625          # 64 chunks; chunk c is simulated from RandomState([3, c])
+
+
+def c4_leaf_states(lo, hi, T, root, leaves, Q, distn):
+    """Sites [lo, hi) of THE config-4 batch (1 000 000 codon sites, seed 3).  The
+    batch is defined chunk by chunk (C4_CHUNK sites from RandomState([3, chunk])),
+    so a rank simulates only the chunks its shard_range overlaps and every rank
+    count sees the same million sites."""
+    if not (0 <= lo <= hi <= C4_NSITES):
+        raise ValueError('site range outside the config-4 batch')
+    node_to_P = dict((nb, _expm(Q, T[na][nb]['weight']))
+                     for na, nb in nx.bfs_edges(T, root))
+    parts = []
+    for c in range(lo // C4_CHUNK, -(-hi // C4_CHUNK)):
+        states = simulate_states(T, root, node_to_P, distn, C4_CHUNK,
+                                 np.array([3, c], dtype=np.uint32))
+        chunk = np.stack([states[v] for v in leaves], axis=1)
+        a = max(lo, c * C4_CHUNK) - c * C4_CHUNK
+        b = min(hi, (c + 1) * C4_CHUNK) - c * C4_CHUNK
+        parts.append(chunk[a:b])
+    if not parts:
+        return np.zeros((0, len(leaves)), dtype=np.int64)
+    return np.concatenate(parts, axis=0)
+
+
+def make_config(name, nsites=None, site_range=None):
     """Build one of the BASELINE.json configurations.
+
+    ``site_range=(lo, hi)`` (config 4 only): that slice of the one million-site
+    batch (what rank r of a sharded run uploads: dist.shard_range); ``nsites`` for
+    c4 is shorthand for ``site_range=(0, nsites)``.
 
     Returns a dict with keys: name, T (nx.Graph with 'weight' and, for C5, 'Q'
     per edge), root, leaves, nstates, Q_default (or None), root_distn,
@@ -265,12 +313,21 @@ def make_config(name, nsites=None):
         Q, distn = hky85()
         nsites = 100000 if nsites is None else nsites
         seed = 1
-    elif name in ('c3', 'c4'):
+    elif name == 'c4':
         T, root, leaves = balanced_tree(64, seed=0)
         Q, distn = mg94()
-        default = 10000 if name == 'c3' else 1000000
-        nsites = default if nsites is None else nsites
-        seed = 2 if name == 'c3' else 3
+        if site_range is None:
+            site_range = (0, C4_NSITES if nsites is None else nsites)
+        leaf_states = c4_leaf_states(site_range[0], site_range[1], T, root, leaves,
+                                     Q, distn)
+        return dict(name=name, T=T, root=root, leaves=leaves, nstates=len(distn),
+                    Q_default=Q, root_distn=distn, leaf_states=leaf_states,
+                    obs_kind='state', site_range=tuple(site_range))
+    elif name == 'c3':
+        T, root, leaves = balanced_tree(64, seed=0)
+        Q, distn = mg94()
+        nsites = 10000 if nsites is None else nsites
+        seed = 2
     elif name == 'c5':
         return _make_c5(50000 if nsites is None else nsites)
     else:

@@ -17,7 +17,37 @@ import torch.distributed as dist                      # noqa: E402
 from oracle import oracle_numpy as orc                # noqa: E402
 from raoteh_amd import synth                          # noqa: E402
 from raoteh_amd.dist import (SocketControl, TorchControl, env_rank_world,  # noqa: E402
-                             reduce_history_statistics, reduce_totals, shard_range)
+                             init_rccl, reduce_history_statistics, reduce_totals,
+                             shard_range)
+
+
+class StubComm(object):
+    """Stands in for device.Context in init_rccl: `fail` = (stage, rank) makes that
+    stage fail on that rank only."""
+
+    def __init__(self, rank, fail):
+        self.rank, self.fail = rank, fail
+        self.inited = self.destroyed = False
+
+    def _hit(self, stage):
+        return self.fail == (stage, self.rank)
+
+    def comm_available(self):
+        return not self._hit('load')
+
+    def comm_unique_id(self):
+        if self._hit('uid'):
+            raise RuntimeError('stub: ncclGetUniqueId failed')
+        return bytes(range(128))
+
+    def comm_init(self, world, rank, uid):
+        assert uid == bytes(range(128))
+        if self._hit('init'):
+            raise RuntimeError('stub: ncclCommInitRank failed')
+        self.inited = True
+
+    def comm_destroy(self):
+        self.destroyed = True
 
 
 def main():
@@ -62,6 +92,20 @@ def main():
     results['expect_socket'] = [a.tolist() for a in got]
     if rank == 0:
         results['expect_want'] = [a.tolist() for a in shard_statistics(0, 7)]
+    # RCCL bring-up with one rank failing at each stage: every rank must get the same
+    # answer and the control plane must stay in step (the reduce after it is right)
+    rccl = []
+    for ctl in (tc, sc):
+        for fail in (None, ('load', 0), ('load', world - 1), ('uid', 0), ('init', 0),
+                     ('init', world - 1)):
+            stub = StubComm(rank, fail)
+            got = init_rccl(stub, ctl)
+            after = float(ctl.allreduce([rank + 1.0], np.sum)[0])
+            answers = ctl.allgather(bytes([1 if got else 0]))
+            rccl.append(dict(fail=fail, got=got, agree=len(set(answers)) == 1,
+                             after_ok=after == world * (world + 1) / 2.0,
+                             leaked=bool(stub.inited and not got and not stub.destroyed)))
+    results['rccl'] = rccl
     results['socket'] = reduce_totals(local, sc).tolist()
     results['max_rank'] = float(sc.allreduce([float(rank)], np.max)[0])
     sc.barrier()

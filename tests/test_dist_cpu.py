@@ -66,6 +66,12 @@ def test_sharded_reduce_matches_single_process(tmp_path, world):
     for key in ('expect_gloo', 'expect_socket'):
         for got_arr, want_arr in zip(res[key], res['expect_want']):
             np.testing.assert_allclose(got_arr, want_arr, rtol=1e-13, atol=1e-15)
+    # init_rccl with a rank failing at each stage (rank 0 used to skip the
+    # all-gather and desynchronise the control plane; the others hung)
+    assert len(res['rccl']) == 12
+    for row in res['rccl']:
+        assert row['agree'] and row['after_ok'] and not row['leaked'], row
+        assert row['got'] == (row['fail'] is None), row
     ranges = res['ranges']
     assert ranges[0][0] == 0 and ranges[-1][1] == 1003
     for a, b in zip(ranges, ranges[1:]):
