@@ -124,6 +124,66 @@ def expm_pade(Q, t):
     return X
 
 
+# The algorithm of the device's DEFAULT expm kernel for n > 4 (round 2): scaling and
+# squaring around a Taylor polynomial evaluated by Paterson-Stockmeyer (products only,
+# no solve).  theta_m = largest 1-norm for which the backward error of the degree-m
+# Taylor polynomial stays below 2^-53 (Higham 2005 sec. 2 applied to the Taylor series;
+# the values of Al-Mohy & Higham 2011, table 3.1).  Like expm_pade this restates OUR
+# algorithm, so kernel-vs-scipy differences separate into algorithm and implementation;
+# the reference's own call is scipy.linalg.expm (custom_expm above, _mjp_dense.py:24-25).
+TAYLOR_THETA = {4: 3.3971688e-4, 8: 4.9912289e-2, 12: 2.9961589e-1, 16: 7.8028743e-1}
+
+
+def taylor_order_and_squarings(norm1):
+    """Degree m and number of squarings s of the Taylor kernel for 1-norm ``norm1``."""
+    for m in (4, 8, 12):
+        if norm1 <= TAYLOR_THETA[m]:
+            return m, 0
+    s = 0
+    if norm1 > TAYLOR_THETA[16]:
+        s = max(0, int(np.ceil(np.log2(norm1 / TAYLOR_THETA[16]))))
+    return 16, s
+
+
+def expm_taylor(Q, t):
+    """exp(Q t) by the algorithm of csrc/expm.hip expm_taylor_kernel: powers A^2..A^k
+    with A as the left factor, then Horner in A^k over the blocks
+    B_j = sum_{i<k} A^i / (k j + i)!, k = 2 (degree 4) or 4 (degrees 8, 12, 16)."""
+    import math
+    A = np.asarray(Q, dtype=float) * float(t)
+    n = A.shape[0]
+    I = np.eye(n)
+    norm1 = np.abs(A).sum(axis=0).max() if n else 0.0
+    m, s = taylor_order_and_squarings(norm1)
+    if s:
+        A = A * (2.0 ** -s)
+    c = [1.0 / math.factorial(i) for i in range(m + 1)]
+    k = 2 if m == 4 else 4
+    powers = [I, A]
+    for _ in range(2, k + 1):
+        powers.append(A @ powers[-1])
+    q = m // k
+
+    def block(j):
+        return sum(c[k * j + i] * powers[i] for i in range(k))
+    X = c[m] * powers[k] + block(q - 1)
+    for j in range(q - 2, -1, -1):
+        X = powers[k] @ X + block(j)
+    for _ in range(s):
+        X = X @ X
+    return X
+
+
+def device_expm_restated(Q, t):
+    """What the device computes for this size: Pade below 5 states (lane kernel),
+    Taylor above."""
+    return expm_pade(Q, t) if np.asarray(Q).shape[0] <= 4 else expm_taylor(Q, t)
+
+
+def device_expm_order_and_squarings(n, norm1):
+    return pade_order_and_squarings(norm1) if n <= 4 else taylor_order_and_squarings(norm1)
+
+
 # ---------------------------------------------------------------------------
 # tree marshalling (reference: _mcy_dense.py:246-255, _density.py:104-180)
 # ---------------------------------------------------------------------------

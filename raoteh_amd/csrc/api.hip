@@ -800,8 +800,38 @@ static int sites_alloc(rt_sites *s, bool generic)
 
 // Tree-specialised kernel for this batch (lane family): source from the
 // schedule, compiled once per distinct (tree, observed nodes) and device.
-static int sites_jit(rt_sites *s, bool generic, int kind)
+// How rt_sites_create picks the pruning kernel of a batch: the automatic policy, the
+// interpreter kernels only, or exactly the tree-specialised kernel of another batch
+// (the probe batches of verify_jit_kernel).
+struct jit_override {
+    int mode = 0;             // 0 automatic, 1 interpreter only, 2 exactly these parameters
+    int T = 1, S = 64, WG = 1, D = 1, LA = 1, compact = 0;
+};
+
+static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov)
 {
+    if (ov && ov->mode == 1) return RT_OK;
+    if (ov && ov->mode == 2) {
+        const int n = (int)s->model->n, K = (int)s->nobs;
+        const bool mfma = s->layout == RT_LAYOUT_MFMA;
+        const bool split = mfma && (n > 32 || !s->mfma_solo);
+        const std::string src =
+            !mfma ? rt_jit_lane_source(s->ops, n, K, ov->D, ov->LA, ov->S, ov->WG, ov->compact)
+            : split ? rt_jit_mfma_split_source(s->ops, n, K, ov->T, ov->D, ov->LA)
+                    : rt_jit_mfma_source(s->ops, n, K, ov->T, ov->D, ov->LA);
+        RT_TRY(rt_jit_get(s->model->ctx, src, &s->jit_fn, mfma));
+        s->jit_prefetch = ov->D;
+        s->jit_lookahead = ov->LA;
+        s->jit_tiles = ov->T;
+        if (!mfma) {
+            s->block_sites = ov->S;
+            s->jit_waves = ov->WG;
+            s->compact_states = ov->compact;
+        } else if (split) {
+            s->jit_waves = (n + 15) / 16;
+        }
+        return RT_OK;
+    }
     int want = opt_jit(s->model->ctx);
     if (const char *v = getenv("RAOTEH_JIT")) want = atoi(v);
     const bool forced = want > 0;
@@ -828,6 +858,7 @@ static int sites_jit(rt_sites *s, bool generic, int kind)
             if (const char *v = getenv("RAOTEH_JIT_PREFETCH")) D = std::max(1, atoi(v));
             if (const char *v = getenv("RAOTEH_JIT_LOOKAHEAD")) LA = std::max(1, atoi(v));
             s->jit_prefetch = D;
+            s->jit_lookahead = LA;
             int rc = RT_ERR_UNSUPPORTED;
             for (; T >= 1 && rc == RT_ERR_UNSUPPORTED; --T) {     // fewer tiles if it spills
                 const std::string src =
@@ -861,6 +892,7 @@ static int sites_jit(rt_sites *s, bool generic, int kind)
         if (const char *v = getenv("RAOTEH_JIT_PREFETCH")) D = std::max(1, atoi(v));
         if (const char *v = getenv("RAOTEH_JIT_LOOKAHEAD")) LA = std::max(1, atoi(v));
         s->jit_prefetch = D;
+        s->jit_lookahead = LA;
         int rc = RT_ERR_UNSUPPORTED;
         for (; T >= 1 && rc == RT_ERR_UNSUPPORTED; --T) {         // fewer tiles if it spills
             const std::string src =
@@ -925,6 +957,7 @@ static int sites_jit(rt_sites *s, bool generic, int kind)
     const std::string src =
         rt_jit_lane_source(s->ops, (int)s->model->n, (int)s->nobs, D, LA, S, WG, states);
     s->jit_prefetch = D;
+    s->jit_lookahead = LA;
     const int rc = rt_jit_get(s->model->ctx, src, &s->jit_fn, false, &s->jit_compile_s);
     if (rc != RT_OK && (!forced || rc == RT_ERR_UNSUPPORTED)) {
         // the interpreter kernel (prune.hip) computes the same numbers;
@@ -974,9 +1007,11 @@ extern "C" int rt_jit_source(int64_t nnodes, const int64_t *idx, const int64_t *
     return RT_OK;
 }
 
-extern "C" int rt_sites_create(rt_model *m, int64_t nsites, int kind, int64_t nobs,
-                               const int64_t *obs_nodes, const void *data,
-                               rt_sites **out)
+static int verify_jit_kernel(rt_sites *s, int kind);
+
+static int sites_create_impl(rt_model *m, int64_t nsites, int kind, int64_t nobs,
+                             const int64_t *obs_nodes, const void *data,
+                             const jit_override *ov, rt_sites **out)
 {
     RT_REQUIRE(m && out, "null pointer");
     *out = nullptr;
@@ -1029,7 +1064,23 @@ extern "C" int rt_sites_create(rt_model *m, int64_t nsites, int kind, int64_t no
     if (const char *v = getenv("RAOTEH_LANE_VARIANT")) s->lane_dma = strcmp(v, "dma") == 0;
     if (const char *r = getenv("RAOTEH_LANE_RING")) s->lane_ring = atoi(r);
     else s->lane_ring = s->lane_dma ? 0 : 8;      // 0: rt_launch_prune picks what fits
-    int rc = sites_jit(s, generic, kind);    // before the layout is fixed: block_sites
+    int rc = sites_jit(s, generic, kind, ov);    // before the layout is fixed: block_sites
+    // a freshly compiled kernel is checked against the interpreter kernel on a probe batch
+    // before any user batch may launch it; if it fails this batch runs the interpreter
+    // (RAOTEH_JIT_NO_VERIFY: diagnostics only, tests/soak/spill_probe.py)
+    if (rc == RT_OK && s->jit_fn && !ov && !rt_jit_verified(m->ctx, s->jit_fn) &&
+        !getenv("RAOTEH_JIT_NO_VERIFY")) {
+        const int vrc = verify_jit_kernel(s, kind);
+        rt_jit_set_verified(m->ctx, s->jit_fn, vrc == RT_OK);
+        if (vrc != RT_OK) {
+            rt_jit_ref(m->ctx, s->jit_fn, -1);
+            s->jit_fn = nullptr;
+            s->block_sites = 64;
+            s->jit_waves = 1;
+            s->jit_tiles = 1;
+            s->compact_states = 0;
+        }
+    }
     if (rc == RT_OK) rc = sites_alloc(s, generic);
     if (rc == RT_OK) rc = rt_sites_pack(s, kind, src_of_k.data(), data);
     if (rc != RT_OK) {
@@ -1038,6 +1089,123 @@ extern "C" int rt_sites_create(rt_model *m, int64_t nsites, int kind, int64_t no
     }
     *out = s;
     return RT_OK;
+}
+
+extern "C" int rt_sites_create(rt_model *m, int64_t nsites, int kind, int64_t nobs,
+                               const int64_t *obs_nodes, const void *data,
+                               rt_sites **out)
+{
+    return sites_create_impl(m, nsites, kind, nobs, obs_nodes, data, nullptr, out);
+}
+
+// A tree-specialised kernel is compiled at run time by a compiler this library does not
+// control, with the whole register file in use.  Round 1's randomised soak found one that
+// returned wrong log-likelihoods (31 / 32 states, 4 site tiles per wave); the cause, found
+// in round 2 from the ISA of that kernel (tools/jit_offline.py, tests/soak/spill_probe.py),
+// is a register-allocation defect of ROCm 7.2's AMDGPU backend: a 64-bit value living in an
+// AGPR pair (a root weight, live through the whole walk) is split when the file is full --
+// low half to a scratch slot, high half copied to a VGPR that is then treated as dead -- and
+// the reload restores the low half only.  Nothing in the source is wrong and a kernel that
+// spills far more (256 registers) is right, so "it has scratch" is a proxy, not the defect.
+// Hence this check: every freshly compiled kernel runs once on a probe batch (random
+// transition matrices, root weights and observations on the batch's own tree) next to the
+// interpreter kernel, and is used only if all log-likelihoods and statuses agree bit for
+// bit -- which is what correct code guarantees (same arithmetic order).  ~1 ms per compile.
+static int verify_jit_kernel(rt_sites *s, int kind)
+{
+    rt_model *m = s->model;
+    const int64_t n = m->n, N = m->nnodes, K = s->nobs;
+    const bool mfma = s->layout == RT_LAYOUT_MFMA;
+    // three full blocks / tile groups of the kernel and a ragged tail
+    const int64_t per = mfma ? 16 * s->jit_tiles : s->block_sites * s->jit_waves;
+    const int64_t np = 3 * per + 5;
+    uint64_t state = 0x9E3779B97F4A7C15ull ^ (uint64_t)(N * 1315423911u + n);
+    auto next = [&]() {            // splitmix64 -> (0, 1)
+        uint64_t z = (state += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        return ((double)(z >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+    };
+    std::vector<double> esd((size_t)N * n * n), root((size_t)n);
+    for (double &v : esd) v = 0.02 + next();
+    for (double &v : root) v = 0.1 + next();
+    std::vector<int64_t> obs_nodes((size_t)K);
+    for (int64_t v = 0; v < N; ++v)
+        if (s->node_obs[(size_t)v] >= 0) obs_nodes[(size_t)s->node_obs[(size_t)v]] = v;
+    // observations of the kind the kernel was specialised for (compact kernels read bytes)
+    const int pkind = s->compact_states == 1 ? RT_OBS_STATE
+                    : s->compact_states == 2 ? RT_OBS_MASK : RT_OBS_DENSE;
+    (void)kind;
+    std::vector<double> dense;
+    std::vector<unsigned char> states;
+    std::vector<uint64_t> masks;
+    const void *data = nullptr;
+    if (pkind == RT_OBS_DENSE) {
+        dense.resize((size_t)np * K * n);
+        for (double &v : dense) {
+            const double u = next();
+            v = u < 0.15 ? 0.0 : u;
+        }
+        data = dense.data();
+    } else if (pkind == RT_OBS_STATE) {
+        states.resize((size_t)np * K);
+        for (unsigned char &v : states) {
+            const double u = next();
+            v = u < 0.15 ? 255 : (unsigned char)((int)(next() * n) % (int)n);
+        }
+        data = states.data();
+    } else {
+        masks.resize((size_t)np * K);
+        for (uint64_t &v : masks) v = 1 + (uint64_t)(next() * ((1ull << n) - 1));
+        data = masks.data();
+    }
+    rt_model *tm = nullptr;
+    rt_sites *si = nullptr, *sj = nullptr;
+    int rc = rt_model_create(m->ctx, N, n, m->indices.data(), m->indptr.data(), &tm);
+    if (rc == RT_OK) rc = rt_model_set_transitions(tm, esd.data());
+    if (rc == RT_OK) rc = rt_model_set_root_distn(tm, root.data());
+    jit_override interp, same;
+    interp.mode = 1;
+    same.mode = 2;
+    same.T = s->jit_tiles;
+    same.S = s->block_sites;
+    same.WG = s->jit_waves;
+    same.D = s->jit_prefetch;
+    same.LA = s->jit_lookahead;
+    same.compact = s->compact_states;
+    if (rc == RT_OK)
+        rc = sites_create_impl(tm, np, pkind, K, obs_nodes.data(), data, &interp, &si);
+    if (rc == RT_OK)
+        rc = sites_create_impl(tm, np, pkind, K, obs_nodes.data(), data, &same, &sj);
+    if (rc == RT_OK && sj->jit_fn != s->jit_fn) {
+        rt_set_error("probe batch did not get the kernel under test");
+        rc = RT_ERR_UNSUPPORTED;
+    }
+    std::vector<double> li((size_t)np), lj((size_t)np);
+    std::vector<int32_t> sti((size_t)np), stj((size_t)np);
+    // no event timing for the probe launches (they are not the caller's)
+    const bool timing = m->ctx->timing;
+    m->ctx->timing = false;
+    if (rc == RT_OK) rc = rt_prune(tm, si);
+    if (rc == RT_OK) rc = rt_prune(tm, sj);
+    m->ctx->timing = timing;
+    if (rc == RT_OK) rc = rt_sites_get_logliks(si, li.data(), sti.data());
+    if (rc == RT_OK) rc = rt_sites_get_logliks(sj, lj.data(), stj.data());
+    if (rc == RT_OK) {
+        int64_t bad = 0;
+        for (int64_t i = 0; i < np; ++i)
+            bad += memcmp(&li[(size_t)i], &lj[(size_t)i], 8) != 0 || sti[(size_t)i] != stj[(size_t)i];
+        if (bad) {
+            rt_set_error("tree-specialised kernel rejected: %lld of %lld probe sites differ from "
+                         "the interpreter kernel (miscompiled)", (long long)bad, (long long)np);
+            rc = RT_ERR_UNSUPPORTED;
+        }
+    }
+    rt_sites_destroy(si);
+    rt_sites_destroy(sj);
+    rt_model_destroy(tm);
+    return rc;
 }
 
 extern "C" int rt_sites_clone(rt_sites *src, rt_sites **out)
@@ -1057,6 +1225,7 @@ extern "C" int rt_sites_clone(rt_sites *src, rt_sites **out)
     s->jit_fn = src->jit_fn;
     rt_jit_ref(src->model->ctx, s->jit_fn, +1);
     s->jit_prefetch = src->jit_prefetch;
+    s->jit_lookahead = src->jit_lookahead;
     s->block_sites = src->block_sites;
     s->jit_waves = src->jit_waves;
     s->jit_tiles = src->jit_tiles;

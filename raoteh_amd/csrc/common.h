@@ -159,6 +159,7 @@ struct rt_sites {
     bool comm_pending = false;
     void *jit_fn = nullptr;         // hipFunction_t of the tree-specialised kernel (jit.hip)
     int jit_prefetch = 0;           // its prefetch distance (stream positions)
+    int jit_lookahead = 1;          // ... and P records requested ahead
     int block_sites = 64;           // lane family: sites per block (< 64 only with jit_fn)
     int jit_waves = 1;              // waves per workgroup of the tree-specialised kernel
     int jit_tiles = 1;              // MFMA family: site tiles per wave of that kernel
@@ -201,6 +202,11 @@ std::string rt_jit_mfma_split_source(const std::vector<rt_op> &ops, int n, int K
 int rt_jit_get(rt_ctx *ctx, const std::string &src, void **fn, bool mfma = false,
                double *compile_s = nullptr);
 void rt_jit_ref(const rt_ctx *ctx, void *fn, int delta);
+// every freshly compiled kernel is run once against the interpreter kernel on a probe
+// batch before a user batch may launch it (api.hip verify_jit_kernel): 0 = not yet,
+// 1 = verified; rt_jit_set_verified(false) rejects the kernel for good
+int rt_jit_verified(const rt_ctx *ctx, void *fn);
+void rt_jit_set_verified(const rt_ctx *ctx, void *fn, bool ok);
 void rt_jit_release(const rt_ctx *ctx);
 int rt_launch_prune_jit(rt_model *m, rt_sites *s);
 int rt_sites_pack(rt_sites *s, int kind, const int64_t *obs_order,

@@ -445,6 +445,270 @@ expm_kernel(int n, const double *__restrict__ Q, const int *__restrict__ qidx,
 }
 
 // ---------------------------------------------------------------------------
+// 4 < n <= 62, default: scaling and squaring around a TAYLOR polynomial evaluated
+// by Paterson-Stockmeyer -- matrix products only, no linear solve.
+//
+// The [m/m] Pade kernel above spends half of its time in the n pivot steps of the
+// solve (two workgroup barriers each, a chain of n dependent rank-1 updates that the
+// matrix pipe cannot help with: 50 of 103 us at n = 61).  A Taylor polynomial of
+// degree m = k q costs (k - 1) + (q - 1) products and nothing else:
+//     powers   A^2 = A A, ..., A^k = A A^(k-1)                      (k - 1 products)
+//     Horner   T = c_m A^k + B_(q-1);  T = A^k T + B_j, j = q-2..0  (q - 1 products)
+//     with B_j = sum_{i<k} c_(kj+i) A^i  (elementwise),  c_i = 1 / i!
+// Degree from ||A||_1 against theta_m, the largest norm for which the backward error
+// of T_m stays below 2^-53 (computed as in Higham 2005 sec. 2 for the Taylor series of
+// log(e^-x T_m(x)); the same numbers as Al-Mohy & Higham 2011, table 3.1):
+//     m = 4 (k = 2: 2 products), 8, 12, 16 (k = 4: 4, 5, 6 products);
+// beyond theta_16 = 0.78 one squaring per doubling of the norm (a squaring doubles the
+// range for one product, a higher degree does not).  Entrywise accuracy against
+// 60-digit arithmetic on the codon matrix: 6e-15 relative at t = 0.1 (scipy's Pade
+// approximant: 5e-14).
+//
+// Products run on the f64 matrix pipe as in lds_matmul, but with the operands of
+// k-step kk + 1 requested before the MFMAs of k-step kk are issued and the up to four
+// output tiles of a wave advanced together (four independent accumulation chains), and
+// the "+ B_j" of a Horner step is applied when the product is stored.
+// ---------------------------------------------------------------------------
+
+__constant__ double c_theta_taylor[4] = {3.3971688e-4, 4.9912289e-2, 2.9961589e-1,
+                                         7.8028743e-1};
+// 1 / i!, i = 0..16
+__constant__ double c_inv_fact[17] = {
+    1.0, 1.0, 0.5, 1.0 / 6.0, 1.0 / 24.0, 1.0 / 120.0, 1.0 / 720.0, 1.0 / 5040.0,
+    1.0 / 40320.0, 1.0 / 362880.0, 1.0 / 3628800.0, 1.0 / 39916800.0, 1.0 / 479001600.0,
+    1.0 / 6227020800.0, 1.0 / 87178291200.0, 1.0 / 1307674368000.0,
+    1.0 / 20922789888000.0};
+
+// C = X * Y (+ B) on the matrix pipe; n x n matrices in LDS, leading dimension ld.
+// B = cf[0] I + cf[1] P1 + cf[2] P2 + cf[3] P3 when cf != nullptr (P2 / P3 may be null).
+// C may alias X and / or Y (results are held in registers across a barrier).
+__device__ __forceinline__ void lds_matmul_pipelined(const double *X, const double *Y, double *C,
+                                                     int n, int ld, int NT, int KS,
+                                                     const double *cf, const double *P1,
+                                                     const double *P2, const double *P3)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int nitems = NT * NT;
+    double4_t acc[4];
+    const double *ap[4];
+    const double *bp[4];
+    bool aok[4], bok[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        acc[it] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        const int item = wave + 4 * it;
+        const bool valid = item < nitems;
+        const int m = valid ? item / NT : 0, j = valid ? item - m * NT : 0;
+        const int arow = 16 * m + lr, bcol = 16 * j + lr;
+        aok[it] = valid && arow < n;
+        bok[it] = valid && bcol < n;
+        ap[it] = X + (aok[it] ? arow : 0) * ld;
+        bp[it] = Y + (bok[it] ? bcol : 0);
+    }
+    const int myitems = nitems > wave ? (nitems - wave + 3) / 4 : 0;     // wave-uniform
+    double a0[4], b0[4];
+    {
+        const bool kok = lq < n;
+        const int k = kok ? lq : 0;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            a0[it] = (aok[it] && kok) ? ap[it][k] : 0.0;
+            b0[it] = (bok[it] && kok) ? bp[it][k * ld] : 0.0;
+        }
+    }
+    for (int kk = 0; kk < KS; ++kk) {
+        double a1[4], b1[4];
+        {
+            // operands of the next k-step (the last iteration re-reads its own)
+            const int kn = 4 * (kk + 1 < KS ? kk + 1 : kk) + lq;
+            const bool kok = kn < n;
+            const int k = kok ? kn : 0;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                a1[it] = (aok[it] && kok) ? ap[it][k] : 0.0;
+                b1[it] = (bok[it] && kok) ? bp[it][k * ld] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            if (it < myitems)
+                acc[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[it], b0[it], acc[it], 0, 0, 0);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) { a0[it] = a1[it]; b0[it] = b1[it]; }
+    }
+    // the addend of a Horner step, read before the barrier (C may alias P1..P3 never,
+    // but X / Y are still being read by slower waves)
+    double4_t add[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        add[it] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        const int item = wave + 4 * it;
+        if (cf && item < nitems) {
+            const int m = item / NT, j = item - m * NT;
+            const int col = 16 * j + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * m + 4 * r + lq;
+                if (row < n && col < n) {
+                    const int o = row * ld + col;
+                    double v = cf[1] * P1[o] + (row == col ? cf[0] : 0.0);
+                    if (P2) v += cf[2] * P2[o];
+                    if (P3) v += cf[3] * P3[o];
+                    add[it][r] = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int item = wave + 4 * it;
+        if (item < nitems) {
+            const int m = item / NT, j = item - m * NT;
+            const int col = 16 * j + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * m + 4 * r + lq;
+                if (row < n && col < n) C[row * ld + col] = acc[it][r] + add[it][r];
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(TPB)
+expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ qidx,
+                   const double *__restrict__ tt, double *__restrict__ P,
+                   int *__restrict__ info, const int *__restrict__ step_of_node,
+                   int frag_kind, double *__restrict__ Pfrag)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int ld = n | 1;
+    const int msz = n * ld;
+    const int NT = (n + 15) / 16;
+    const int KS = (n + 3) / 4;
+    double *B0 = (double *)smem;               // A
+    double *B1 = B0 + msz;                     // A^2
+    double *B2 = B1 + msz;                     // A^3
+    double *B3 = B2 + msz;                     // A^4
+    double *B4 = B3 + msz;                     // T
+    double *cfs = B4 + msz;                    // [4] coefficients of the current B_j
+
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int nn = n * n;
+    double *Pb = P + (long)b * nn;
+    const int qi = qidx[b];
+    const int step = step_of_node ? step_of_node[b] : -1;
+    if (qi < 0) {                              // root slot: zeros (_density.py:171)
+        for (int e = tid; e < nn; e += TPB) Pb[e] = 0.0;
+        if (info && tid == 0) { info[2 * b] = 0; info[2 * b + 1] = 0; }
+        if (step >= 0 && frag_kind == 0)
+            for (int e = tid; e < nn; e += TPB) Pfrag[(long)step * nn + e] = 0.0;
+        if (step >= 0 && frag_kind == 1) {
+            const int total = NT * ((KS + 1) / 2) * 128;
+            for (int e = tid; e < total; e += TPB) Pfrag[(long)step * total + e] = 0.0;
+        }
+        return;
+    }
+    const double *Qb = Q + (long)qi * nn;
+    const double t = tt[b];
+    RT_FOR_EACH_ELEMENT(i, j, o_unused_) {
+        B0[i * ld + j] = Qb[i * n + j] * t;
+    }
+    __syncthreads();
+    double nrm;
+    {
+        double s = 0.0;
+        if (lane < n)
+            for (int i = 0; i < n; ++i) s += fabs(B0[i * ld + lane]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s = fmax(s, __shfl_xor(s, o, 64));
+        nrm = s;
+    }
+    if (!(nrm < 1e300)) {                      // inf / NaN in Q * t (wave- and block-uniform)
+        for (int e = tid; e < nn; e += TPB) Pb[e] = __builtin_nan("");
+        if (info && tid == 0) { info[2 * b] = -1; info[2 * b + 1] = 0; }
+        return;
+    }
+    int m = 16, s = 0;
+    if (nrm <= c_theta_taylor[0]) m = 4;
+    else if (nrm <= c_theta_taylor[1]) m = 8;
+    else if (nrm <= c_theta_taylor[2]) m = 12;
+    else if (nrm > c_theta_taylor[3]) {
+        int e;
+        const double f = frexp(nrm / c_theta_taylor[3], &e);    // ratio = f * 2^e
+        s = (f == 0.5) ? e - 1 : e;
+        if (s < 0) s = 0;
+    }
+    m = __builtin_amdgcn_readfirstlane(m);
+    s = __builtin_amdgcn_readfirstlane(s);
+    if (info && tid == 0) { info[2 * b] = m; info[2 * b + 1] = s; }
+    if (s > 0) {
+        __syncthreads();
+        const double sc = ldexp(1.0, -s);
+        RT_FOR_EACH_ELEMENT(i, j, o) {
+            B0[o] *= sc;
+        }
+        __syncthreads();
+    }
+    const int k = (m == 4) ? 2 : 4;
+    const int q = m / k;
+    lds_matmul_pipelined(B0, B0, B1, n, ld, NT, KS, nullptr, nullptr, nullptr, nullptr);   // A^2
+    if (k == 4) {
+        lds_matmul_pipelined(B0, B1, B2, n, ld, NT, KS, nullptr, nullptr, nullptr, nullptr);  // A^3
+        lds_matmul_pipelined(B0, B2, B3, n, ld, NT, KS, nullptr, nullptr, nullptr, nullptr);  // A^4
+    }
+    const double *Pk = (k == 4) ? B3 : B1;
+    const double *P2 = (k == 4) ? B1 : nullptr;
+    const double *P3 = (k == 4) ? B2 : nullptr;
+    // T = c_m A^k + B_(q-1)
+    {
+        const int base = k * (q - 1);
+        RT_FOR_EACH_ELEMENT(i, j, o) {
+            double v = c_inv_fact[m] * Pk[o] + c_inv_fact[base + 1] * B0[o] +
+                       (i == j ? c_inv_fact[base] : 0.0);
+            if (k == 4) v += c_inv_fact[base + 2] * B1[o] + c_inv_fact[base + 3] * B2[o];
+            B4[o] = v;
+        }
+        __syncthreads();
+    }
+    for (int jj = q - 2; jj >= 0; --jj) {
+        if (tid < 4) cfs[tid] = (tid < k) ? c_inv_fact[k * jj + tid] : 0.0;
+        __syncthreads();
+        lds_matmul_pipelined(Pk, B4, B4, n, ld, NT, KS, cfs, B0, P2, P3);   // T = A^k T + B_j
+    }
+    for (int r = 0; r < s; ++r)
+        lds_matmul_pipelined(B4, B4, B4, n, ld, NT, KS, nullptr, nullptr, nullptr, nullptr);
+
+    const double *Xb = B4;
+    RT_FOR_EACH_ELEMENT(i, j, o_unused_) {
+        Pb[i * n + j] = Xb[i * ld + j];
+    }
+    if (step >= 0 && frag_kind == 0) {
+        RT_FOR_EACH_ELEMENT(i, j, o_unused_) {
+            Pfrag[(long)step * nn + i * n + j] = Xb[i * ld + j];
+        }
+    } else if (step >= 0 && frag_kind == 1) {
+        // Pfrag[step][m][q][lane][e2] = P[16m + (lane&15)][4(2q+e2) + (lane>>4)]
+        const int KP = (KS + 1) / 2;
+        const int total = NT * KP * 128;
+        for (int e = tid; e < total; e += TPB) {
+            const int e2 = e & 1;
+            const int ln = (e >> 1) & 63;
+            const int qq = (e >> 7) % KP;
+            const int mm = (e >> 7) / KP;
+            const int row = 16 * mm + (ln & 15);
+            const int col = 4 * (2 * qq + e2) + (ln >> 4);
+            Pfrag[(long)step * total + e] = (row < n && col < n) ? Xb[row * ld + col] : 0.0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // n <= 4: one LANE per matrix, everything in registers (compile-time N, fully
 // unrolled, statically indexed).  A 64-leaf 4-state tree has 126 matrices: the
 // workgroup-per-matrix kernel above spends its time in barriers there, and the
@@ -671,6 +935,25 @@ int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
         default: RT_SMALL(4); break;
         }
 #undef RT_SMALL
+        RT_HIP(hipGetLastError());
+        rt_time_end(ctx, RT_K_EXPM, ev);
+        return RT_OK;
+    }
+    // default: the Taylor / Paterson-Stockmeyer kernel (products only);
+    // RAOTEH_EXPM=pade keeps the Pade + register Gauss-Jordan kernel (A/B runs, soak)
+    const char *which = getenv("RAOTEH_EXPM");
+    if (!(which && strcmp(which, "pade") == 0)) {
+        const size_t lds_t = (size_t)5 * n * ld * 8 + 4 * 8;
+        if (lds_t > ctx->expm_ts_attr_lds) {
+            RT_HIP(hipFuncSetAttribute((const void *)expm_taylor_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
+            ctx->expm_ts_attr_lds = lds_t;
+        }
+        hipEvent_t ev = nullptr;
+        rt_time_begin(ctx, RT_K_EXPM, "expm_taylor_ps_mfma", &ev);
+        RT_LAUNCH_TIMED(ctx, expm_taylor_kernel, dim3((unsigned)count), dim3(TPB), lds_t,
+                        (int)n, d_Q, d_qidx, d_t, d_P, d_info, d_step_of_node, frag_kind,
+                        d_Pfrag);
         RT_HIP(hipGetLastError());
         rt_time_end(ctx, RT_K_EXPM, ev);
         return RT_OK;

@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 RAOTEH_JIT=1 timeout -k 10 600 python -m pytest tests -m gpu -x -q --timeout=300 > gpurun_out/ab_tests_jit.log 2>&1 || { tail -30 gpurun_out/ab_tests_jit.log; exit 1; }
 tail -2 gpurun_out/ab_tests_jit.log
 run() {
-  python bench.py --workload ${W:-c2} --steps 400 --warmup 40 --no-cpu-baseline 2>gpurun_out/ab_err.log | python -c "
+  python bench.py --workload ${W:-c2} --steps 400 --warmup 40 --no-cpu-baseline --also '' 2>gpurun_out/ab_err.log | python -c "
 import sys, json
 d = json.loads(sys.stdin.readlines()[-1])
 print('$1', '%.4g' % d['value'], '%.2f us/step' % (d['ms_per_step']*1e3), d['roofline']['kernel'], 'prune %.1f us' % d['kernels_us']['prune'], 'frac %.3f' % d['roofline']['frac'])" || tail -5 gpurun_out/ab_err.log

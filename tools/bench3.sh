@@ -5,7 +5,7 @@ timeout -k 10 400 python -m pytest tests -m gpu -q --timeout=300 -x > gpurun_out
 echo pytest_rc=$rc; tail -${TAILN:-5} gpurun_out/pytest.log
 [ $rc -eq 0 ] || exit $rc
 for w in ${WORKLOADS:-c2 c3 c5}; do
-  python bench.py --workload $w --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/b_$w.json 2>gpurun_out/b_$w.err || { tail -3 gpurun_out/b_$w.err; continue; }
+  python bench.py --workload $w --steps 100 --warmup 10 --no-cpu-baseline --also '' > gpurun_out/b_$w.json 2>gpurun_out/b_$w.err || { tail -3 gpurun_out/b_$w.err; continue; }
   python - <<PY
 import json
 d=json.load(open("gpurun_out/b_$w.json"))

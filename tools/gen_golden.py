@@ -21,6 +21,7 @@ Reference functions exercised:
   _mcz.get_node_to_pmap                        raoteh/sampler/_mcz.py:94-166
   _linalg.sparse_expm_naive                    raoteh/sampler/_linalg.py:72-90
   _conditional_expectation.get_jukes_cantor_*  raoteh/sampler/_conditional_expectation.py:15-33
+  examples/code2x3/run.py do_blinking_process  :329-475 (builder of the config-5 model)
 expm per edge is ``scipy.linalg.expm(Q*t)`` exactly as ``_mjp_dense.py:24-25``.
 
 usage: python tools/gen_golden.py [--out tests/golden]
@@ -704,10 +705,97 @@ def fixture_expm(mods):
     return dict(rows=rows)
 
 
+def fixture_blinking(mods):
+    """The reference's own builder of the blinking compound process
+    (examples/code2x3/run.py:329-461, ``do_blinking_process``) run on the
+    (nprimary = 5, nparts = 2) model of config 5: its rate matrix, its root
+    distribution and its per-node allowed compound-state sets, captured where
+    the reference hands them to ``_mjp_dense.get_likelihood`` (run.py:473-475).
+    run.py imports ``raoteh.sampler._mjp_dense`` (pyfelscore) and ``extras``:
+    both are replaced by recording stand-ins for the import; nothing after the
+    captured call is used."""
+    import importlib.util
+    import io
+    import contextlib
+    captured = []
+    fake_mjp = types.ModuleType('raoteh.sampler._mjp_dense')
+
+    def get_likelihood(T, node_to_allowed_states, root, nstates,
+                       root_distn=None, Q_default=None):
+        captured.append(dict(T=T, allowed=node_to_allowed_states, root=root,
+                             nstates=nstates, root_distn=root_distn,
+                             Q=Q_default))
+        return 1.0
+    fake_mjp.get_likelihood = get_likelihood
+    fake_extras = types.ModuleType('extras')
+    fake_extras.get_expected_ntransitions = lambda *a, **k: {}
+    saved = dict((k, sys.modules.get(k)) for k in
+                 ('raoteh.sampler._mjp_dense', 'extras'))
+    sys.modules['raoteh.sampler._mjp_dense'] = fake_mjp
+    sys.modules['raoteh.sampler']._mjp_dense = fake_mjp
+    sys.modules['extras'] = fake_extras
+    try:
+        spec = importlib.util.spec_from_file_location(
+            'code2x3_run', REF + '/examples/code2x3/run.py')
+        run = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(run)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+        if hasattr(sys.modules['raoteh.sampler'], '_mjp_dense'):
+            del sys.modules['raoteh.sampler']._mjp_dense
+    from raoteh_amd import synth
+    nprimary, nparts = 5, 2
+    primary_to_part = {0: 0, 1: 0, 2: 0, 3: 1, 4: 1}
+    rng = np.random.RandomState(4)
+    w = 0.5 + rng.exponential(size=nprimary)
+    primary_distn = w / w.sum()
+    S = 0.5 + rng.exponential(size=(nprimary, nprimary))
+    S = (S + S.T) / 2
+    Q_primary = synth._finish_rate_matrix(S * primary_distn[None, :], primary_distn)
+    rows = []
+    # a 7-node tree: leaves 3..6 observe primary states, the others nothing;
+    # no tolerance ("disease") data anywhere, as in config 5
+    preorder_nodes = [0, 1, 3, 4, 2, 5, 6]
+    preorder_edges = [(0, 1), (1, 3), (1, 4), (0, 2), (2, 5), (2, 6)]
+    for rate_on, rate_off, leaf_primary in ((1.3, 0.7, (0, 3, 4, 2)),
+                                            (0.55, 2.4, (1, 1, 3, 0)),
+                                            (0.5 + rng.exponential(),
+                                             0.5 + rng.exponential(), (4, 2, 0, 3))):
+        allowed_primary = dict((v, set(range(nprimary))) for v in preorder_nodes)
+        for leaf, c in zip((3, 4, 5, 6), leaf_primary):
+            allowed_primary[leaf] = {c}
+        part_allowed = dict(((v, p), {0, 1}) for v in preorder_nodes
+                            for p in range(nparts))
+        del captured[:]
+        with contextlib.redirect_stdout(io.StringIO()):
+            run.do_blinking_process(
+                Q_primary, primary_distn, preorder_nodes, preorder_edges, 0.1,
+                primary_to_part, rate_on, rate_off, allowed_primary, part_allowed)
+        cap = captured[0]
+        rows.append(dict(
+            rate_on=float(rate_on), rate_off=float(rate_off),
+            leaf_primary=list(leaf_primary), leaves=[3, 4, 5, 6],
+            Q=np.asarray(cap['Q']).tolist(),
+            root_distn=np.asarray(cap['root_distn']).tolist(),
+            nstates=int(cap['nstates']),
+            allowed=dict((str(v), sorted(int(x) for x in ss))
+                         for v, ss in cap['allowed'].items())))
+    return dict(nprimary=nprimary, nparts=nparts,
+                primary_to_part=dict((str(k), v) for k, v in primary_to_part.items()),
+                Q_primary=Q_primary.tolist(), primary_distn=primary_distn.tolist(),
+                rows=rows)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(os.path.dirname(HERE),
                                                   'tests', 'golden'))
+    ap.add_argument('--only', default=None,
+                    help='comma-separated fixture names (default: all)')
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     mods = import_reference()
@@ -715,21 +803,24 @@ def main():
                 reference='/root/reference (argriffing/raoteh)',
                 python=sys.version.split()[0], numpy=np.__version__,
                 scipy=scipy.__version__, networkx=nx.__version__)
-    fixtures = dict(
-        test_mjp_rerooting=fixture_test_mjp(mods),
-        sum_to_one=fixture_sum_to_one(mods),
-        kat_history=fixture_kat_history(mods),
-        jukes_cantor=fixture_jukes_cantor(mods),
-        random_sparse=fixture_random_sparse(mods),
-        sparse_api=fixture_sparse_api(mods),
-        p53_mg94=fixture_p53_mg94(mods),
-        expectations=fixture_expectations(mods),
-        expm=fixture_expm(mods),
-        config_c1=fixture_config(mods, 'c1', 4, with_pmap=True),
-        config_c2=fixture_config(mods, 'c2', 6),
-        config_c3=fixture_config(mods, 'c3', 2),
-        config_c5=fixture_config(mods, 'c5', 4),
+    makers = dict(
+        test_mjp_rerooting=lambda: fixture_test_mjp(mods),
+        sum_to_one=lambda: fixture_sum_to_one(mods),
+        kat_history=lambda: fixture_kat_history(mods),
+        jukes_cantor=lambda: fixture_jukes_cantor(mods),
+        random_sparse=lambda: fixture_random_sparse(mods),
+        sparse_api=lambda: fixture_sparse_api(mods),
+        p53_mg94=lambda: fixture_p53_mg94(mods),
+        expectations=lambda: fixture_expectations(mods),
+        expm=lambda: fixture_expm(mods),
+        config_c1=lambda: fixture_config(mods, 'c1', 4, with_pmap=True),
+        config_c2=lambda: fixture_config(mods, 'c2', 6),
+        config_c3=lambda: fixture_config(mods, 'c3', 2),
+        config_c5=lambda: fixture_config(mods, 'c5', 4),
+        blinking=lambda: fixture_blinking(mods),
     )
+    only = args.only.split(',') if args.only else list(makers)
+    fixtures = dict((name, makers[name]()) for name in only)
     for name, fx in fixtures.items():
         fx['_meta'] = meta
         path = os.path.join(args.out, name + '.json')

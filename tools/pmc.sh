@@ -4,7 +4,7 @@ W=$1; TAG=$2; shift 2
 REPO=$(pwd); OUT=$REPO/gpurun_out/pmc_${W}_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc "$@" --output-format csv -d $OUT -o pmc -- python3 $REPO/bench.py --workload $W --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench.json 2> $OUT/err.log || { tail -5 $OUT/err.log; exit 1; }
+rocprofv3 --pmc "$@" --output-format csv -d $OUT -o pmc -- python3 $REPO/bench.py --workload $W --steps 8 --warmup 2 --no-cpu-baseline --also '' > $OUT/bench.json 2> $OUT/err.log || { tail -5 $OUT/err.log; exit 1; }
 cd $REPO
 python3 - <<PY
 import csv, glob, collections

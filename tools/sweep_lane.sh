@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 for cfg in "reg 8" "reg 4" "dma 2" "dma 3" "dma 4" "dma 5"; do
   set -- $cfg; v=$1; r=$2
-  RAOTEH_JIT=0 RAOTEH_LANE_VARIANT=$v RAOTEH_LANE_RING=$r timeout -k 10 120 python bench.py --workload c2 --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/sweep_${v}_$r.json 2> gpurun_out/sweep_${v}_$r.err || { echo FAIL $v $r; tail -3 gpurun_out/sweep_${v}_$r.err; continue; }
+  RAOTEH_JIT=0 RAOTEH_LANE_VARIANT=$v RAOTEH_LANE_RING=$r timeout -k 10 120 python bench.py --workload c2 --steps 100 --warmup 10 --no-cpu-baseline --also '' > gpurun_out/sweep_${v}_$r.json 2> gpurun_out/sweep_${v}_$r.err || { echo FAIL $v $r; tail -3 gpurun_out/sweep_${v}_$r.err; continue; }
   python - <<PY
 import json
 d=json.load(open('gpurun_out/sweep_${v}_$r.json'))
