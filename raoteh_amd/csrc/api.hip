@@ -83,6 +83,8 @@ extern "C" int rt_ctx_create(int device, rt_ctx **out)
 extern "C" int rt_ctx_sync(rt_ctx *ctx)
 {
     RT_REQUIRE(ctx, "null context");
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_TRY(rt_flush_reduce(ctx));
     RT_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->comm_stream) RT_HIP(hipStreamSynchronize(ctx->comm_stream));
     return RT_OK;
@@ -113,6 +115,7 @@ extern "C" int rt_ctx_destroy(rt_ctx *ctx)
 {
     if (!ctx) return RT_OK;
     hipSetDevice(ctx->device);
+    ctx->pending_reduce = nullptr;       // its batch may be gone already
     hipStreamSynchronize(ctx->stream);
     rt_comm_destroy(ctx);
     rt_jit_release(ctx);
@@ -433,8 +436,12 @@ extern "C" int rt_model_create(rt_ctx *ctx, int64_t nnodes, int64_t n,
 static int model_run_expm(rt_model *m)
 {
     // the expm epilogue also writes the step-ordered layout the pruning kernel reads
+    // a reduction deferred by the previous rt_step rides on this launch
+    rt_reduce_args red;
+    const bool carry = rt_take_pending_reduce(m->ctx, &red);
     RT_TRY(rt_launch_expm(m->ctx, m->n, m->nnodes, m->d_Q, m->d_qidx, m->d_t, m->d_P,
-                          m->d_info, m->d_step_of_node, m->n <= 4 ? 0 : 1, m->d_Pfrag));
+                          m->d_info, m->d_step_of_node, m->n <= 4 ? 0 : 1, m->d_Pfrag,
+                          carry ? &red : nullptr));
     m->have_P = true;
     m->frag_dirty = false;
     return RT_OK;
@@ -614,6 +621,7 @@ extern "C" int rt_sites_destroy(rt_sites *s)
 {
     if (!s) return RT_OK;
     hipSetDevice(s->model->ctx->device);
+    if (s->model->ctx->pending_reduce == s) s->model->ctx->pending_reduce = nullptr;
     hipStreamSynchronize(s->model->ctx->stream);
     // an all-reduce of this batch's totals may still be in flight on the comm stream
     rt_jit_ref(s->model->ctx, s->jit_fn, -1);
@@ -1290,7 +1298,9 @@ extern "C" int rt_step(rt_model *m, rt_sites *s, int recompute_transitions)
                "the model has no transition matrices yet");
     RT_HIP(hipSetDevice(m->ctx->device));
     if (recompute_transitions) RT_TRY(model_run_expm(m));
-    return rt_launch_prune(m, s);
+    // the batch sum is reduced by the next step's expm launch (or by whoever reads the
+    // totals first): two launches per step instead of three
+    return rt_launch_prune(m, s, true);
 }
 
 extern "C" int rt_sites_get_logliks(rt_sites *s, double *loglik, int32_t *status)
@@ -1309,6 +1319,7 @@ extern "C" int rt_sites_get_totals(rt_sites *s, double totals[3])
 {
     RT_REQUIRE(s && totals, "null pointer");
     RT_HIP(hipSetDevice(s->model->ctx->device));
+    RT_TRY(rt_flush_reduce(s->model->ctx));
     RT_HIP(hipStreamSynchronize(s->model->ctx->stream));
     if (s->model->ctx->comm_stream)
         RT_HIP(hipStreamSynchronize(s->model->ctx->comm_stream));

@@ -135,6 +135,7 @@ extern "C" int rt_allreduce_totals_group(rt_ctx *ctx, rt_sites **sites, int64_t 
                    (long long)k);
     }
     RT_HIP(hipSetDevice(ctx->device));
+    RT_TRY(rt_flush_reduce(ctx));        // the totals of the last step may still be partial sums
     if (!ctx->ev_reduced) {
         RT_HIP(hipEventCreateWithFlags(&ctx->ev_reduced, hipEventDisableTiming));
         for (auto &e : ctx->comm_events)

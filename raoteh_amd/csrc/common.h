@@ -83,8 +83,14 @@ struct rt_ctx {
     int opt_force_generic = -2;
     int opt_jit = -2;
     int opt_jit_block_sites = -2;
+    // The batch whose per-wave partial sums still await their fixed-order reduction.
+    // rt_step defers it: the reduction of step j rides as one extra workgroup of step
+    // j + 1's expm launch (two launches per step instead of three: on config 2 the two
+    // launch-latency-sized kernels were a quarter of the step); every reader of the
+    // totals, rt_prune, rt_ctx_sync and the destructors flush it (rt_flush_reduce).
+    struct rt_sites *pending_reduce = nullptr;
     size_t expm_attr_lds = 0;      // dynamic-LDS attribute already granted to expm_kernel
-    size_t expm_ts_attr_lds = 0;   // ... to the Taylor kernels
+    size_t expm_ts_attr_lds[4] = {0, 0, 0, 0};   // ... to the Taylor kernels (per NT)
 };
 static const int RT_OPT_UNSET = -2;
 
@@ -176,10 +182,21 @@ struct rt_sites {
 void rt_time_begin(rt_ctx *ctx, int kernel, const char *name, hipEvent_t *start);
 void rt_time_end(rt_ctx *ctx, int kernel, hipEvent_t start);
 
+// the reduction a launch may carry in one extra workgroup (partial == nullptr: none)
+struct rt_reduce_args {
+    const double *partial = nullptr;   // [npartials][2]
+    long npartials = 0;
+    double *totals = nullptr;          // [3]
+    double nsites = 0.0;
+};
 int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
                    const int32_t *d_qidx, const double *d_t, double *d_P,
                    int32_t *d_info, const int32_t *d_step_of_node, int frag_kind,
-                   double *d_Pfrag);
+                   double *d_Pfrag, const rt_reduce_args *fused_reduce = nullptr);
+// the pending reduction, handed to the next expm launch (-> true) ...
+bool rt_take_pending_reduce(rt_ctx *ctx, rt_reduce_args *out);
+// ... or launched on its own now (no-op when nothing is pending)
+int rt_flush_reduce(rt_ctx *ctx);
 // A timed launch: the runtime stamps the two events with the kernel's own begin and
 // end (what rocprofv3's kernel trace reports), not with the stream position of an
 // event record, which adds 2-3 us per pair.  Null events: a plain launch.
@@ -192,7 +209,7 @@ int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
             hipLaunchKernelGGL(kern, grid, block, lds, (ctx)->stream, __VA_ARGS__);     \
     } while (0)
 int rt_launch_pfrag(rt_model *m);
-int rt_launch_prune(rt_model *m, rt_sites *s);
+int rt_launch_prune(rt_model *m, rt_sites *s, bool defer_reduce = false);
 // jit.hip
 std::string rt_jit_lane_source(const std::vector<rt_op> &ops, int n, int K, int D, int LA,
                                int S, int WG, int compact = 0);

@@ -24,6 +24,7 @@
 //   step-ordered layout the pruning kernel of this model reads (lane family:
 //   [step][n][n]; MFMA family: A-fragment order), which removes a launch.
 #include "common.h"
+#include "reduce.h"
 
 #include <cstdlib>
 
@@ -145,9 +146,13 @@ expm_kernel(int n, const double *__restrict__ Q, const int *__restrict__ qidx,
             int *__restrict__ info,
             // fused repack (all optional): step of each node, layout, output
             const int *__restrict__ step_of_node, int frag_kind,
-            double *__restrict__ Pfrag)
+            double *__restrict__ Pfrag, rt_reduce_args red)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (red.partial && blockIdx.x == gridDim.x - 1) {      // the carried reduction
+        rt_reduce_partials_body(red.partial, red.npartials, red.totals, red.nsites);
+        return;
+    }
     const int ld = n | 1;
     const int msz = n * ld;
     const int NT = (n + 15) / 16;
@@ -482,21 +487,29 @@ __constant__ double c_inv_fact[17] = {
 // C = X * Y (+ B) on the matrix pipe; n x n matrices in LDS, leading dimension ld.
 // B = cf[0] I + cf[1] P1 + cf[2] P2 + cf[3] P3 when cf != nullptr (P2 / P3 may be null).
 // C may alias X and / or Y (results are held in registers across a barrier).
+// NT (row / column tiles, n <= 16 NT) is a template parameter so that the number of
+// output tiles per wave NI is a constant and the loop body is straight-line code: every
+// LDS read is unconditional (clamped address, value selected afterwards) and every wave
+// issues NI MFMAs per k-step -- a branch per load or per MFMA makes hipcc serialise the
+// whole product (one exec-mask region per read, the accumulators copied in and out of the
+// AGPRs around every MFMA: 78 us per 61-state expm instead of 20).
+template <int NT>
 __device__ __forceinline__ void lds_matmul_pipelined(const double *X, const double *Y, double *C,
-                                                     int n, int ld, int NT, int KS,
+                                                     int n, int ld, int KS,
                                                      const double *cf, const double *P1,
                                                      const double *P2, const double *P3)
 {
+    constexpr int NI = NT == 4 ? 4 : NT == 3 ? 3 : 1;      // items (output tiles) per wave
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lq = lane >> 4;
-    const int nitems = NT * NT;
-    double4_t acc[4];
-    const double *ap[4];
-    const double *bp[4];
-    bool aok[4], bok[4];
+    constexpr int nitems = NT * NT;
+    double4_t acc[NI];
+    const double *ap[NI];
+    const double *bp[NI];
+    bool aok[NI], bok[NI];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < NI; ++it) {
         acc[it] = (double4_t){0.0, 0.0, 0.0, 0.0};
         const int item = wave + 4 * it;
         const bool valid = item < nitems;
@@ -507,42 +520,41 @@ __device__ __forceinline__ void lds_matmul_pipelined(const double *X, const doub
         ap[it] = X + (aok[it] ? arow : 0) * ld;
         bp[it] = Y + (bok[it] ? bcol : 0);
     }
-    const int myitems = nitems > wave ? (nitems - wave + 3) / 4 : 0;     // wave-uniform
-    double a0[4], b0[4];
+    double a0[NI], b0[NI];
     {
         const bool kok = lq < n;
         const int k = kok ? lq : 0;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            a0[it] = (aok[it] && kok) ? ap[it][k] : 0.0;
-            b0[it] = (bok[it] && kok) ? bp[it][k * ld] : 0.0;
+        for (int it = 0; it < NI; ++it) {
+            const double av = ap[it][k], bv = bp[it][k * ld];      // always in bounds
+            a0[it] = (aok[it] && kok) ? av : 0.0;
+            b0[it] = (bok[it] && kok) ? bv : 0.0;
         }
     }
     for (int kk = 0; kk < KS; ++kk) {
-        double a1[4], b1[4];
+        double a1[NI], b1[NI];
         {
             // operands of the next k-step (the last iteration re-reads its own)
             const int kn = 4 * (kk + 1 < KS ? kk + 1 : kk) + lq;
             const bool kok = kn < n;
             const int k = kok ? kn : 0;
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                a1[it] = (aok[it] && kok) ? ap[it][k] : 0.0;
-                b1[it] = (bok[it] && kok) ? bp[it][k * ld] : 0.0;
+            for (int it = 0; it < NI; ++it) {
+                const double av = ap[it][k], bv = bp[it][k * ld];
+                a1[it] = (aok[it] && kok) ? av : 0.0;
+                b1[it] = (bok[it] && kok) ? bv : 0.0;
             }
         }
 #pragma unroll
-        for (int it = 0; it < 4; ++it)
-            if (it < myitems)
-                acc[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[it], b0[it], acc[it], 0, 0, 0);
+        for (int it = 0; it < NI; ++it)
+            acc[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[it], b0[it], acc[it], 0, 0, 0);
 #pragma unroll
-        for (int it = 0; it < 4; ++it) { a0[it] = a1[it]; b0[it] = b1[it]; }
+        for (int it = 0; it < NI; ++it) { a0[it] = a1[it]; b0[it] = b1[it]; }
     }
-    // the addend of a Horner step, read before the barrier (C may alias P1..P3 never,
-    // but X / Y are still being read by slower waves)
-    double4_t add[4];
+    // the addend of a Horner step, read before the barrier
+    double4_t add[NI];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < NI; ++it) {
         add[it] = (double4_t){0.0, 0.0, 0.0, 0.0};
         const int item = wave + 4 * it;
         if (cf && item < nitems) {
@@ -563,7 +575,7 @@ __device__ __forceinline__ void lds_matmul_pipelined(const double *X, const doub
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < NI; ++it) {
         const int item = wave + 4 * it;
         if (item < nitems) {
             const int m = item / NT, j = item - m * NT;
@@ -578,16 +590,20 @@ __device__ __forceinline__ void lds_matmul_pipelined(const double *X, const doub
     __syncthreads();
 }
 
+template <int NT>
 __global__ void __launch_bounds__(TPB)
 expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ qidx,
                    const double *__restrict__ tt, double *__restrict__ P,
                    int *__restrict__ info, const int *__restrict__ step_of_node,
-                   int frag_kind, double *__restrict__ Pfrag)
+                   int frag_kind, double *__restrict__ Pfrag, rt_reduce_args red)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (red.partial && blockIdx.x == gridDim.x - 1) {      // the carried reduction
+        rt_reduce_partials_body(red.partial, red.npartials, red.totals, red.nsites);
+        return;
+    }
     const int ld = n | 1;
     const int msz = n * ld;
-    const int NT = (n + 15) / 16;
     const int KS = (n + 3) / 4;
     double *B0 = (double *)smem;               // A
     double *B1 = B0 + msz;                     // A^2
@@ -657,10 +673,10 @@ expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ 
     }
     const int k = (m == 4) ? 2 : 4;
     const int q = m / k;
-    lds_matmul_pipelined(B0, B0, B1, n, ld, NT, KS, nullptr, nullptr, nullptr, nullptr);   // A^2
+    lds_matmul_pipelined<NT>(B0, B0, B1, n, ld, KS, nullptr, nullptr, nullptr, nullptr);   // A^2
     if (k == 4) {
-        lds_matmul_pipelined(B0, B1, B2, n, ld, NT, KS, nullptr, nullptr, nullptr, nullptr);  // A^3
-        lds_matmul_pipelined(B0, B2, B3, n, ld, NT, KS, nullptr, nullptr, nullptr, nullptr);  // A^4
+        lds_matmul_pipelined<NT>(B0, B1, B2, n, ld, KS, nullptr, nullptr, nullptr, nullptr);  // A^3
+        lds_matmul_pipelined<NT>(B0, B2, B3, n, ld, KS, nullptr, nullptr, nullptr, nullptr);  // A^4
     }
     const double *Pk = (k == 4) ? B3 : B1;
     const double *P2 = (k == 4) ? B1 : nullptr;
@@ -679,10 +695,10 @@ expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ 
     for (int jj = q - 2; jj >= 0; --jj) {
         if (tid < 4) cfs[tid] = (tid < k) ? c_inv_fact[k * jj + tid] : 0.0;
         __syncthreads();
-        lds_matmul_pipelined(Pk, B4, B4, n, ld, NT, KS, cfs, B0, P2, P3);   // T = A^k T + B_j
+        lds_matmul_pipelined<NT>(Pk, B4, B4, n, ld, KS, cfs, B0, P2, P3);   // T = A^k T + B_j
     }
     for (int r = 0; r < s; ++r)
-        lds_matmul_pipelined(B4, B4, B4, n, ld, NT, KS, nullptr, nullptr, nullptr, nullptr);
+        lds_matmul_pipelined<NT>(B4, B4, B4, n, ld, KS, nullptr, nullptr, nullptr, nullptr);
 
     const double *Xb = B4;
     RT_FOR_EACH_ELEMENT(i, j, o_unused_) {
@@ -755,13 +771,17 @@ __device__ __forceinline__ void sm_comb(SmallMat<N> &out, double ca, const Small
 }
 
 template <int N>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 expm_small_kernel(int count, const double *__restrict__ Q, const int *__restrict__ qidx,
                   const double *__restrict__ tt, double *__restrict__ P,
                   int *__restrict__ info, const int *__restrict__ step_of_node,
-                  double *__restrict__ Pfrag)
+                  double *__restrict__ Pfrag, rt_reduce_args red)
 {
-    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (red.partial && blockIdx.x == gridDim.x - 1) {      // the carried reduction
+        rt_reduce_partials_body(red.partial, red.npartials, red.totals, red.nsites);
+        return;
+    }
+    const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= count) return;
     constexpr int NN = N * N;
     double *Pb = P + (long)b * NN;
@@ -904,13 +924,16 @@ expm_small_kernel(int count, const double *__restrict__ Q, const int *__restrict
 int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
                    const int32_t *d_qidx, const double *d_t, double *d_P,
                    int32_t *d_info, const int32_t *d_step_of_node, int frag_kind,
-                   double *d_Pfrag)
+                   double *d_Pfrag, const rt_reduce_args *fused_reduce)
 {
+    // one extra workgroup when the launch carries the pending reduction of a batch
+    const rt_reduce_args red = fused_reduce ? *fused_reduce : rt_reduce_args();
+    const unsigned extra = red.partial ? 1u : 0u;
     if (n < 1 || n > RT_MAX_EXPM_STATES) {
         rt_set_error("expm: n=%lld outside 1..%d", (long long)n, RT_MAX_EXPM_STATES);
         return RT_ERR_UNSUPPORTED;
     }
-    if (count <= 0) return RT_OK;
+    if (count <= 0 && !extra) return RT_OK;
     const int ld = (int)n | 1;
     const size_t lds = (size_t)5 * n * ld * 8 + (128 + 128 + 64) * 8 + (8 + 64) * 4;
     size_t &attr_lds = ctx->expm_attr_lds;
@@ -923,11 +946,11 @@ int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
     if (n <= 4 && !getenv("RAOTEH_EXPM_NO_SMALL")) {
         hipEvent_t ev = nullptr;
         rt_time_begin(ctx, RT_K_EXPM, "expm_small_lane_per_matrix", &ev);
-        const unsigned grid = (unsigned)((count + 63) / 64);
+        const unsigned grid = (unsigned)((count + 255) / 256) + extra;
         const int *son = frag_kind == 0 ? d_step_of_node : nullptr;
 #define RT_SMALL(NV)                                                                 \
-        RT_LAUNCH_TIMED(ctx, expm_small_kernel<NV>, dim3(grid), dim3(64), 0, \
-                           (int)count, d_Q, d_qidx, d_t, d_P, d_info, son, d_Pfrag)
+        RT_LAUNCH_TIMED(ctx, expm_small_kernel<NV>, dim3(grid), dim3(256), 0, \
+                           (int)count, d_Q, d_qidx, d_t, d_P, d_info, son, d_Pfrag, red)
         switch ((int)n) {
         case 1: RT_SMALL(1); break;
         case 2: RT_SMALL(2); break;
@@ -944,25 +967,37 @@ int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
     const char *which = getenv("RAOTEH_EXPM");
     if (!(which && strcmp(which, "pade") == 0)) {
         const size_t lds_t = (size_t)5 * n * ld * 8 + 4 * 8;
-        if (lds_t > ctx->expm_ts_attr_lds) {
-            RT_HIP(hipFuncSetAttribute((const void *)expm_taylor_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
-            ctx->expm_ts_attr_lds = lds_t;
-        }
+        const int nt = (int)((n + 15) / 16);
         hipEvent_t ev = nullptr;
         rt_time_begin(ctx, RT_K_EXPM, "expm_taylor_ps_mfma", &ev);
-        RT_LAUNCH_TIMED(ctx, expm_taylor_kernel, dim3((unsigned)count), dim3(TPB), lds_t,
-                        (int)n, d_Q, d_qidx, d_t, d_P, d_info, d_step_of_node, frag_kind,
-                        d_Pfrag);
+#define RT_TAYLOR(NTV)                                                                          \
+        do {                                                                                    \
+            if (lds_t > ctx->expm_ts_attr_lds[NTV - 1]) {                                       \
+                RT_HIP(hipFuncSetAttribute((const void *)expm_taylor_kernel<NTV>,               \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,          \
+                                           (int)lds_t));                                        \
+                ctx->expm_ts_attr_lds[NTV - 1] = lds_t;                                         \
+            }                                                                                   \
+            RT_LAUNCH_TIMED(ctx, expm_taylor_kernel<NTV>, dim3((unsigned)count + extra),        \
+                            dim3(TPB), lds_t, (int)n, d_Q, d_qidx, d_t, d_P, d_info,            \
+                            d_step_of_node, frag_kind, d_Pfrag, red);                           \
+        } while (0)
+        switch (nt) {
+        case 1: RT_TAYLOR(1); break;
+        case 2: RT_TAYLOR(2); break;
+        case 3: RT_TAYLOR(3); break;
+        default: RT_TAYLOR(4); break;
+        }
+#undef RT_TAYLOR
         RT_HIP(hipGetLastError());
         rt_time_end(ctx, RT_K_EXPM, ev);
         return RT_OK;
     }
     hipEvent_t ev = nullptr;
     rt_time_begin(ctx, RT_K_EXPM, "expm_mfma_regsolve", &ev);
-    RT_LAUNCH_TIMED(ctx, expm_kernel, dim3((unsigned)count), dim3(TPB), lds,
+    RT_LAUNCH_TIMED(ctx, expm_kernel, dim3((unsigned)count + extra), dim3(TPB), lds,
                        (int)n, d_Q, d_qidx, d_t, d_P, d_info, d_step_of_node, frag_kind,
-                       d_Pfrag);
+                       d_Pfrag, red);
     RT_HIP(hipGetLastError());
     rt_time_end(ctx, RT_K_EXPM, ev);
     return RT_OK;

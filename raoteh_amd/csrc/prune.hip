@@ -26,6 +26,7 @@
 //   prune_generic_kernel  any n <= 64, any stack depth: one lane = one site,
 //                       accumulators in a global scratch stack.  Fallback only.
 #include "common.h"
+#include "reduce.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -1027,43 +1028,7 @@ __global__ void __launch_bounds__(256)
 reduce_partials_kernel(const double *__restrict__ partial, long npartials,
                        double *__restrict__ totals, double nsites)
 {
-    __shared__ double ssum[256];
-    __shared__ double szero[256];
-    // thread t adds partials t, t + 256, ... in that order (the order fixes the
-    // rounding: totals are bitwise reproducible); the loads of eight of them are
-    // issued together so that the pass costs one L2 round trip per 2 048 partials
-    double s = 0.0, z = 0.0;
-    const double2 *p2 = (const double2 *)partial;
-    for (long base = threadIdx.x; base < npartials; base += 256 * 8) {
-        double2 v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const long i = base + 256 * j;
-            v[j] = i < npartials ? p2[i] : make_double2(0.0, 0.0);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (base + 256 * j < npartials) {
-                s += v[j].x;
-                z += v[j].y;
-            }
-        }
-    }
-    ssum[threadIdx.x] = s;
-    szero[threadIdx.x] = z;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) {
-            ssum[threadIdx.x] += ssum[threadIdx.x + w];
-            szero[threadIdx.x] += szero[threadIdx.x + w];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        totals[0] = ssum[0];
-        totals[1] = szero[0];
-        totals[2] = nsites;
-    }
+    rt_reduce_partials_body(partial, npartials, totals, nsites);
 }
 
 // ---------------------------------------------------------------------------
@@ -1483,11 +1448,57 @@ static int launch_generic(rt_model *m, rt_sites *s, const char **name)
     return RT_OK;
 }
 
-int rt_launch_prune(rt_model *m, rt_sites *s)
+// the batch's previous all-reduce must have finished before its totals are rewritten
+static int wait_for_collective(rt_ctx *ctx, rt_sites *s)
+{
+    if (s->comm_pending) {
+        // usually it has, long ago, and a wait packet on the compute stream (a few us
+        // of dispatch latency each) is not needed
+        if (ctx->comm && hipEventQuery(s->ev_comm_done) != hipSuccess)
+            RT_HIP(hipStreamWaitEvent(ctx->stream, s->ev_comm_done, 0));
+        (void)hipGetLastError();             // hipErrorNotReady is not an error
+        s->comm_pending = false;
+    }
+    return RT_OK;
+}
+
+bool rt_take_pending_reduce(rt_ctx *ctx, rt_reduce_args *out)
+{
+    rt_sites *s = ctx->pending_reduce;
+    if (!s) return false;
+    if (wait_for_collective(ctx, s) != RT_OK) return false;    // stays pending: flushed later
+    ctx->pending_reduce = nullptr;
+    out->partial = s->d_partial;
+    out->npartials = (long)s->npartials;
+    out->totals = s->d_totals;
+    out->nsites = (double)s->nsites;
+    return true;
+}
+
+int rt_flush_reduce(rt_ctx *ctx)
+{
+    rt_sites *s = ctx->pending_reduce;
+    if (!s) return RT_OK;
+    ctx->pending_reduce = nullptr;
+    RT_TRY(wait_for_collective(ctx, s));
+    hipEvent_t ev = nullptr;
+    rt_time_begin(ctx, RT_K_REDUCE, "reduce_partials", &ev);
+    RT_LAUNCH_TIMED(ctx, reduce_partials_kernel, dim3(1), dim3(256), 0,
+                       s->d_partial, (long)s->npartials, s->d_totals,
+                       (double)s->nsites);
+    RT_HIP(hipGetLastError());
+    rt_time_end(ctx, RT_K_REDUCE, ev);
+    return RT_OK;
+}
+
+int rt_launch_prune(rt_model *m, rt_sites *s, bool defer_reduce)
 {
     rt_ctx *ctx = m->ctx;
     const char *name = "";
     hipEvent_t ev = nullptr;
+    // a reduction still pending reads d_partial of ITS batch: if that is this batch, it
+    // must run before the pruning kernel overwrites the partial sums
+    if (ctx->pending_reduce) RT_TRY(rt_flush_reduce(ctx));
     // which family this batch was packed for
     const bool generic = s->d_scratch != nullptr;
     if (!generic) RT_TRY(rt_launch_pfrag(m));
@@ -1519,20 +1530,8 @@ int rt_launch_prune(rt_model *m, rt_sites *s)
     if (name != s->kernel_name) snprintf(s->kernel_name, sizeof(s->kernel_name), "%s", name);
     rt_time_end(ctx, RT_K_PRUNE, ev);
 
-    if (s->comm_pending) {
-        // the previous all-reduce of this batch's totals must have finished before
-        // the totals are rewritten; usually it has, long ago, and a wait packet on
-        // the compute stream (a few us of dispatch latency each) is not needed
-        if (ctx->comm && hipEventQuery(s->ev_comm_done) != hipSuccess)
-            RT_HIP(hipStreamWaitEvent(ctx->stream, s->ev_comm_done, 0));
-        (void)hipGetLastError();             // hipErrorNotReady is not an error
-        s->comm_pending = false;
-    }
-    rt_time_begin(ctx, RT_K_REDUCE, "reduce_partials", &ev);
-    RT_LAUNCH_TIMED(ctx, reduce_partials_kernel, dim3(1), dim3(256), 0,
-                       s->d_partial, (long)s->npartials, s->d_totals,
-                       (double)s->nsites);
-    RT_HIP(hipGetLastError());
-    rt_time_end(ctx, RT_K_REDUCE, ev);
-    return RT_OK;
+    ctx->pending_reduce = s;
+    // deferred (rt_step): the reduction rides on the next expm launch of this context
+    if (defer_reduce && !getenv("RAOTEH_NO_DEFER_REDUCE")) return RT_OK;
+    return rt_flush_reduce(ctx);
 }

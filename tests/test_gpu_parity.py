@@ -926,6 +926,65 @@ def test_full_size_configs(ra, name, nsites):
     np.testing.assert_array_equal(ll3, ll)
 
 
+def test_config4_rank0_shard_of_eight(ra):
+    """Config 4 = the one million-site codon batch (seed 3) sharded over 8 GPUs
+    (examples/p53/p53.py:88-100 is the sum being sharded): rank 0 of 8 owns sites
+    dist.shard_range(1 000 000, 0, 8) = [0, 125 000).  The whole shard runs on the one
+    GPU here: the oracle on a 2 000-site sample, and size-independent properties on all
+    of it."""
+    from raoteh_amd.dist import shard_range
+    lo, hi = shard_range(ra.synth.C4_NSITES, 0, 8)
+    assert (lo, hi) == (0, 125000)
+    cfg = ra.synth.make_config('c4', site_range=(lo, hi))
+    T, root, n = cfg['T'], cfg['root'], cfg['nstates']
+    leaves, distn = cfg['leaves'], cfg['root_distn']
+    states = cfg['leaf_states']
+    assert states.shape == (125000, 64) and n == 61
+    # the batch is defined chunk by chunk: any sub-range gives the same sites
+    sub = ra.synth.make_config('c4', site_range=(31000, 31500))['leaf_states']
+    np.testing.assert_array_equal(sub, states[31000:31500])
+    model = ra.device.TreeModel(T, root, n)
+    model.set_rates(Q_default=cfg['Q_default'])
+    model.set_root_distn(distn)
+    # uint8 states cross PCIe; the resident layout is the dense f64 one (3.9 GB)
+    batch = model.upload_sites(leaves, states, kind='state')
+    assert batch.device_bytes >= 125000 * 64 * 61 * 8
+    ll, st = model.log_likelihoods(batch)
+    tot = model.fetch_totals(batch)
+    assert batch.kernel_name.startswith('prune_tree_jit_mfma<61')
+    assert not st.any() and np.isfinite(ll).all() and tot[1] == 0 and tot[2] == 125000
+    # the oracle on a bounded sample
+    pick = np.sort(np.random.RandomState(8).choice(125000, 2000, replace=False))
+    pre, idx, ptr, esd = orc.get_expm_augmented_transitions(
+        T, root, n, Q_default=cfg['Q_default'])
+    oidx = [pre.index(v) for v in leaves]
+    want, wst = orc.batch_log_likelihoods(
+        idx, ptr, esd, oidx, ra.synth.one_hot(states[pick], n), distn)
+    assert not wst.any()
+    np.testing.assert_allclose(ll[pick], want, rtol=RTOL_LL)
+    # checksum of checksums: the device total is the sum of the per-site values
+    assert tot[0] == pytest.approx(ll.sum(), rel=1e-12)
+    # shards add: two half shards, each in its own batch (other tile positions, the
+    # second through a dense upload), give the same per-site values bit for bit
+    a = model.upload_sites(leaves, states[:62500], kind='state')
+    lla, _ = model.log_likelihoods(a)
+    ta = model.fetch_totals(a)
+    a.close()
+    b = model.upload_sites(leaves, ra.synth.one_hot(states[62500:70500], n), kind='dense')
+    llb, _ = model.log_likelihoods(b)
+    b.close()
+    np.testing.assert_array_equal(lla, ll[:62500])
+    np.testing.assert_array_equal(llb, ll[62500:70500])
+    assert ta[0] + ll[62500:].sum() == pytest.approx(tot[0], rel=1e-12)
+    # one step of the repeated-evaluation loop (expm + prune, reduce deferred) leaves
+    # every number where it was
+    model.step(batch)
+    tot2 = model.fetch_totals(batch)
+    ll2, _ = model.fetch_log_likelihoods(batch)
+    np.testing.assert_array_equal(ll2, ll)
+    assert tot2[0] == tot[0]
+
+
 def test_reversible_model_rerooting_invariance_full_batch(ra):
     # reference tests/test_mjp.py:126-137 property at batch scale
     cfg = ra.synth.make_config('c2', nsites=5000)
@@ -941,6 +1000,82 @@ def test_reversible_model_rerooting_invariance_full_batch(ra):
             base = ll
         else:
             np.testing.assert_allclose(ll, base, rtol=1e-10)
+
+
+def test_deferred_reduce_gives_the_same_totals(ra):
+    # rt_step leaves the fixed-order reduction of the batch sum to the next expm launch
+    # (one extra workgroup) or to whoever reads the totals first; the numbers are those
+    # of the stand-alone reduce kernel bit for bit
+    cfg = ra.synth.make_config('c2', nsites=30011)
+    model = ra.device.TreeModel(cfg['T'], cfg['root'], cfg['nstates'])
+    model.set_rates(Q_default=cfg['Q_default'])
+    model.set_root_distn(cfg['root_distn'])
+    dense = ra.synth.leaf_likelihoods(cfg)
+    b1 = model.upload_sites(cfg['leaves'], dense[:20000])
+    b2 = model.upload_sites(cfg['leaves'], dense[20000:])
+    model.prune(b1)                       # reduce launched right away
+    model.prune(b2)
+    t1, t2 = model.fetch_totals(b1), model.fetch_totals(b2)
+    assert t1[2] == 20000 and t2[2] == 10011
+    for order in ((b1, b2, b1, b1, b2), (b2, b2, b1)):
+        for b in order:
+            model.step(b)                 # reduce of the previous step rides on this expm
+        np.testing.assert_array_equal(model.fetch_totals(b1), t1)
+        np.testing.assert_array_equal(model.fetch_totals(b2), t2)
+    model.step(b1)
+    model.step(b2)
+    ra.ctx.sync()                         # flushes the reduction still pending
+    np.testing.assert_array_equal(model.fetch_totals(b2), t2)
+    # a batch may go away while its reduction is pending
+    model.step(b1)
+    b3 = model.upload_sites(cfg['leaves'], dense[:777])
+    model.step(b3)
+    b3.close()
+    model.step(b2)
+    np.testing.assert_array_equal(model.fetch_totals(b1), t1)
+    np.testing.assert_array_equal(model.fetch_totals(b2), t2)
+    # the same with a model whose expm kernel is the workgroup-per-matrix one
+    cfg5 = ra.synth.make_config('c5', nsites=3000)
+    m5 = ra.device.TreeModel(cfg5['T'], cfg5['root'], cfg5['nstates'])
+    m5.set_rates(Q_default=cfg5['Q_default'])
+    m5.set_root_distn(cfg5['root_distn'])
+    c1 = m5.upload_sites(cfg5['leaves'], ra.synth.leaf_likelihoods(cfg5))
+    m5.prune(c1)
+    want = m5.fetch_totals(c1)
+    for _ in range(3):
+        m5.step(c1)
+    np.testing.assert_array_equal(m5.fetch_totals(c1), want)
+    model.step(b1)                        # two models of one context interleave
+    m5.step(c1)
+    model.step(b2)
+    np.testing.assert_array_equal(m5.fetch_totals(c1), want)
+    np.testing.assert_array_equal(model.fetch_totals(b1), t1)
+
+
+def test_options_are_per_context_and_kernels_are_verified(ra):
+    cfg = ra.synth.make_config('c5', nsites=500)
+    dense = ra.synth.leaf_likelihoods(cfg)
+    other = ra.device.Context(0)
+    names = {}
+    for ctx, jit in ((ra.ctx, None), (other, 0), (ra.ctx, 1)):
+        if jit is not None:
+            ctx.set_option('jit', jit)
+        model = ra.device.TreeModel(cfg['T'], cfg['root'], cfg['nstates'], ctx=ctx)
+        model.set_rates(Q_default=cfg['Q_default'])
+        model.set_root_distn(cfg['root_distn'])
+        b = model.upload_sites(cfg['leaves'], dense)
+        ll, st = model.log_likelihoods(b)
+        names[(ctx is other, jit)] = (b.kernel_name, ll)
+    ra.ctx.set_option('jit', None)
+    # 500 sites: automatic = interpreter; the other context was told "never", this one
+    # "always" afterwards -- neither setting leaked into the other context
+    assert names[(False, None)][0].startswith('prune_mfma_solo')
+    assert names[(True, 0)][0].startswith('prune_mfma_solo')
+    assert names[(False, 1)][0].startswith('prune_tree_jit_mfma')
+    np.testing.assert_array_equal(names[(False, 1)][1], names[(True, 0)][1])
+    with pytest.raises(ValueError):
+        ra.ctx.set_option('no_such_option', 1)
+    other.close()
 
 
 def test_timing_and_clone(ra):

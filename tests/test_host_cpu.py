@@ -279,3 +279,19 @@ def test_frechet_block_assembly_is_the_adjoint_of_expm_frechet():
     with pytest.raises(ValueError):
         _mjp_dense._frechet_contractions(ScipyExpm(), [np.zeros((32, 32))], [1.0],
                                          np.zeros((1, 32, 32)))
+
+
+def test_observed_states_are_range_checked_not_wrapped():
+    # a plain uint8 cast would turn state 256 into state 0 silently
+    from raoteh_amd.device import _as_uint8_states
+    a = _as_uint8_states(np.array([[0, 3, 255], [-1, 2, 1]]), 4)
+    assert a.dtype == np.uint8 and a.tolist() == [[0, 3, 255], [255, 2, 1]]
+    assert _as_uint8_states(np.array([[60, 255]], dtype=np.uint8), 61).tolist() == [[60, 255]]
+    for bad in (np.array([[256]]), np.array([[4]]), np.array([[-2]]),
+                np.array([[61]], dtype=np.uint8)):
+        with pytest.raises(ValueError):
+            _as_uint8_states(bad, 4 if bad.dtype != np.uint8 else 61)
+    with pytest.raises(ValueError):
+        _as_uint8_states(np.array([[0.0]]), 4)
+    with pytest.raises(ValueError):
+        _as_uint8_states(np.array([[0]]), 300)
