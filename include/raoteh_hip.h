@@ -37,7 +37,9 @@ extern "C" {
 #define RT_ERR_SINGULAR     -6   /* expm: Pade denominator singular          */
 
 #define RT_MAX_STATES       64   /* n <= 64 for the pruning kernels          */
-#define RT_MAX_EXPM_STATES  62   /* n <= 62 for the LDS-resident expm        */
+#define RT_MAX_EXPM_STATES 128   /* expm: n <= 64 LDS-resident, <= 128 through
+                                    L2-resident scratch (the Frechet blocks of the
+                                    61-state codon model have order 122)        */
 
 /* per-site status written by rt_prune (reference: StructuralZeroProb raised
  * by _mc0_dense.py:190-203 when the root likelihood is zero)                */

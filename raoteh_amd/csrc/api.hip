@@ -126,6 +126,7 @@ extern "C" int rt_ctx_destroy(rt_ctx *ctx)
     hipStreamDestroy(ctx->stream);
     hipFree(ctx->d_totals_arena);
     hipFree(ctx->d_scratch);
+    hipFree(ctx->d_expm_scratch);
     delete ctx;
     return RT_OK;
 }

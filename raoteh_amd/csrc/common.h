@@ -90,7 +90,9 @@ struct rt_ctx {
     // totals, rt_prune, rt_ctx_sync and the destructors flush it (rt_flush_reduce).
     struct rt_sites *pending_reduce = nullptr;
     size_t expm_attr_lds = 0;      // dynamic-LDS attribute already granted to expm_kernel
-    size_t expm_ts_attr_lds[4] = {0, 0, 0, 0};   // ... to the Taylor kernels (per NT)
+    size_t expm_ts_attr_lds[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ... to the Taylor kernels (per NT)
+    double *d_expm_scratch = nullptr;   // matrices of the order > 64 Taylor kernel (grow-only)
+    size_t expm_scratch_bytes = 0;
 };
 static const int RT_OPT_UNSET = -2;
 

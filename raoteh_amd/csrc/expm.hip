@@ -450,172 +450,152 @@ expm_kernel(int n, const double *__restrict__ Q, const int *__restrict__ qidx,
 }
 
 // ---------------------------------------------------------------------------
-// 4 < n <= 62, default: scaling and squaring around a TAYLOR polynomial evaluated
-// by Paterson-Stockmeyer -- matrix products only, no linear solve.
+// n > 4, default: scaling and squaring around a TAYLOR polynomial evaluated by
+// Paterson-Stockmeyer -- matrix products only, no linear solve.
 //
 // The [m/m] Pade kernel above spends half of its time in the n pivot steps of the
 // solve (two workgroup barriers each, a chain of n dependent rank-1 updates that the
 // matrix pipe cannot help with: 50 of 103 us at n = 61).  A Taylor polynomial of
-// degree m = k q costs (k - 1) + (q - 1) products and nothing else:
-//     powers   A^2 = A A, ..., A^k = A A^(k-1)                      (k - 1 products)
-//     Horner   T = c_m A^k + B_(q-1);  T = A^k T + B_j, j = q-2..0  (q - 1 products)
-//     with B_j = sum_{i<k} c_(kj+i) A^i  (elementwise),  c_i = 1 / i!
+// degree m = 3 q costs 2 + (q - 1) products and nothing else:
+//     powers   A^2 = A A,  A^3 = A A^2                                (2 products)
+//     Horner   T = B_(q-1);  T = A^3 T + B_j, j = q-2..0              (q - 1 products)
+//     with B_j = c_(3j) I + c_(3j+1) A + c_(3j+2) A^2 (elementwise),  c_i = 1 / i!
 // Degree from ||A||_1 against theta_m, the largest norm for which the backward error
 // of T_m stays below 2^-53 (computed as in Higham 2005 sec. 2 for the Taylor series of
 // log(e^-x T_m(x)); the same numbers as Al-Mohy & Higham 2011, table 3.1):
-//     m = 4 (k = 2: 2 products), 8, 12, 16 (k = 4: 4, 5, 6 products);
-// beyond theta_16 = 0.78 one squaring per doubling of the norm (a squaring doubles the
+//     m = 3, 6, 9, 12, 15  (2, 3, 4, 5, 6 products);
+// beyond theta_15 = 0.64 one squaring per doubling of the norm (a squaring doubles the
 // range for one product, a higher degree does not).  Entrywise accuracy against
 // 60-digit arithmetic on the codon matrix: 6e-15 relative at t = 0.1 (scipy's Pade
 // approximant: 5e-14).
 //
-// Products run on the f64 matrix pipe as in lds_matmul, but with the operands of
-// k-step kk + 1 requested before the MFMAs of k-step kk are issued and the up to four
-// output tiles of a wave advanced together (four independent accumulation chains), and
-// the "+ B_j" of a Horner step is applied when the product is stored.
+// Four matrices (A, A^2, A^3, T) live zero-padded to 16 NT rows with an odd leading
+// dimension 16 NT + 1 -- in LDS for n <= 64 (133 KB), in a per-workgroup slice of global
+// scratch (L2-resident) for 64 < n <= 128, the order of the Frechet blocks of the codon
+// model -- so that no operand fetch needs a bounds check.  The four waves tile the
+// output 2 x 2; each holds RH x RH output tiles (RH = ceil(NT / 2)) and per k-step
+// fetches RH slices of X and RH of Y for RH^2 MFMAs, the fetches of k-step kk + 1 issued
+// before the MFMAs of k-step kk.  "+ B_j" is applied when the product is stored.
 // ---------------------------------------------------------------------------
 
-__constant__ double c_theta_taylor[4] = {3.3971688e-4, 4.9912289e-2, 2.9961589e-1,
-                                         7.8028743e-1};
-// 1 / i!, i = 0..16
-__constant__ double c_inv_fact[17] = {
+__constant__ double c_theta_taylor[5] = {1.3863479e-5, 9.0656564e-3, 8.9577602e-2,
+                                         2.9961589e-1, 6.4108352e-1};
+// 1 / i!, i = 0..15
+__constant__ double c_inv_fact[16] = {
     1.0, 1.0, 0.5, 1.0 / 6.0, 1.0 / 24.0, 1.0 / 120.0, 1.0 / 720.0, 1.0 / 5040.0,
     1.0 / 40320.0, 1.0 / 362880.0, 1.0 / 3628800.0, 1.0 / 39916800.0, 1.0 / 479001600.0,
-    1.0 / 6227020800.0, 1.0 / 87178291200.0, 1.0 / 1307674368000.0,
-    1.0 / 20922789888000.0};
+    1.0 / 6227020800.0, 1.0 / 87178291200.0, 1.0 / 1307674368000.0};
 
-// C = X * Y (+ B) on the matrix pipe; n x n matrices in LDS, leading dimension ld.
-// B = cf[0] I + cf[1] P1 + cf[2] P2 + cf[3] P3 when cf != nullptr (P2 / P3 may be null).
+// C = X * Y (+ cf0 I + cf1 P1 + cf2 P2 when cf != nullptr) on the matrix pipe.  All
+// matrices RN x RN (RN = 16 NT), leading dimension LD = RN + 1, zero outside n x n.
 // C may alias X and / or Y (results are held in registers across a barrier).
-// NT (row / column tiles, n <= 16 NT) is a template parameter so that the number of
-// output tiles per wave NI is a constant and the loop body is straight-line code: every
-// LDS read is unconditional (clamped address, value selected afterwards) and every wave
-// issues NI MFMAs per k-step -- a branch per load or per MFMA makes hipcc serialise the
-// whole product (one exec-mask region per read, the accumulators copied in and out of the
-// AGPRs around every MFMA: 78 us per 61-state expm instead of 20).
 template <int NT>
-__device__ __forceinline__ void lds_matmul_pipelined(const double *X, const double *Y, double *C,
-                                                     int n, int ld, int KS,
-                                                     const double *cf, const double *P1,
-                                                     const double *P2, const double *P3)
+__device__ __forceinline__ void mm_blocked(const double *X, const double *Y, double *C,
+                                           const double *cf, const double *P1, const double *P2)
 {
-    constexpr int NI = NT == 4 ? 4 : NT == 3 ? 3 : 1;      // items (output tiles) per wave
+    constexpr int RH = (NT + 1) / 2;
+    constexpr int LD = 16 * NT + 1;
+    constexpr int KS = 4 * NT;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
     const int lr = lane & 15, lq = lane >> 4;
-    constexpr int nitems = NT * NT;
-    double4_t acc[NI];
-    const double *ap[NI];
-    const double *bp[NI];
-    bool aok[NI], bok[NI];
+    double4_t acc[RH][RH];
+    const double *ap[RH];
+    const double *bp[RH];
+    bool rok[RH], cok[RH];
 #pragma unroll
-    for (int it = 0; it < NI; ++it) {
-        acc[it] = (double4_t){0.0, 0.0, 0.0, 0.0};
-        const int item = wave + 4 * it;
-        const bool valid = item < nitems;
-        const int m = valid ? item / NT : 0, j = valid ? item - m * NT : 0;
-        const int arow = 16 * m + lr, bcol = 16 * j + lr;
-        aok[it] = valid && arow < n;
-        bok[it] = valid && bcol < n;
-        ap[it] = X + (aok[it] ? arow : 0) * ld;
-        bp[it] = Y + (bok[it] ? bcol : 0);
-    }
-    double a0[NI], b0[NI];
-    {
-        const bool kok = lq < n;
-        const int k = kok ? lq : 0;
+    for (int u = 0; u < RH; ++u) {
+        const int m = wr * RH + u, j = wc * RH + u;
+        rok[u] = m < NT;                       // wave-uniform: NT odd leaves a slot empty
+        cok[u] = j < NT;
+        ap[u] = X + (16 * (rok[u] ? m : 0) + lr) * LD + lq;
+        bp[u] = Y + lq * LD + 16 * (cok[u] ? j : 0) + lr;
 #pragma unroll
-        for (int it = 0; it < NI; ++it) {
-            const double av = ap[it][k], bv = bp[it][k * ld];      // always in bounds
-            a0[it] = (aok[it] && kok) ? av : 0.0;
-            b0[it] = (bok[it] && kok) ? bv : 0.0;
-        }
+        for (int v = 0; v < RH; ++v) acc[u][v] = (double4_t){0.0, 0.0, 0.0, 0.0};
     }
+    double a0[RH], b0[RH];
+#pragma unroll
+    for (int u = 0; u < RH; ++u) { a0[u] = ap[u][0]; b0[u] = bp[u][0]; }
     for (int kk = 0; kk < KS; ++kk) {
-        double a1[NI], b1[NI];
-        {
-            // operands of the next k-step (the last iteration re-reads its own)
-            const int kn = 4 * (kk + 1 < KS ? kk + 1 : kk) + lq;
-            const bool kok = kn < n;
-            const int k = kok ? kn : 0;
+        // operands of the next k-step first (the last iteration re-reads its own)
+        const int kn = kk + 1 < KS ? kk + 1 : kk;
+        double a1[RH], b1[RH];
 #pragma unroll
-            for (int it = 0; it < NI; ++it) {
-                const double av = ap[it][k], bv = bp[it][k * ld];
-                a1[it] = (aok[it] && kok) ? av : 0.0;
-                b1[it] = (bok[it] && kok) ? bv : 0.0;
-            }
-        }
+        for (int u = 0; u < RH; ++u) { a1[u] = ap[u][4 * kn]; b1[u] = bp[u][4 * kn * LD]; }
 #pragma unroll
-        for (int it = 0; it < NI; ++it)
-            acc[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[it], b0[it], acc[it], 0, 0, 0);
+        for (int u = 0; u < RH; ++u)
 #pragma unroll
-        for (int it = 0; it < NI; ++it) { a0[it] = a1[it]; b0[it] = b1[it]; }
+            for (int v = 0; v < RH; ++v)
+                acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[v], acc[u][v], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < RH; ++u) { a0[u] = a1[u]; b0[u] = b1[u]; }
     }
     // the addend of a Horner step, read before the barrier
-    double4_t add[NI];
+    if (cf) {
+        const double c0 = cf[0], c1 = cf[1], c2 = cf[2];
 #pragma unroll
-    for (int it = 0; it < NI; ++it) {
-        add[it] = (double4_t){0.0, 0.0, 0.0, 0.0};
-        const int item = wave + 4 * it;
-        if (cf && item < nitems) {
-            const int m = item / NT, j = item - m * NT;
-            const int col = 16 * j + lr;
+        for (int u = 0; u < RH; ++u)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * m + 4 * r + lq;
-                if (row < n && col < n) {
-                    const int o = row * ld + col;
-                    double v = cf[1] * P1[o] + (row == col ? cf[0] : 0.0);
-                    if (P2) v += cf[2] * P2[o];
-                    if (P3) v += cf[3] * P3[o];
-                    add[it][r] = v;
+            for (int v = 0; v < RH; ++v)
+                if (rok[u] && cok[v]) {
+                    const int m = wr * RH + u, j = wc * RH + v;
+                    const int col = 16 * j + lr;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * m + 4 * r + lq;
+                        const int o = row * LD + col;
+                        double w = c1 * P1[o];
+                        if (P2) w += c2 * P2[o];
+                        // the identity only inside n x n: P1 (= A) is zero outside, so
+                        // the diagonal of the padding stays as cf[3] says (0 or c0)
+                        if (row == col && (double)row < cf[3]) w += c0;
+                        acc[u][v][r] += w;
+                    }
                 }
-            }
-        }
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < NI; ++it) {
-        const int item = wave + 4 * it;
-        if (item < nitems) {
-            const int m = item / NT, j = item - m * NT;
-            const int col = 16 * j + lr;
+    for (int u = 0; u < RH; ++u)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * m + 4 * r + lq;
-                if (row < n && col < n) C[row * ld + col] = acc[it][r] + add[it][r];
+        for (int v = 0; v < RH; ++v)
+            if (rok[u] && cok[v]) {
+                const int m = wr * RH + u, j = wc * RH + v;
+                const int col = 16 * j + lr;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) C[(16 * m + 4 * r + lq) * LD + col] = acc[u][v][r];
             }
-        }
-    }
     __syncthreads();
 }
 
-template <int NT>
+// GLOBAL = false: the four matrices in LDS (n <= 64); true: in scratch[blockIdx] (n <= 128)
+template <int NT, bool GLOBAL>
 __global__ void __launch_bounds__(TPB)
 expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ qidx,
                    const double *__restrict__ tt, double *__restrict__ P,
                    int *__restrict__ info, const int *__restrict__ step_of_node,
-                   int frag_kind, double *__restrict__ Pfrag, rt_reduce_args red)
+                   int frag_kind, double *__restrict__ Pfrag, double *__restrict__ scratch,
+                   rt_reduce_args red)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (red.partial && blockIdx.x == gridDim.x - 1) {      // the carried reduction
         rt_reduce_partials_body(red.partial, red.npartials, red.totals, red.nsites);
         return;
     }
-    const int ld = n | 1;
-    const int msz = n * ld;
-    const int KS = (n + 3) / 4;
-    double *B0 = (double *)smem;               // A
-    double *B1 = B0 + msz;                     // A^2
-    double *B2 = B1 + msz;                     // A^3
-    double *B3 = B2 + msz;                     // A^4
-    double *B4 = B3 + msz;                     // T
-    double *cfs = B4 + msz;                    // [4] coefficients of the current B_j
+    constexpr int RN = 16 * NT;
+    constexpr int LD = RN + 1;
+    constexpr int MSZ = RN * LD;
+    __shared__ double cfs[4];
+    __shared__ double colsum[RN];
+    double *B0 = GLOBAL ? scratch + (size_t)blockIdx.x * 4 * MSZ : (double *)smem;   // A
+    double *B1 = B0 + MSZ;                     // A^2
+    double *B2 = B1 + MSZ;                     // A^3
+    double *B3 = B2 + MSZ;                     // T
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
     const int nn = n * n;
+    const int KSn = (n + 3) / 4, NTn = (n + 15) / 16;      // of the n x n matrix (Pfrag)
     double *Pb = P + (long)b * nn;
     const int qi = qidx[b];
     const int step = step_of_node ? step_of_node[b] : -1;
@@ -625,38 +605,55 @@ expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ 
         if (step >= 0 && frag_kind == 0)
             for (int e = tid; e < nn; e += TPB) Pfrag[(long)step * nn + e] = 0.0;
         if (step >= 0 && frag_kind == 1) {
-            const int total = NT * ((KS + 1) / 2) * 128;
+            const int total = NTn * ((KSn + 1) / 2) * 128;
             for (int e = tid; e < total; e += TPB) Pfrag[(long)step * total + e] = 0.0;
         }
         return;
     }
     const double *Qb = Q + (long)qi * nn;
     const double t = tt[b];
-    RT_FOR_EACH_ELEMENT(i, j, o_unused_) {
-        B0[i * ld + j] = Qb[i * n + j] * t;
+    // A = Q t, zero-padded; every thread's loads are in flight together (a loop of
+    // dependent load -> store pairs costs one L2 round trip per iteration)
+    {
+        constexpr int PER = (MSZ + TPB - 1) / TPB;
+        for (int c0 = 0; c0 < PER; c0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = (c0 + u) * TPB + tid;
+                const int i = e / LD, j = e - i * LD;
+                v[u] = (e < MSZ && i < n && j < n) ? Qb[i * n + j] * t : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = (c0 + u) * TPB + tid;
+                if (e < MSZ) B0[e] = v[u];
+            }
+        }
     }
     __syncthreads();
-    double nrm;
-    {
+    // ||A||_1 = max column sum
+    for (int j = tid; j < RN; j += TPB) {
         double s = 0.0;
-        if (lane < n)
-            for (int i = 0; i < n; ++i) s += fabs(B0[i * ld + lane]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s = fmax(s, __shfl_xor(s, o, 64));
-        nrm = s;
+        for (int i = 0; i < n; ++i) s += fabs(B0[i * LD + j]);
+        colsum[j] = s;
     }
-    if (!(nrm < 1e300)) {                      // inf / NaN in Q * t (wave- and block-uniform)
+    __syncthreads();
+    double nrm = 0.0;
+    for (int j = 0; j < RN; ++j) nrm = fmax(nrm, colsum[j]);
+    if (!(nrm < 1e300)) {                      // inf / NaN in Q * t (block-uniform)
         for (int e = tid; e < nn; e += TPB) Pb[e] = __builtin_nan("");
         if (info && tid == 0) { info[2 * b] = -1; info[2 * b + 1] = 0; }
         return;
     }
-    int m = 16, s = 0;
-    if (nrm <= c_theta_taylor[0]) m = 4;
-    else if (nrm <= c_theta_taylor[1]) m = 8;
-    else if (nrm <= c_theta_taylor[2]) m = 12;
-    else if (nrm > c_theta_taylor[3]) {
+    int m = 15, s = 0;
+    if (nrm <= c_theta_taylor[0]) m = 3;
+    else if (nrm <= c_theta_taylor[1]) m = 6;
+    else if (nrm <= c_theta_taylor[2]) m = 9;
+    else if (nrm <= c_theta_taylor[3]) m = 12;
+    else if (nrm > c_theta_taylor[4]) {
         int e;
-        const double f = frexp(nrm / c_theta_taylor[3], &e);    // ratio = f * 2^e
+        const double f = frexp(nrm / c_theta_taylor[4], &e);    // ratio = f * 2^e
         s = (f == 0.5) ? e - 1 : e;
         if (s < 0) s = 0;
     }
@@ -664,54 +661,49 @@ expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ 
     s = __builtin_amdgcn_readfirstlane(s);
     if (info && tid == 0) { info[2 * b] = m; info[2 * b + 1] = s; }
     if (s > 0) {
-        __syncthreads();
         const double sc = ldexp(1.0, -s);
-        RT_FOR_EACH_ELEMENT(i, j, o) {
-            B0[o] *= sc;
-        }
+        for (int e = tid; e < MSZ; e += TPB) B0[e] *= sc;
         __syncthreads();
     }
-    const int k = (m == 4) ? 2 : 4;
-    const int q = m / k;
-    lds_matmul_pipelined<NT>(B0, B0, B1, n, ld, KS, nullptr, nullptr, nullptr, nullptr);   // A^2
-    if (k == 4) {
-        lds_matmul_pipelined<NT>(B0, B1, B2, n, ld, KS, nullptr, nullptr, nullptr, nullptr);  // A^3
-        lds_matmul_pipelined<NT>(B0, B2, B3, n, ld, KS, nullptr, nullptr, nullptr, nullptr);  // A^4
-    }
-    const double *Pk = (k == 4) ? B3 : B1;
-    const double *P2 = (k == 4) ? B1 : nullptr;
-    const double *P3 = (k == 4) ? B2 : nullptr;
-    // T = c_m A^k + B_(q-1)
+    const int q = m / 3;
+    mm_blocked<NT>(B0, B0, B1, nullptr, nullptr, nullptr);     // A^2
+    mm_blocked<NT>(B0, B1, B2, nullptr, nullptr, nullptr);     // A^3
+    // T = B_(q-1) = c I + c A + c A^2 (the top block has no A^3 term: m = 3 q - ... see
+    // below: the degree-m polynomial is sum_{j<q} A^(3j) B_j plus c_m A^m, and c_m A^m =
+    // A^(3(q-1)) (c_m A^3), so the top block carries the A^3 term)
     {
-        const int base = k * (q - 1);
-        RT_FOR_EACH_ELEMENT(i, j, o) {
-            double v = c_inv_fact[m] * Pk[o] + c_inv_fact[base + 1] * B0[o] +
-                       (i == j ? c_inv_fact[base] : 0.0);
-            if (k == 4) v += c_inv_fact[base + 2] * B1[o] + c_inv_fact[base + 3] * B2[o];
-            B4[o] = v;
+        const int base = 3 * (q - 1);
+        const double c0 = c_inv_fact[base], c1 = c_inv_fact[base + 1],
+                     c2 = c_inv_fact[base + 2], c3 = c_inv_fact[m];
+        for (int e = tid; e < MSZ; e += TPB) {
+            const int i = e / LD, j = e - i * LD;
+            B3[e] = c1 * B0[e] + c2 * B1[e] + c3 * B2[e] + ((i == j && i < n) ? c0 : 0.0);
         }
         __syncthreads();
     }
     for (int jj = q - 2; jj >= 0; --jj) {
-        if (tid < 4) cfs[tid] = (tid < k) ? c_inv_fact[k * jj + tid] : 0.0;
+        if (tid < 3) cfs[tid] = c_inv_fact[3 * jj + tid];
+        if (tid == 3) cfs[3] = (double)n;
         __syncthreads();
-        lds_matmul_pipelined<NT>(Pk, B4, B4, n, ld, KS, cfs, B0, P2, P3);   // T = A^k T + B_j
+        mm_blocked<NT>(B2, B3, B3, cfs, B0, B1);               // T = A^3 T + B_j
     }
-    for (int r = 0; r < s; ++r)
-        lds_matmul_pipelined<NT>(B4, B4, B4, n, ld, KS, nullptr, nullptr, nullptr, nullptr);
+    for (int r = 0; r < s; ++r) mm_blocked<NT>(B3, B3, B3, nullptr, nullptr, nullptr);
 
-    const double *Xb = B4;
-    RT_FOR_EACH_ELEMENT(i, j, o_unused_) {
-        Pb[i * n + j] = Xb[i * ld + j];
+    const double *Xb = B3;
+    for (int e = tid; e < nn; e += TPB) {
+        const int i = e / n, j = e - i * n;
+        Pb[e] = Xb[i * LD + j];
     }
     if (step >= 0 && frag_kind == 0) {
-        RT_FOR_EACH_ELEMENT(i, j, o_unused_) {
-            Pfrag[(long)step * nn + i * n + j] = Xb[i * ld + j];
+        for (int e = tid; e < nn; e += TPB) {
+            const int i = e / n, j = e - i * n;
+            Pfrag[(long)step * nn + e] = Xb[i * LD + j];
         }
     } else if (step >= 0 && frag_kind == 1) {
-        // Pfrag[step][m][q][lane][e2] = P[16m + (lane&15)][4(2q+e2) + (lane>>4)]
-        const int KP = (KS + 1) / 2;
-        const int total = NT * KP * 128;
+        // Pfrag[step][m][q][lane][e2] = P[16m + (lane&15)][4(2q+e2) + (lane>>4)]; the
+        // padding of Xb is zero, so no bounds check (KP pairs cover <= RN columns)
+        const int KP = (KSn + 1) / 2;
+        const int total = NTn * KP * 128;
         for (int e = tid; e < total; e += TPB) {
             const int e2 = e & 1;
             const int ln = (e >> 1) & 63;
@@ -719,7 +711,7 @@ expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ 
             const int mm = (e >> 7) / KP;
             const int row = 16 * mm + (ln & 15);
             const int col = 4 * (2 * qq + e2) + (ln >> 4);
-            Pfrag[(long)step * total + e] = (row < n && col < n) ? Xb[row * ld + col] : 0.0;
+            Pfrag[(long)step * total + e] = (col < RN) ? Xb[row * LD + col] : 0.0;
         }
     }
 }
@@ -933,11 +925,12 @@ int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
         rt_set_error("expm: n=%lld outside 1..%d", (long long)n, RT_MAX_EXPM_STATES);
         return RT_ERR_UNSUPPORTED;
     }
+    const int64_t RT_MAX_PADE_STATES = 62;     // five n x (n|1) LDS buffers
     if (count <= 0 && !extra) return RT_OK;
     const int ld = (int)n | 1;
     const size_t lds = (size_t)5 * n * ld * 8 + (128 + 128 + 64) * 8 + (8 + 64) * 4;
     size_t &attr_lds = ctx->expm_attr_lds;
-    if (lds > attr_lds) {
+    if (n <= RT_MAX_PADE_STATES && lds > attr_lds) {
         RT_HIP(hipFuncSetAttribute((const void *)expm_kernel,
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
@@ -965,28 +958,49 @@ int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
     // default: the Taylor / Paterson-Stockmeyer kernel (products only);
     // RAOTEH_EXPM=pade keeps the Pade + register Gauss-Jordan kernel (A/B runs, soak)
     const char *which = getenv("RAOTEH_EXPM");
-    if (!(which && strcmp(which, "pade") == 0)) {
-        const size_t lds_t = (size_t)5 * n * ld * 8 + 4 * 8;
+    if (n > RT_MAX_PADE_STATES || !(which && strcmp(which, "pade") == 0)) {
         const int nt = (int)((n + 15) / 16);
+        const size_t msz = (size_t)(16 * nt) * (16 * nt + 1);
+        const bool global = nt > 4;
+        const size_t lds_t = global ? 0 : 4 * msz * 8;
+        double *scratch = nullptr;
+        if (global) {
+            // four matrices per workgroup in global scratch (grow-only, per context)
+            const size_t need = (size_t)count * 4 * msz * 8;
+            if (need > ctx->expm_scratch_bytes) {
+                RT_HIP(hipStreamSynchronize(ctx->stream));
+                hipFree(ctx->d_expm_scratch);
+                ctx->d_expm_scratch = nullptr;
+                ctx->expm_scratch_bytes = 0;
+                RT_HIP(hipMalloc((void **)&ctx->d_expm_scratch, need));
+                ctx->expm_scratch_bytes = need;
+            }
+            scratch = ctx->d_expm_scratch;
+        }
         hipEvent_t ev = nullptr;
-        rt_time_begin(ctx, RT_K_EXPM, "expm_taylor_ps_mfma", &ev);
-#define RT_TAYLOR(NTV)                                                                          \
+        rt_time_begin(ctx, RT_K_EXPM, global ? "expm_taylor_ps_mfma_global" : "expm_taylor_ps_mfma",
+                      &ev);
+#define RT_TAYLOR(NTV, GL)                                                                      \
         do {                                                                                    \
             if (lds_t > ctx->expm_ts_attr_lds[NTV - 1]) {                                       \
-                RT_HIP(hipFuncSetAttribute((const void *)expm_taylor_kernel<NTV>,               \
+                RT_HIP(hipFuncSetAttribute((const void *)expm_taylor_kernel<NTV, GL>,           \
                                            hipFuncAttributeMaxDynamicSharedMemorySize,          \
                                            (int)lds_t));                                        \
                 ctx->expm_ts_attr_lds[NTV - 1] = lds_t;                                         \
             }                                                                                   \
-            RT_LAUNCH_TIMED(ctx, expm_taylor_kernel<NTV>, dim3((unsigned)count + extra),        \
+            RT_LAUNCH_TIMED(ctx, (expm_taylor_kernel<NTV, GL>), dim3((unsigned)count + extra),  \
                             dim3(TPB), lds_t, (int)n, d_Q, d_qidx, d_t, d_P, d_info,            \
-                            d_step_of_node, frag_kind, d_Pfrag, red);                           \
+                            d_step_of_node, frag_kind, d_Pfrag, scratch, red);                  \
         } while (0)
         switch (nt) {
-        case 1: RT_TAYLOR(1); break;
-        case 2: RT_TAYLOR(2); break;
-        case 3: RT_TAYLOR(3); break;
-        default: RT_TAYLOR(4); break;
+        case 1: RT_TAYLOR(1, false); break;
+        case 2: RT_TAYLOR(2, false); break;
+        case 3: RT_TAYLOR(3, false); break;
+        case 4: RT_TAYLOR(4, false); break;
+        case 5: RT_TAYLOR(5, true); break;
+        case 6: RT_TAYLOR(6, true); break;
+        case 7: RT_TAYLOR(7, true); break;
+        default: RT_TAYLOR(8, true); break;
         }
 #undef RT_TAYLOR
         RT_HIP(hipGetLastError());
