@@ -266,6 +266,9 @@ int64_t rt_sites_device_bytes(const rt_sites *sites);
  * (0: none, or the kernel came from the cache), and the name of the pruning kernel
  * variant the batch last ran (owned by the batch; "" before the first rt_prune). */
 double rt_sites_jit_compile_seconds(const rt_sites *sites);
+/* Diagnostics: copy a __device__ variable of the batch's compiled kernel to the host
+ * (the per-step clock stamps of RAOTEH_JIT_TRACE, tools/trace_c3.py).              */
+int rt_debug_jit_global(rt_sites *sites, const char *name, void *dst, int64_t bytes);
 const char *rt_sites_kernel_name(const rt_sites *sites);
 
 int rt_prune(rt_model *model, rt_sites *sites);
@@ -299,6 +302,45 @@ int rt_allreduce_totals(rt_ctx *ctx, rt_sites *sites);
  * batches were created one after the other (their totals are then neighbours in
  * device memory), else one collective each.                                  */
 int rt_allreduce_totals_group(rt_ctx *ctx, rt_sites **sites, int64_t count);
+
+/* ---- 4. Rao-Teh sweep core: ragged batches of trees, one shared matrix --------
+ * One sweep of the Rao-Teh sampler (_sampler.py:366-390) re-samples the states of a
+ * chunk tree (_graph_transform.py:298-375) per chain, all with the SAME uniformized
+ * transition matrix P = I + Q / omega (_sample_mjp_dense.py:72-114); the topologies
+ * differ from chain to chain and from sweep to sweep.  A forest is the concatenation
+ * of `ntrees` such trees:
+ *   tree_node_offset int64[ntrees + 1]   tree k owns nodes [off[k], off[k+1]), numbered
+ *       in ITS OWN DFS preorder (local index 0 = its root)
+ *   tree_csr_indptr  int64[total + ntrees]  tree k's indptr (nnodes_k + 1 entries, as
+ *       _density.digraph_to_bool_csr returns it) starts at off[k] + k
+ *   tree_csr_indices int64[total - ntrees]  tree k's child indices (nnodes_k - 1 local
+ *       preorder indices) start at off[k] - k
+ *   P f64[n][n]: an entry that is exactly zero is a structural zero; n <= 64
+ *   allowed_sets uint64[total]: bit s = state s allowed at the node (in / out).
+ *
+ * rt_forest_passes: pyfelscore.mcy_get_node_to_pset then pyfelscore.get_node_to_set
+ * with a boolean CSR of P (_mcy.py:139-181; un-accelerated twins _mcy.py:396-470,
+ * _mc0.py:89-138), in place on allowed_sets, then (subtree_probability != NULL) the
+ * upward pass with that matrix on every edge (_mcy.py:611-682): f64[total][n], every
+ * entry written.                                                                  */
+int rt_forest_passes(rt_ctx *ctx, int64_t n, int64_t ntrees,
+            const int64_t *tree_node_offset, const int64_t *tree_csr_indices,
+            const int64_t *tree_csr_indptr, const double *P,
+            uint64_t *allowed_sets, double *subtree_probability);
+/* The same passes followed by _sample_mc0_dense.resample_states (:53-98) for every
+ * tree: root ~ root_distn * L[root] (root_distn NULL = weights of one), child ~
+ * P[parent's state] * L[child].  Draws come from Philox-4x32-10 keyed by `seed` with
+ * counter (sweep, global node index): the same (seed, sweep, forest) gives the same
+ * states whatever the launch shape.  states int32[total] out (-1 where status != 0),
+ * status int32[ntrees] out: 1 = the tree has zero likelihood (the reference raises
+ * StructuralZeroProb / NumericalZeroProb, _sample_mc0_dense.py:57-62), 2 = a
+ * non-root node had no state of positive weight.  subtree_probability (optional,
+ * f64[total][n]) receives the upward messages the draws were made from.           */
+int rt_forest_resample_states(rt_ctx *ctx, int64_t n, int64_t ntrees,
+            const int64_t *tree_node_offset, const int64_t *tree_csr_indices,
+            const int64_t *tree_csr_indptr, const double *P, const double *root_distn,
+            uint64_t *allowed_sets, uint64_t seed, uint64_t sweep, int32_t *states,
+            int32_t *status, double *subtree_probability);
 
 #ifdef __cplusplus
 }

@@ -131,24 +131,26 @@ def expm_pade(Q, t):
 # the values of Al-Mohy & Higham 2011, table 3.1).  Like expm_pade this restates OUR
 # algorithm, so kernel-vs-scipy differences separate into algorithm and implementation;
 # the reference's own call is scipy.linalg.expm (custom_expm above, _mjp_dense.py:24-25).
-TAYLOR_THETA = {4: 3.3971688e-4, 8: 4.9912289e-2, 12: 2.9961589e-1, 16: 7.8028743e-1}
+TAYLOR_THETA = {3: 1.3863479e-5, 6: 9.0656564e-3, 9: 8.9577602e-2, 12: 2.9961589e-1,
+                15: 6.4108352e-1}
 
 
 def taylor_order_and_squarings(norm1):
     """Degree m and number of squarings s of the Taylor kernel for 1-norm ``norm1``."""
-    for m in (4, 8, 12):
+    for m in (3, 6, 9, 12):
         if norm1 <= TAYLOR_THETA[m]:
             return m, 0
     s = 0
-    if norm1 > TAYLOR_THETA[16]:
-        s = max(0, int(np.ceil(np.log2(norm1 / TAYLOR_THETA[16]))))
-    return 16, s
+    if norm1 > TAYLOR_THETA[15]:
+        s = max(0, int(np.ceil(np.log2(norm1 / TAYLOR_THETA[15]))))
+    return 15, s
 
 
 def expm_taylor(Q, t):
-    """exp(Q t) by the algorithm of csrc/expm.hip expm_taylor_kernel: powers A^2..A^k
-    with A as the left factor, then Horner in A^k over the blocks
-    B_j = sum_{i<k} A^i / (k j + i)!, k = 2 (degree 4) or 4 (degrees 8, 12, 16)."""
+    """exp(Q t) by the algorithm of csrc/expm.hip expm_taylor_kernel: A^2 = A A,
+    A^3 = A A^2, then Horner in A^3 over the blocks
+    B_j = I / (3j)! + A / (3j+1)! + A^2 / (3j+2)!  (the top block also carries
+    A^3 / m!), degree m = 3 q in {3, 6, 9, 12, 15}, then s squarings."""
     import math
     A = np.asarray(Q, dtype=float) * float(t)
     n = A.shape[0]
@@ -158,17 +160,15 @@ def expm_taylor(Q, t):
     if s:
         A = A * (2.0 ** -s)
     c = [1.0 / math.factorial(i) for i in range(m + 1)]
-    k = 2 if m == 4 else 4
-    powers = [I, A]
-    for _ in range(2, k + 1):
-        powers.append(A @ powers[-1])
-    q = m // k
+    A2 = A @ A
+    A3 = A @ A2
+    q = m // 3
 
     def block(j):
-        return sum(c[k * j + i] * powers[i] for i in range(k))
-    X = c[m] * powers[k] + block(q - 1)
+        return c[3 * j] * I + c[3 * j + 1] * A + c[3 * j + 2] * A2
+    X = block(q - 1) + c[m] * A3
     for j in range(q - 2, -1, -1):
-        X = powers[k] @ X + block(j)
+        X = A3 @ X + block(j)
     for _ in range(s):
         X = X @ X
     return X

@@ -101,6 +101,7 @@ SIGNATURES = {
     'rt_ctx_set_option': (c_int, [c_void_p, c_char_p, c_int64]),
     'rt_sites_jit_compile_seconds': (c_double, [c_void_p]),
     'rt_sites_kernel_name': (c_char_p, [c_void_p]),
+    'rt_debug_jit_global': (c_int, [c_void_p, c_char_p, c_void_p, c_int64]),
     'rt_jit_source': (c_int, [c_int64, _p_i64, _p_i64, c_int64, c_int64, _p_i64, c_int64,
                               c_char_p, c_int64]),
     'rt_sites_create': (c_int, [c_void_p, c_int64, c_int, c_int64, _p_i64,
@@ -118,6 +119,12 @@ SIGNATURES = {
     'rt_comm_destroy': (c_int, [c_void_p]),
     'rt_allreduce_totals': (c_int, [c_void_p, c_void_p]),
     'rt_allreduce_totals_group': (c_int, [c_void_p, POINTER(c_void_p), c_int64]),
+    'rt_forest_passes': (c_int, [c_void_p, c_int64, c_int64, _p_i64, _p_i64, _p_i64, _p_f64,
+                                 POINTER(ctypes.c_uint64), _p_f64]),
+    'rt_forest_resample_states': (c_int, [c_void_p, c_int64, c_int64, _p_i64, _p_i64, _p_i64,
+                                          _p_f64, _p_f64, POINTER(ctypes.c_uint64),
+                                          ctypes.c_uint64, ctypes.c_uint64, _p_i32, _p_i32,
+                                          _p_f64]),
 }
 
 _lib = None

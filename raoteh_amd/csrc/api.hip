@@ -361,7 +361,7 @@ extern "C" int rt_model_destroy(rt_model *m)
     hipSetDevice(m->ctx->device);
     hipStreamSynchronize(m->ctx->stream);
     hipFree(m->d_indices); hipFree(m->d_indptr); hipFree(m->d_ops); hipFree(m->d_P);
-    hipFree(m->d_Pfrag); hipFree(m->d_root); hipFree(m->d_Q); hipFree(m->d_qidx);
+    hipFree(m->d_Pfrag); hipFree(m->d_Pquad); hipFree(m->d_root); hipFree(m->d_Q); hipFree(m->d_qidx);
     hipFree(m->d_t); hipFree(m->d_info); hipFree(m->d_step_of_node);
     delete m;
     return RT_OK;
@@ -406,6 +406,12 @@ extern "C" int rt_model_create(rt_ctx *ctx, int64_t nnodes, int64_t n,
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_P, nnodes * nn * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_Pfrag, pfrag_doubles(m) * 8);
     if (e == hipSuccess) e = hipMemset(m->d_Pfrag, 0, pfrag_doubles(m) * 8);
+    if (e == hipSuccess && n > 4 && n <= 32) {
+        const size_t ks = (size_t)((n + 3) / 4);
+        const size_t bytes = m->ops.size() * ks * ks * 16 * 8;
+        e = hipMalloc((void **)&m->d_Pquad, bytes);
+        if (e == hipSuccess) e = hipMemset(m->d_Pquad, 0, bytes);
+    }
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_root, n * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_qidx, nnodes * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_t, nnodes * 8);
@@ -442,7 +448,7 @@ static int model_run_expm(rt_model *m)
     const bool carry = rt_take_pending_reduce(m->ctx, &red);
     RT_TRY(rt_launch_expm(m->ctx, m->n, m->nnodes, m->d_Q, m->d_qidx, m->d_t, m->d_P,
                           m->d_info, m->d_step_of_node, m->n <= 4 ? 0 : 1, m->d_Pfrag,
-                          carry ? &red : nullptr));
+                          carry ? &red : nullptr, m->d_Pquad));
     m->have_P = true;
     m->frag_dirty = false;
     return RT_OK;
@@ -815,6 +821,7 @@ static int sites_alloc(rt_sites *s, bool generic)
 struct jit_override {
     int mode = 0;             // 0 automatic, 1 interpreter only, 2 exactly these parameters
     int T = 1, S = 64, WG = 1, D = 1, LA = 1, compact = 0;
+    bool quad = false;
 };
 
 static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov)
@@ -827,8 +834,9 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
         const std::string src =
             !mfma ? rt_jit_lane_source(s->ops, n, K, ov->D, ov->LA, ov->S, ov->WG, ov->compact)
             : split ? rt_jit_mfma_split_source(s->ops, n, K, ov->T, ov->D, ov->LA)
-                    : rt_jit_mfma_source(s->ops, n, K, ov->T, ov->D, ov->LA);
+                    : rt_jit_mfma_source(s->ops, n, K, ov->T, ov->D, ov->LA, ov->quad);
         RT_TRY(rt_jit_get(s->model->ctx, src, &s->jit_fn, mfma));
+        s->jit_quad = mfma && !split && ov->quad;
         s->jit_prefetch = ov->D;
         s->jit_lookahead = ov->LA;
         s->jit_tiles = ov->T;
@@ -902,13 +910,22 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
         if (const char *v = getenv("RAOTEH_JIT_LOOKAHEAD")) LA = std::max(1, atoi(v));
         s->jit_prefetch = D;
         s->jit_lookahead = LA;
+        // built on v_mfma_f64_4x4x4_4b (4 rows x 16 sites per instruction: no padding of
+        // n to a multiple of 16 rows) unless RAOTEH_JIT_QUAD=0
+        // (off by default: measured on config 5 it changes nothing -- 86.9 us against
+        // 83.9 us at T = 4, and it is slower at fewer tiles per wave, where the 25 replicated
+        // A fetches per step of this form weigh more -- because that kernel is not bound by
+        // the matrix pipe but by what one wave per SIMD can keep in flight)
+        const bool quad = s->model->d_Pquad != nullptr && getenv("RAOTEH_JIT_QUAD") &&
+                          atoi(getenv("RAOTEH_JIT_QUAD")) != 0;
         int rc = RT_ERR_UNSUPPORTED;
         for (; T >= 1 && rc == RT_ERR_UNSUPPORTED; --T) {         // fewer tiles if it spills
             const std::string src =
-                rt_jit_mfma_source(s->ops, (int)s->model->n, (int)s->nobs, T, D, LA);
+                rt_jit_mfma_source(s->ops, (int)s->model->n, (int)s->nobs, T, D, LA, quad);
             rc = rt_jit_get(s->model->ctx, src, &s->jit_fn, true, &s->jit_compile_s);
         }
         ++T;
+        if (rc == RT_OK) s->jit_quad = quad;
         if (rc != RT_OK && (!forced || rc == RT_ERR_UNSUPPORTED)) {
             s->jit_fn = nullptr;               // the interpreter kernel runs
             return RT_OK;
@@ -1007,7 +1024,8 @@ extern "C" int rt_jit_source(int64_t nnodes, const int64_t *idx, const int64_t *
     const std::string src = n <= 4
         ? rt_jit_lane_source(m.ops, (int)n, (int)nobs, (int)prefetch, LA, 64, 4,
                              getenv("RAOTEH_JIT_SOURCE_STATES") != nullptr)
-        : n <= 32 ? rt_jit_mfma_source(m.ops, (int)n, (int)nobs, T, (int)prefetch, 1)
+        : n <= 32 ? rt_jit_mfma_source(m.ops, (int)n, (int)nobs, T, (int)prefetch, 1,
+                                       getenv("RAOTEH_JIT_QUAD") && atoi(getenv("RAOTEH_JIT_QUAD")) != 0)
                   : rt_jit_mfma_split_source(m.ops, (int)n, (int)nobs, std::min(T, 3),
                                              (int)prefetch, 1);
     RT_REQUIRE((int64_t)src.size() + 1 <= capacity, "buffer too small: %lld bytes needed",
@@ -1088,6 +1106,7 @@ static int sites_create_impl(rt_model *m, int64_t nsites, int kind, int64_t nobs
             s->jit_waves = 1;
             s->jit_tiles = 1;
             s->compact_states = 0;
+            s->jit_quad = false;
         }
     }
     if (rc == RT_OK) rc = sites_alloc(s, generic);
@@ -1183,6 +1202,7 @@ static int verify_jit_kernel(rt_sites *s, int kind)
     same.D = s->jit_prefetch;
     same.LA = s->jit_lookahead;
     same.compact = s->compact_states;
+    same.quad = s->jit_quad;
     if (rc == RT_OK)
         rc = sites_create_impl(tm, np, pkind, K, obs_nodes.data(), data, &interp, &si);
     if (rc == RT_OK)
@@ -1238,6 +1258,7 @@ extern "C" int rt_sites_clone(rt_sites *src, rt_sites **out)
     s->block_sites = src->block_sites;
     s->jit_waves = src->jit_waves;
     s->jit_tiles = src->jit_tiles;
+    s->jit_quad = src->jit_quad;
     s->compact_states = src->compact_states;
     s->node_obs = src->node_obs;
     s->ops = src->ops;
@@ -1270,6 +1291,16 @@ extern "C" int64_t rt_sites_device_bytes(const rt_sites *s)
 extern "C" double rt_sites_jit_compile_seconds(const rt_sites *s)
 {
     return s ? s->jit_compile_s : 0.0;
+}
+
+// diagnostics (tools/trace_c3.py): a __device__ variable of the batch's compiled kernel
+extern "C" int rt_debug_jit_global(rt_sites *s, const char *name, void *dst, int64_t bytes)
+{
+    RT_REQUIRE(s && name && dst && bytes > 0, "bad arguments");
+    RT_REQUIRE(s->jit_fn, "the batch has no tree-specialised kernel");
+    RT_HIP(hipSetDevice(s->model->ctx->device));
+    RT_HIP(hipStreamSynchronize(s->model->ctx->stream));
+    return rt_jit_read_global(s->model->ctx, s->jit_fn, name, dst, (size_t)bytes);
 }
 
 extern "C" const char *rt_sites_kernel_name(const rt_sites *s)

@@ -122,6 +122,11 @@ struct rt_model {
     rt_op *d_ops = nullptr;
     double *d_P = nullptr;          // [nnodes][n][n] esd_transitions
     double *d_Pfrag = nullptr;      // MFMA A-fragment order (n > 4)
+    // 4 < n <= 32: the same matrices as 4 x 4 blocks [step][row quad][col quad][k][i] =
+    // P[4 rq + i][4 kk + k], what the v_mfma_f64_4x4x4_4b kernels of jit.hip read (the
+    // four blocks of that instruction share A: 4 rows x 16 sites per instruction, so 20
+    // states cost 5 x 5 instructions of 16 cycles instead of 2 x 5 of 64)
+    double *d_Pquad = nullptr;
     double *d_root = nullptr;       // [n] root weights (ones if unset)
     double *d_Q = nullptr;          // rate matrices of the last set_rates
     int64_t q_capacity = 0;
@@ -171,6 +176,7 @@ struct rt_sites {
     int block_sites = 64;           // lane family: sites per block (< 64 only with jit_fn)
     int jit_waves = 1;              // waves per workgroup of the tree-specialised kernel
     int jit_tiles = 1;              // MFMA family: site tiles per wave of that kernel
+    bool jit_quad = false;          // ... built on v_mfma_f64_4x4x4_4b (reads d_Pquad)
     int compact_states = 0;         // lane family + specialised kernel: the batch stays resident
                                     // as one byte per leaf: 1 = uint8 states, 2 = allowed-set masks
     double *d_scratch = nullptr;    // generic kernel message stack
@@ -194,7 +200,8 @@ struct rt_reduce_args {
 int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
                    const int32_t *d_qidx, const double *d_t, double *d_P,
                    int32_t *d_info, const int32_t *d_step_of_node, int frag_kind,
-                   double *d_Pfrag, const rt_reduce_args *fused_reduce = nullptr);
+                   double *d_Pfrag, const rt_reduce_args *fused_reduce = nullptr,
+                   double *d_Pquad = nullptr);
 // the pending reduction, handed to the next expm launch (-> true) ...
 bool rt_take_pending_reduce(rt_ctx *ctx, rt_reduce_args *out);
 // ... or launched on its own now (no-op when nothing is pending)
@@ -215,7 +222,8 @@ int rt_launch_prune(rt_model *m, rt_sites *s, bool defer_reduce = false);
 // jit.hip
 std::string rt_jit_lane_source(const std::vector<rt_op> &ops, int n, int K, int D, int LA,
                                int S, int WG, int compact = 0);
-std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int T, int D, int LA);
+std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int T, int D, int LA,
+                               bool quad = false);
 std::string rt_jit_mfma_split_source(const std::vector<rt_op> &ops, int n, int K, int T, int D,
                                      int LA);
 int rt_jit_get(rt_ctx *ctx, const std::string &src, void **fn, bool mfma = false,
@@ -227,6 +235,7 @@ void rt_jit_ref(const rt_ctx *ctx, void *fn, int delta);
 int rt_jit_verified(const rt_ctx *ctx, void *fn);
 void rt_jit_set_verified(const rt_ctx *ctx, void *fn, bool ok);
 void rt_jit_release(const rt_ctx *ctx);
+int rt_jit_read_global(const rt_ctx *ctx, void *fn, const char *name, void *dst, size_t bytes);
 int rt_launch_prune_jit(rt_model *m, rt_sites *s);
 int rt_sites_pack(rt_sites *s, int kind, const int64_t *obs_order,
                   const void *data);

@@ -146,7 +146,7 @@ expm_kernel(int n, const double *__restrict__ Q, const int *__restrict__ qidx,
             int *__restrict__ info,
             // fused repack (all optional): step of each node, layout, output
             const int *__restrict__ step_of_node, int frag_kind,
-            double *__restrict__ Pfrag, rt_reduce_args red)
+            double *__restrict__ Pfrag, double *__restrict__ Pquad, rt_reduce_args red)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (red.partial && blockIdx.x == gridDim.x - 1) {      // the carried reduction
@@ -183,6 +183,8 @@ expm_kernel(int n, const double *__restrict__ Q, const int *__restrict__ qidx,
         if (step >= 0 && frag_kind == 1) {
             const int total = NT * ((KS + 1) / 2) * 128;
             for (int e = tid; e < total; e += TPB) Pfrag[(long)step * total + e] = 0.0;
+            if (Pquad)
+                for (int e = tid; e < KS * KS * 16; e += TPB) Pquad[(long)step * KS * KS * 16 + e] = 0.0;
         }
         return;
     }
@@ -446,6 +448,15 @@ expm_kernel(int n, const double *__restrict__ Q, const int *__restrict__ qidx,
             const int col = 4 * (2 * q + e2) + (ln >> 4);
             Pfrag[(long)step * total + e] = (row < n && col < n) ? Xb[row * ld + col] : 0.0;
         }
+        if (Pquad) {
+            // Pquad[step][rq][kk][k][i] = P[4 rq + i][4 kk + k]
+            const int tq = KS * KS * 16;
+            for (int e = tid; e < tq; e += TPB) {
+                const int i = e & 3, k = (e >> 2) & 3, blk = e >> 4;
+                const int row = 4 * (blk / KS) + i, col = 4 * (blk % KS) + k;
+                Pquad[(long)step * tq + e] = (row < n && col < n) ? Xb[row * ld + col] : 0.0;
+            }
+        }
     }
 }
 
@@ -574,8 +585,8 @@ __global__ void __launch_bounds__(TPB)
 expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ qidx,
                    const double *__restrict__ tt, double *__restrict__ P,
                    int *__restrict__ info, const int *__restrict__ step_of_node,
-                   int frag_kind, double *__restrict__ Pfrag, double *__restrict__ scratch,
-                   rt_reduce_args red)
+                   int frag_kind, double *__restrict__ Pfrag, double *__restrict__ Pquad,
+                   double *__restrict__ scratch, rt_reduce_args red)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (red.partial && blockIdx.x == gridDim.x - 1) {      // the carried reduction
@@ -607,6 +618,9 @@ expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ 
         if (step >= 0 && frag_kind == 1) {
             const int total = NTn * ((KSn + 1) / 2) * 128;
             for (int e = tid; e < total; e += TPB) Pfrag[(long)step * total + e] = 0.0;
+            if (Pquad)
+                for (int e = tid; e < KSn * KSn * 16; e += TPB)
+                    Pquad[(long)step * KSn * KSn * 16 + e] = 0.0;
         }
         return;
     }
@@ -712,6 +726,15 @@ expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ 
             const int row = 16 * mm + (ln & 15);
             const int col = 4 * (2 * qq + e2) + (ln >> 4);
             Pfrag[(long)step * total + e] = (col < RN) ? Xb[row * LD + col] : 0.0;
+        }
+        if (Pquad) {
+            // Pquad[step][rq][kk][k][i] = P[4 rq + i][4 kk + k] (the padding is zero)
+            const int tq = KSn * KSn * 16;
+            for (int e = tid; e < tq; e += TPB) {
+                const int i = e & 3, k = (e >> 2) & 3, blk = e >> 4;
+                const int row = 4 * (blk / KSn) + i, col = 4 * (blk % KSn) + k;
+                Pquad[(long)step * tq + e] = Xb[row * LD + col];
+            }
         }
     }
 }
@@ -916,7 +939,7 @@ expm_small_kernel(int count, const double *__restrict__ Q, const int *__restrict
 int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
                    const int32_t *d_qidx, const double *d_t, double *d_P,
                    int32_t *d_info, const int32_t *d_step_of_node, int frag_kind,
-                   double *d_Pfrag, const rt_reduce_args *fused_reduce)
+                   double *d_Pfrag, const rt_reduce_args *fused_reduce, double *d_Pquad)
 {
     // one extra workgroup when the launch carries the pending reduction of a batch
     const rt_reduce_args red = fused_reduce ? *fused_reduce : rt_reduce_args();
@@ -990,7 +1013,7 @@ int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
             }                                                                                   \
             RT_LAUNCH_TIMED(ctx, (expm_taylor_kernel<NTV, GL>), dim3((unsigned)count + extra),  \
                             dim3(TPB), lds_t, (int)n, d_Q, d_qidx, d_t, d_P, d_info,            \
-                            d_step_of_node, frag_kind, d_Pfrag, scratch, red);                  \
+                            d_step_of_node, frag_kind, d_Pfrag, d_Pquad, scratch, red);         \
         } while (0)
         switch (nt) {
         case 1: RT_TAYLOR(1, false); break;
@@ -1011,7 +1034,7 @@ int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
     rt_time_begin(ctx, RT_K_EXPM, "expm_mfma_regsolve", &ev);
     RT_LAUNCH_TIMED(ctx, expm_kernel, dim3((unsigned)count + extra), dim3(TPB), lds,
                        (int)n, d_Q, d_qidx, d_t, d_P, d_info, d_step_of_node, frag_kind,
-                       d_Pfrag, red);
+                       d_Pfrag, d_Pquad, red);
     RT_HIP(hipGetLastError());
     rt_time_end(ctx, RT_K_EXPM, ev);
     return RT_OK;

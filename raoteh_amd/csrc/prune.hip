@@ -1068,6 +1068,23 @@ __global__ void pack_p_mfma_kernel(const double *__restrict__ P,
     }
 }
 
+// quad blocks: Pquad[i][rq][kk][k][r] = P[node_i][4 rq + r][4 kk + k]
+__global__ void pack_p_quad_kernel(const double *__restrict__ P,
+                                   const rt_op *__restrict__ ops, int nops, int n, int KS,
+                                   double *__restrict__ Pquad)
+{
+    const int i = blockIdx.x;
+    const rt_op op = ops[i];
+    const int total = KS * KS * 16;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int r = e & 3, k = (e >> 2) & 3, blk = e >> 4;
+        const int row = 4 * (blk / KS) + r, col = 4 * (blk % KS) + k;
+        double v = 0.0;
+        if (op.dst >= 0 && row < n && col < n) v = P[(long)op.node * n * n + row * n + col];
+        Pquad[(long)i * total + e] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // site packing: user data -> kernel-native HBM layout
 // ---------------------------------------------------------------------------
@@ -1198,6 +1215,9 @@ int rt_launch_pfrag(rt_model *m)
     } else {
         hipLaunchKernelGGL(pack_p_mfma_kernel, dim3(nops), dim3(256), 0, st, m->d_P,
                            m->d_ops, nops, n, nt_of(n), (ks_of(n) + 1) / 2, m->d_Pfrag);
+        if (m->d_Pquad)
+            hipLaunchKernelGGL(pack_p_quad_kernel, dim3(nops), dim3(256), 0, st, m->d_P,
+                               m->d_ops, nops, n, ks_of(n), m->d_Pquad);
     }
     RT_HIP(hipGetLastError());
     m->frag_dirty = false;
@@ -1513,8 +1533,8 @@ int rt_launch_prune(rt_model *m, rt_sites *s, bool defer_reduce)
                      s->jit_prefetch, s->compact_states == 1 ? ",states"
                                       : s->compact_states == 2 ? ",masks" : "");
         else
-            snprintf(jit_name, sizeof(s->kernel_name), "prune_tree_jit_mfma<%d,T%d>", (int)m->n,
-                     s->jit_tiles);
+            snprintf(jit_name, sizeof(s->kernel_name), "prune_tree_jit_mfma%s<%d,T%d>",
+                     s->jit_quad ? "4x4" : "", (int)m->n, s->jit_tiles);
         name = jit_name;
     } else if (s->layout == RT_LAYOUT_LANE) {
         switch ((int)m->n) {

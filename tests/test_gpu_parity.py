@@ -83,6 +83,40 @@ def test_expm_against_own_algorithm_restated(ra):
                                        rtol=1e-8, atol=1e-13)
 
 
+def test_expm_orders_above_64_through_global_scratch(ra):
+    # 64 < n <= 128: the four matrices of the Taylor kernel live in an L2-resident slice of
+    # global scratch per workgroup (the Frechet blocks of the 61-state codon model have
+    # order 122); same algorithm, checked against scipy and the restated algorithm
+    rng = np.random.RandomState(17)
+    for n in (65, 80, 97, 122, 128):
+        Q = rng.exponential(size=(3, n, n)) * (rng.uniform(size=(3, n, n)) < 0.2)
+        for q in Q:
+            np.fill_diagonal(q, 0)
+            q -= np.diag(q.sum(axis=1))
+            q /= np.abs(np.diag(q)).max()
+        t = np.array([0.003, 0.4, 7.0])
+        P, info = ra.ctx.expm(Q, t, return_info=True)
+        for k in range(3):
+            want = orc.custom_expm(Q[k], t[k])
+            np.testing.assert_allclose(P[k], want, rtol=1e-9, atol=1e-13)
+            np.testing.assert_allclose(P[k], orc.expm_taylor(Q[k], t[k]), rtol=1e-9, atol=1e-13)
+            assert np.abs(P[k].sum(axis=1) - 1).max() < 1e-12
+            assert tuple(info[k]) == orc.taylor_order_and_squarings(
+                np.abs(Q[k] * t[k]).sum(axis=0).max())
+    # a block-triangular matrix of order 122 gives the Frechet derivative in its corner
+    n = 61
+    Qc, _ = ra.synth.mg94()
+    E = rng.uniform(size=(n, n))
+    B = np.zeros((2 * n, 2 * n))
+    B[:n, :n] = B[n:, n:] = 0.1 * Qc
+    B[:n, n:] = E
+    got = ra.ctx.expm(B, [1.0])[0]
+    import scipy.linalg
+    want_P, want_L = scipy.linalg.expm_frechet(0.1 * Qc, E)
+    np.testing.assert_allclose(got[:n, :n], want_P, rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(got[:n, n:], want_L, rtol=1e-10, atol=1e-13)
+
+
 def test_expm_shared_q_and_errors(ra):
     Q, _ = ra.synth.hky85()
     t = np.linspace(0.01, 2.0, 50)
@@ -97,7 +131,7 @@ def test_expm_shared_q_and_errors(ra):
     with pytest.raises(ValueError):
         ra.mjp.custom_expm(None, 1.0)
     with pytest.raises(Exception):
-        ra.ctx.expm(np.zeros((63, 63)), [1.0])     # > RT_MAX_EXPM_STATES
+        ra.ctx.expm(np.zeros((129, 129)), [1.0])   # > RT_MAX_EXPM_STATES
     out = np.empty((3, 3))
     Q3 = np.array([[-1., 1, 0], [2, -5, 3], [0, 0, 0]])
     ra.pyf.get_tolerance_rate_matrix(0.7, Q3, out)
@@ -1304,3 +1338,113 @@ def test_compact_state_batches_match_dense(ra, n):
         ok = wst == 0
         if ok.any():
             np.testing.assert_allclose(outm['mask'][0][:64][ok], want[ok], rtol=RTOL_LL)
+
+
+# ---------------------------------------------------------------------------
+# Rao-Teh sweep core: ragged batches of trees with one shared matrix (csrc/forest.hip)
+# ---------------------------------------------------------------------------
+
+def _forest_cases():
+    fx = load_golden('forest')
+    out = []
+    for c in fx['cases']:
+        T = nx.Graph()
+        T.add_nodes_from(c['chunk_nodes'])
+        T.add_edges_from((a, b) for a, b in c['chunk_edges'])
+        out.append((c, T))
+    return out
+
+
+def test_forest_passes_match_the_reference(ra):
+    """pset / set / pmap of every chunk tree of the fixture in ONE ragged batch against
+    the reference's un-accelerated functions with P_default = the uniformized matrix
+    (tests/golden/forest.json, tools/gen_golden.py fixture_forest)."""
+    from raoteh_amd import _forest
+    cases = _forest_cases()
+    # each fixture case has its own P: a batch per case = its tree with its observations
+    # plus up to three other trees of the same state count without observations, so that
+    # the batch is ragged
+    for c, T in cases:
+        n = c['nstates']
+        P = np.array(c['P'])
+        allowed = dict((int(v), set(ss)) for v, ss in c['allowed'].items())
+        other = [(T2, c2) for c2, T2 in cases if c2['nstates'] == n][:3]
+        trees = [(T, c['root'])] + [(T2, c2['root']) for T2, c2 in other]
+        obs = [allowed] + [None] * len(other)
+        forest = _forest.Forest(trees)
+        sets, pmaps = _forest.get_node_to_set_and_pmap(forest, P, obs)
+        for v in T:
+            assert sets[0][v] == set(c['set'][str(v)]), (v, sets[0][v], c['set'][str(v)])
+            np.testing.assert_allclose(pmaps[0][v], c['pmap'][str(v)], rtol=1e-12, atol=0)
+        # unrestricted trees: every state everywhere, pmap = 1 (P is stochastic)
+        for k in range(1, len(trees)):
+            for v in trees[k][0]:
+                assert sets[k][v] == set(range(n))
+                np.testing.assert_allclose(pmaps[k][v], 1.0, rtol=1e-12)
+
+
+def test_forest_sampling_follows_the_exact_posterior(ra):
+    """Sampled states against the exact posterior node marginals of the reference
+    (_mc0.get_node_to_distn): many sweeps of the same forest, frequencies within
+    sampling error; zero-likelihood trees are flagged, not sampled; draws are
+    reproducible and independent of the position of a tree in the batch."""
+    from raoteh_amd import _forest
+    cases = _forest_cases()
+    reps = 4000
+    for c, T in cases[:12]:
+        n = c['nstates']
+        P = np.array(c['P'])
+        allowed = dict((int(v), set(ss)) for v, ss in c['allowed'].items())
+        distn = np.array(c['root_distn'])
+        forest = _forest.Forest([(T, c['root'])] * reps)
+        obs = [allowed] * reps
+        states, status = _forest.resample_states(forest, P, obs, root_distn=distn,
+                                                 seed=99, sweep=3, return_status=True)
+        if c['zero']:
+            assert (status == 1).all()
+            assert all(s == -1 for d in states for s in d.values())
+            with pytest.raises(ra.pkg.StructuralZeroProb):
+                _forest.resample_states(forest, P, obs, root_distn=distn, seed=99, sweep=3)
+            continue
+        assert not status.any()
+        for v in T:
+            want = np.array(c['distn'][str(v)])
+            got = np.bincount([d[v] for d in states], minlength=n) / float(reps)
+            # never a state outside the posterior support; frequencies within 5 sigma
+            assert not got[want == 0].any(), (v, got, want)
+            sigma = np.sqrt(np.maximum(want * (1 - want), 1e-12) / reps)
+            assert np.all(np.abs(got - want) <= 5 * sigma + 1e-9), (v, got, want)
+        # every parent -> child pair drawn is a transition P allows
+        for d in states[:200]:
+            for a, b in nx.bfs_edges(T, c['root']):
+                assert P[d[a], d[b]] > 0
+        # same (seed, sweep) -> same draws; another sweep -> other draws
+        again, _ = _forest.resample_states(forest, P, obs, root_distn=distn, seed=99, sweep=3,
+                                           return_status=True)
+        assert again == states
+        other, _ = _forest.resample_states(forest, P, obs, root_distn=distn, seed=99, sweep=4,
+                                           return_status=True)
+        if len(T) > 1 or n > 1:
+            assert other != states
+
+
+def test_forest_rejects_bad_layouts(ra):
+    from raoteh_amd import _forest
+    T = nx.path_graph(4)
+    forest = _forest.Forest([(T, 0), (T, 2)])
+    assert forest.node_offset.tolist() == [0, 4, 8] and forest.total == 8
+    P = np.full((3, 3), 1.0 / 3)
+    with pytest.raises(ValueError):
+        _forest.get_node_to_set_and_pmap(forest, np.ones((3, 4)))
+    with pytest.raises(ValueError):
+        _forest.Forest([(T, 17)])
+    with pytest.raises(ValueError):
+        _forest.resample_states(forest, P, [{0: {5}}, None])
+    # a corrupted CSR is caught by the library, not run
+    bad = _forest.Forest([(T, 0)])
+    bad.indices = np.array([0, 2, 3], dtype=np.int64)
+    with pytest.raises(ValueError):
+        _forest.get_node_to_set_and_pmap(bad, P)
+    sets, pmaps = _forest.get_node_to_set_and_pmap(forest, P, [{3: {1}}, {0: {0, 2}}])
+    assert sets[0][3] == {1} and sets[1][0] == {0, 2}
+    np.testing.assert_allclose(pmaps[0][0], 1.0 / 3, rtol=1e-13)

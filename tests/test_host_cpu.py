@@ -295,3 +295,45 @@ def test_observed_states_are_range_checked_not_wrapped():
         _as_uint8_states(np.array([[0.0]]), 4)
     with pytest.raises(ValueError):
         _as_uint8_states(np.array([[0]]), 300)
+
+
+def test_forest_container_and_uniformization():
+    # host side of the Rao-Teh sweep core: the concatenated CSR layout rt_forest_* take
+    # and the uniformized matrix (reference _sample_mjp_dense.py:72-114)
+    from raoteh_amd._forest import Forest
+    from raoteh_amd._sample_mjp_dense import get_uniformized_transition_matrix
+    T0 = nx.Graph([(5, 7), (5, 9), (9, 2)])
+    T1 = nx.Graph()
+    T1.add_node(4)
+    T2 = nx.path_graph(3)
+    f = Forest([(T0, 5), (T1, 4), (T2, 1)])
+    assert f.ntrees == 3 and f.total == 8
+    assert f.node_offset.tolist() == [0, 4, 5, 8]
+    assert f.preorder[0][0] == 5 and f.preorder[1] == [4] and f.preorder[2][0] == 1
+    # tree k's indptr block starts at off[k] + k, its indices block at off[k] - k
+    assert f.indptr.shape == (8 + 3,) and f.indices.shape == (8 - 3,)
+    for k in range(3):
+        lo, nn = int(f.node_offset[k]), len(f.preorder[k])
+        ptr = f.indptr[lo + k:lo + k + nn + 1]
+        assert ptr[0] == 0 and ptr[-1] == nn - 1
+        idx = f.indices[lo - k:lo - k + nn - 1]
+        assert sorted(idx.tolist()) == list(range(1, nn))
+    m = f.allowed_masks([{5: {0, 2}, 2: {1}}, None, {0: {3}}], 4)
+    assert m.dtype == np.uint64 and m[0] == 0b0101 and m[4] == 0b1111
+    assert m[int(f.node_offset[0]) + f.preorder[0].index(2)] == 0b0010
+    assert m[int(f.node_offset[2]) + f.preorder[2].index(0)] == 0b1000
+    with pytest.raises(ValueError):
+        f.allowed_masks([{5: {4}}, None, None], 4)
+    with pytest.raises(ValueError):
+        Forest([])
+    Q = np.array([[-1., 1, 0], [2, -5, 3], [0, 0.5, -0.5]])
+    P = get_uniformized_transition_matrix(Q)
+    np.testing.assert_allclose(P, np.eye(3) + Q / 10.0)
+    np.testing.assert_allclose(get_uniformized_transition_matrix(Q, uniformization_factor=3),
+                               np.eye(3) + Q / 15.0)
+    np.testing.assert_allclose(get_uniformized_transition_matrix(Q, omega=7.0),
+                               np.eye(3) + Q / 7.0)
+    with pytest.raises(ValueError):
+        get_uniformized_transition_matrix(Q, uniformization_factor=2, omega=7.0)
+    with pytest.raises(ValueError):
+        get_uniformized_transition_matrix(np.zeros((2, 3)))

@@ -228,9 +228,9 @@ def test_expm_taylor_matches_scipy_fixture():
         np.testing.assert_allclose(got, want, rtol=1e-10,
                                    atol=1e-14 * max(1.0, np.abs(want).max()),
                                    err_msg='%s t=%g' % (r['form'], r['t']))
-    for nrm, want in ((0.0, (4, 0)), (3e-4, (4, 0)), (0.04, (8, 0)), (0.29, (12, 0)),
-                      (0.78, (16, 0)), (0.79, (16, 1)), (1.5, (16, 1)), (1.6, (16, 2)),
-                      (100.0, (16, 8))):
+    for nrm, want in ((0.0, (3, 0)), (1e-5, (3, 0)), (9e-3, (6, 0)), (0.08, (9, 0)),
+                      (0.29, (12, 0)), (0.64, (15, 0)), (0.65, (15, 1)), (1.28, (15, 1)),
+                      (1.29, (15, 2)), (100.0, (15, 8))):
         assert orc.taylor_order_and_squarings(nrm) == want
 
 

@@ -22,6 +22,8 @@ Reference functions exercised:
   _linalg.sparse_expm_naive                    raoteh/sampler/_linalg.py:72-90
   _conditional_expectation.get_jukes_cantor_*  raoteh/sampler/_conditional_expectation.py:15-33
   examples/code2x3/run.py do_blinking_process  :329-475 (builder of the config-5 model)
+  _graph_transform.get_chunk_tree_type_b       raoteh/sampler/_graph_transform.py:298-375
+  _mc0.get_node_to_distn                       raoteh/sampler/_mc0.py:382-462
 expm per edge is ``scipy.linalg.expm(Q*t)`` exactly as ``_mjp_dense.py:24-25``.
 
 usage: python tools/gen_golden.py [--out tests/golden]
@@ -790,6 +792,91 @@ def fixture_blinking(mods):
                 rows=rows)
 
 
+def fixture_forest(mods, ncases=24):
+    """The Rao-Teh sweep core on a ragged batch of trees with ONE shared matrix: for
+    random trees with random event nodes the reference's chunk tree
+    (_graph_transform.get_chunk_tree_type_b, :298-375), a uniformized P = I + Q / omega
+    of a random sparse rate matrix (_sample_mjp_dense.py:107-110 restated: the module
+    itself imports pyfelscore-bound code), allowed-state sets on some chunk nodes, and
+    the reference's outputs for P_default = that P on every edge: pset
+    (_mcy.unaccelerated_get_node_to_pset), set (_mc0.get_node_to_set_unaccelerated),
+    pmap (_mcy.unaccelerated_get_node_to_pmap) and, where the likelihood is positive,
+    the exact posterior node marginals (_mc0.get_node_to_distn) the sampled states of
+    _sample_mc0.resample_states must follow."""
+    _mc0, _mcy, _util = mods['_mc0'], mods['_mcy'], mods['_util']
+    _gt = importlib.import_module('raoteh.sampler._graph_transform')
+    rng = np.random.RandomState(4321)
+    cases = []
+    for case in range(ncases):
+        n = int(rng.choice([2, 3, 4, 6, 9]))
+        # sparse rate matrix with a connected support (a cycle) plus random extras
+        Q = np.zeros((n, n))
+        for i in range(n):
+            Q[i, (i + 1) % n] = rng.exponential() + 0.1
+        extra = rng.uniform(size=(n, n)) < 0.25
+        Q += extra * rng.exponential(size=(n, n))
+        np.fill_diagonal(Q, 0.0)
+        Q -= np.diag(Q.sum(axis=1))
+        omega = 2.0 * (-np.diag(Q)).max()
+        P = np.identity(n) + Q / omega
+        P_nx = dense_to_nx(P)
+        # a random tree, some of whose degree-2-ish nodes are events -> its chunk tree
+        nnodes = int(rng.randint(3, 26))
+        T = nx.Graph()
+        T.add_node(0)
+        for k in range(1, nnodes):
+            T.add_edge(int(rng.randint(k)), k)
+        events = set(int(v) for v in range(1, nnodes) if rng.uniform() < 0.6)
+        chunk_tree, edge_to_chunk, event_to_edge = _gt.get_chunk_tree_type_b(T, 0, events)
+        root = 0
+        nodes = list(chunk_tree)
+        allowed = dict((v, set(range(n))) for v in nodes)
+        for v in nodes:
+            u = rng.uniform()
+            if u < 0.3:
+                allowed[v] = {int(rng.randint(n))}
+            elif u < 0.5:
+                allowed[v] = set(int(x) for x in rng.choice(n, size=max(1, n // 2),
+                                                             replace=False))
+        w = rng.exponential(size=n)
+        if rng.uniform() < 0.3:
+            w[rng.randint(n)] = 0.0
+        distn = w / w.sum()
+        distn_dict = dict((i, float(p)) for i, p in enumerate(distn) if p)
+        rec = dict(nstates=n, P=P.tolist(), Q=Q.tolist(), omega=float(omega),
+                   tree_edges=[[int(a), int(b)] for a, b in T.edges()],
+                   event_nodes=sorted(events),
+                   chunk_nodes=[int(v) for v in nodes],
+                   chunk_edges=[[int(a), int(b)] for a, b in nx.bfs_edges(chunk_tree, root)]
+                   if len(nodes) > 1 else [],
+                   root=root, allowed=set_json(allowed), root_distn=distn.tolist())
+        if len(nodes) == 1:
+            # a single chunk: the reference's passes need at least one edge
+            rec['single'] = True
+            cases.append(rec)
+            continue
+        pset = _mcy.unaccelerated_get_node_to_pset(
+            chunk_tree, root, node_to_allowed_states=allowed, P_default=P_nx)
+        nset = _mc0.get_node_to_set_unaccelerated(chunk_tree, root, pset, P_default=P_nx)
+        pmap = _mcy.unaccelerated_get_node_to_pmap(
+            chunk_tree, root, node_to_allowed_states=allowed, node_to_set=nset,
+            P_default=P_nx)
+        rec['pset'] = set_json(pset)
+        rec['set'] = set_json(nset)
+        rec['pmap'] = pmap_json(pmap, n)
+        try:
+            rec['likelihood'] = _mc0.get_likelihood(pmap[root], root_distn=distn_dict)
+            rec['zero'] = False
+            nd = _mc0.get_node_to_distn(chunk_tree, root, pmap, root_distn=distn_dict,
+                                        P_default=P_nx)
+            rec['distn'] = pmap_json(nd, n)
+        except _util.StructuralZeroProb:
+            rec['likelihood'] = 0.0
+            rec['zero'] = True
+        cases.append(rec)
+    return dict(cases=cases)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(os.path.dirname(HERE),
@@ -818,6 +905,7 @@ def main():
         config_c3=lambda: fixture_config(mods, 'c3', 2),
         config_c5=lambda: fixture_config(mods, 'c5', 4),
         blinking=lambda: fixture_blinking(mods),
+        forest=lambda: fixture_forest(mods),
     )
     only = args.only.split(',') if args.only else list(makers)
     fixtures = dict((name, makers[name]()) for name in only)
