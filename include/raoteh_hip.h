@@ -189,6 +189,18 @@ int rt_mjp_esd_expectation_weights_obs(rt_ctx *ctx, int64_t nnodes, int64_t n,
             const void *data, const double *site_weights, double *edge_weights,
             int32_t *status);
 
+/* The rest of _mjp_dense.get_expected_history_statistics (:476-533) on the device: from
+ * the per-edge weights W_e (edge_weights above, one slice per edge: f64[nedges][n][n]),
+ * the rate matrix Q[q_index[e]] and branch length t[e] of every edge,
+ *   M_e = L(t_e Q_e^T, W_e)  (Frechet derivative of expm: the corner of the exponential
+ *   of the 2n x 2n block [[t Q^T, W], [0, t Q^T]], all edges in one expm launch),
+ *   dwell[c] = sum_e t_e M_e[c][c],   trans[c][d] = sum_e t_e Q_e[c][d] M_e[c][d]
+ * -- what the reference gets from n + nnz(Q) scipy.linalg.expm_frechet calls per edge
+ * and site.  2n <= RT_MAX_EXPM_STATES (n <= 64: the 61-state codon model included).   */
+int rt_mjp_frechet_statistics(rt_ctx *ctx, int64_t n, int64_t nedges, const double *Q,
+            int64_t nq, const int64_t *q_index, const double *t, const double *W,
+            double *dwell, double *trans);
+
 /* ---- 2. batched, device-resident hot path --------------------------------
  * _mjp_dense.get_likelihood (_mjp_dense.py:362-407) for many sites:
  *   rt_model_create        tree (same CSR as above) -> device, schedule built

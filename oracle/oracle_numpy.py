@@ -547,6 +547,41 @@ def mjp_dense_get_expected_history_statistics(T, node_to_allowed_states, root, n
     return dwell, distn[0], trans
 
 
+def mjp_dense_expected_history_statistics_entries(T, node_to_allowed_states, root, nstates,
+                                                  pairs, root_distn=None, Q_default=None):
+    """The same numbers as mjp_dense_get_expected_history_statistics, for the listed
+    (c, d) entries only: {(c, c): expected dwell time in c, (c, d): expected number of
+    c -> d transitions}.  One expm_frechet call per listed direction and edge, exactly
+    the reference's arithmetic (_mjp_dense.py:483-533) -- a 61-state codon model has
+    ~590 directions per edge, too many to enumerate in a test; a sample of them is not."""
+    n = nstates
+    preorder_nodes, indices, indptr, esd = get_expm_augmented_transitions(
+        T, root, n, Q_default=Q_default)
+    mask = define_state_mask(node_to_allowed_states, preorder_nodes, n)
+    _, pmap = esd_get_node_to_pmap(indices, indptr, esd, mask)
+    distn = mc0_esd_get_node_to_distn(indices, indptr, esd, root_distn, pmap)
+    J = mc0_esd_get_joint_endpoint_distn(indices, indptr, esd, pmap, distn)
+    index = dict((v, i) for i, v in enumerate(preorder_nodes))
+    out = dict(((int(c), int(d)), 0.0) for c, d in pairs)
+    for na, nb in nx.bfs_edges(T, root):
+        edge = T[na][nb]
+        Q = np.asarray(edge.get('Q', Q_default), dtype=float)
+        t = edge['weight']
+        Pe, Je = esd[index[nb]], J[index[nb]]
+        live = Je != 0
+        ratio = np.zeros((n, n))
+        ratio[live] = Je[live] / Pe[live]
+        for c, d in out:
+            if c != d and not Q[c, d]:
+                continue
+            C = np.zeros((n, n))
+            C[c, d] = 1.0
+            interact = scipy.linalg.expm_frechet(t * Q, t * C, compute_expm=False)
+            total = float(np.sum(ratio[live] * interact[live]))
+            out[c, d] += total if c == d else Q[c, d] * total
+    return out, distn[0]
+
+
 # ---------------------------------------------------------------------------
 # batched forms (vectorised over sites) used by the parity tests and the
 # "amortised" CPU baseline

@@ -85,6 +85,8 @@ SIGNATURES = {
                                                    _p_i64, _p_i64, _p_f64, _p_f64, c_int64,
                                                    _p_i64, c_int, c_void_p, _p_f64, _p_f64,
                                                    _p_i32]),
+    'rt_mjp_frechet_statistics': (c_int, [c_void_p, c_int64, c_int64, _p_f64, c_int64, _p_i64,
+                                          _p_f64, _p_f64, _p_f64, _p_f64]),
     'rt_model_create': (c_int, [c_void_p, c_int64, c_int64, _p_i64, _p_i64,
                                 POINTER(c_void_p)]),
     'rt_model_destroy': (c_int, [c_void_p]),

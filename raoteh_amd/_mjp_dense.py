@@ -154,42 +154,33 @@ def get_total_log_likelihood(T, root, nstates, obs_nodes, data, kind='dense',
 # (csrc/expm.hip), W scaled to unit size first so that it does not drive the
 # scaling-and-squaring of the block.
 
-def _frechet_contractions(ctx, Qs, ts, Ws):
-    """M[e] = L(ts[e] * Qs[e]^T, Ws[e]) for every edge, on the device."""
-    E, n = Ws.shape[0], Ws.shape[1]
-    if 2 * n > 62:                      # RT_MAX_EXPM_STATES
-        raise ValueError('expected history statistics need the expm kernel at order 2n = '
-                         '%d; it covers order <= 62' % (2 * n))
-    scale = np.abs(Ws).reshape(E, -1).max(axis=1)
-    scale[scale == 0] = 1.0
-    blocks = np.zeros((E, 2 * n, 2 * n), dtype=np.float64)
-    for e in range(E):
-        A = ts[e] * Qs[e].T
-        blocks[e, :n, :n] = A
-        blocks[e, n:, n:] = A
-        blocks[e, :n, n:] = Ws[e] / scale[e]
-    out = ctx.expm(blocks, np.ones(E))
-    return out[:, :n, n:] * scale[:, None, None]
-
-
 def _edge_rates(T, root, Q_default):
+    """BFS edges of the tree, the distinct rate matrices on them and, per edge, which
+    one it carries and its branch length."""
     edges = list(nx.bfs_edges(T, root))
-    Qs, ts = [], []
+    mats, index_of, q_index, ts = [], {}, [], []
     for na, nb in edges:
         Q = T[na][nb].get('Q', Q_default)
         check_square_dense(Q)
-        Qs.append(np.asarray(Q, dtype=np.float64))
+        key = id(Q)
+        if key not in index_of:
+            index_of[key] = len(mats)
+            mats.append(np.asarray(Q, dtype=np.float64))
+        q_index.append(index_of[key])
         ts.append(float(T[na][nb]['weight']))
-    return edges, Qs, np.array(ts)
+    return edges, mats, np.array(q_index, dtype=np.int64), np.array(ts)
 
 
-def _accumulate(nstates, Qs, ts, M):
-    dwell = np.zeros(nstates)
-    trans = np.zeros((nstates, nstates))
-    for e, Q in enumerate(Qs):
-        dwell += ts[e] * np.diag(M[e])
-        trans += np.where(Q != 0, ts[e] * Q * M[e], 0.0)
-    return dwell, trans
+def _history_statistics_from_weights(ctx, nstates, mats, q_index, ts, Ws):
+    """(dwell, trans) from the per-edge weights: block assembly, the Frechet block
+    exponentials and the contraction over the edges all run on the device
+    (rt_mjp_frechet_statistics); n <= 64, i.e. the 61-state codon model included."""
+    if not len(ts):
+        return np.zeros(nstates), np.zeros((nstates, nstates))
+    if 2 * nstates > 128:                   # RT_MAX_EXPM_STATES
+        raise ValueError('expected history statistics need the expm kernel at order 2n = '
+                         '%d; it covers order <= 128' % (2 * nstates))
+    return ctx.frechet_statistics(np.stack(mats), q_index, ts, Ws)
 
 
 def get_expected_history_statistics(T, node_to_allowed_states, root, nstates,
@@ -209,18 +200,16 @@ def get_expected_history_statistics(T, node_to_allowed_states, root, nstates,
         T_aug, root, node_to_pmap, nstates, root_distn=root_distn)
     T_joint = _mc0_dense.get_joint_endpoint_distn(
         T_aug, root, node_to_pmap, node_to_distn, nstates)
-    edges, Qs, ts = _edge_rates(T, root, Q_default)
+    edges, mats, q_index, ts = _edge_rates(T, root, Q_default)
     Ws = np.zeros((len(edges), nstates, nstates))
     for e, (na, nb) in enumerate(edges):
         J, P = T_joint[na][nb]['J'], T_aug[na][nb]['P']
         live = J != 0
         Ws[e][live] = J[live] / P[live]
-    dwell, trans = np.zeros(nstates), np.zeros((nstates, nstates))
-    if edges:
-        M = _frechet_contractions(get_context(), Qs, ts, Ws)
-        dwell, trans = _accumulate(nstates, Qs, ts, M)
+    dwell, trans = _history_statistics_from_weights(get_context(), nstates, mats, q_index,
+                                                    ts, Ws)
     expected_transitions = nx.DiGraph()
-    for Q in Qs:
+    for Q in mats:
         for c, d in zip(*np.nonzero(Q)):
             if not expected_transitions.has_edge(int(c), int(d)):
                 expected_transitions.add_edge(int(c), int(d), weight=float(trans[c, d]))
@@ -252,19 +241,28 @@ def get_expected_history_statistics_batch(T, root, nstates, sites=None, root_dis
     # upward passes, downward pass and the per-edge site sums of J / P in one call;
     # n*n numbers per edge come back, whatever the number of sites
     if sites is not None:
-        nsites = len(sites)
-        # a node missing from a site's dict is unrestricted there
-        mask = np.ones((nsites, ta.nnodes, nstates), dtype=np.int64)
-        for k, node_to_allowed_states in enumerate(sites):
-            for i, v in enumerate(ta.preorder_nodes):
-                if node_to_allowed_states is not None and v in node_to_allowed_states:
-                    allowed = node_to_allowed_states[v]
-                    mask[k, i] = [1 if s in allowed else 0 for s in range(nstates)]
-        W, root_post, status = ctx.expectation_weights(
-            ta.indices, ta.indptr, esd, root_distn, mask, site_weights=w)
+        # node -> allowed-set dicts become one 64-bit set per site and node that any
+        # site restricts (a node missing from a site's dict is unrestricted there); the
+        # reference-format mask array is built on the device
+        if nstates > 64:
+            raise ValueError('allowed-state sets hold at most 64 states')
+        obs_nodes = [v for v in ta.preorder_nodes
+                     if any(d is not None and v in d for d in sites)]
+        full = np.uint64((1 << nstates) - 1) if nstates < 64 else np.uint64(2 ** 64 - 1)
+        data = np.full((len(sites), len(obs_nodes)), full, dtype=np.uint64)
+        memo = {}
+        for k, d in enumerate(sites):
+            if d is None:
+                continue
+            for j, v in enumerate(obs_nodes):
+                if v in d:
+                    key = frozenset(d[v])
+                    m = memo.get(key)
+                    if m is None:
+                        m = memo[key] = np.uint64(sum(1 << int(s) for s in key))
+                    data[k, j] = m
+        kind = 'mask'
     else:
-        # compact observations: one byte / one 64-bit set per site and observed node;
-        # the reference-format mask array is built on the device
         data = np.asarray(data)
         if data.ndim != 2 or data.shape[1] != len(obs_nodes):
             raise ValueError('data must be [nsites, len(obs_nodes)]')
@@ -272,19 +270,21 @@ def get_expected_history_statistics_batch(T, root, nstates, sites=None, root_dis
             data = np.where((data < 0) | (data >= min(nstates, 255)), 255, data).astype(np.uint8)
             if nstates > 255:
                 raise ValueError("kind='state' holds at most 255 states")
-        cols = [ta.node_to_index[v] for v in obs_nodes]
-        W, root_post, status = ctx.expectation_weights_obs(
-            ta.indices, ta.indptr, esd, root_distn, cols, data, kind, site_weights=w)
+    # compact observations: one byte / one 64-bit set per site and observed node
+    cols = [ta.node_to_index[v] for v in obs_nodes]
+    if len(cols) == 0:                       # nothing observed anywhere
+        cols = [0]
+        data = (np.full((data.shape[0], 1), 255, dtype=np.uint8) if kind == 'state' else
+                np.full((data.shape[0], 1), 2 ** 64 - 1 if nstates == 64 else (1 << nstates) - 1,
+                        dtype=np.uint64))
+    W, root_post, status = ctx.expectation_weights_obs(
+        ta.indices, ta.indptr, esd, root_distn, cols, data, kind, site_weights=w)
     if status.any():
         from ._util import NumericalZeroProb
         raise NumericalZeroProb('the denominator is zero (site %d)'
                                 % int(np.nonzero(status)[0][0]))
-    edges, Qs, ts = _edge_rates(T, root, Q_default)
-    Ws = np.zeros((len(edges), nstates, nstates))
-    for e, (na, nb) in enumerate(edges):
-        Ws[e] = W[ta.node_to_index[nb]]
-    dwell, trans = np.zeros(nstates), np.zeros((nstates, nstates))
-    if edges:
-        M = _frechet_contractions(ctx, Qs, ts, Ws)
-        dwell, trans = _accumulate(nstates, Qs, ts, M)
+    edges, mats, q_index, ts = _edge_rates(T, root, Q_default)
+    Ws = W[[ta.node_to_index[nb] for _, nb in edges]] if edges else \
+        np.zeros((0, nstates, nstates))
+    dwell, trans = _history_statistics_from_weights(ctx, nstates, mats, q_index, ts, Ws)
     return dwell, root_post, trans

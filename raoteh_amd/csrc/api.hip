@@ -818,6 +818,14 @@ static int sites_alloc(rt_sites *s, bool generic)
 // How rt_sites_create picks the pruning kernel of a batch: the automatic policy, the
 // interpreter kernels only, or exactly the tree-specialised kernel of another batch
 // (the probe batches of verify_jit_kernel).
+// the split-M generator in use: pipelined unless RAOTEH_JIT_SPLIT=serial (A/B runs)
+static std::string split_source(const std::vector<rt_op> &ops, int n, int K, int T, int D, int LA)
+{
+    const char *v = getenv("RAOTEH_JIT_SPLIT");
+    if (v && strcmp(v, "serial") == 0) return rt_jit_mfma_split_source(ops, n, K, T, D, LA);
+    return rt_jit_mfma_split_pipelined_source(ops, n, K, T, D, LA);
+}
+
 struct jit_override {
     int mode = 0;             // 0 automatic, 1 interpreter only, 2 exactly these parameters
     int T = 1, S = 64, WG = 1, D = 1, LA = 1, compact = 0;
@@ -833,7 +841,7 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
         const bool split = mfma && (n > 32 || !s->mfma_solo);
         const std::string src =
             !mfma ? rt_jit_lane_source(s->ops, n, K, ov->D, ov->LA, ov->S, ov->WG, ov->compact)
-            : split ? rt_jit_mfma_split_source(s->ops, n, K, ov->T, ov->D, ov->LA)
+            : split ? split_source(s->ops, n, K, ov->T, ov->D, ov->LA)
                     : rt_jit_mfma_source(s->ops, n, K, ov->T, ov->D, ov->LA, ov->quad);
         RT_TRY(rt_jit_get(s->model->ctx, src, &s->jit_fn, mfma));
         s->jit_quad = mfma && !split && ov->quad;
@@ -879,7 +887,7 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
             int rc = RT_ERR_UNSUPPORTED;
             for (; T >= 1 && rc == RT_ERR_UNSUPPORTED; --T) {     // fewer tiles if it spills
                 const std::string src =
-                    rt_jit_mfma_split_source(s->ops, (int)s->model->n, (int)s->nobs, T, D, LA);
+                    split_source(s->ops, (int)s->model->n, (int)s->nobs, T, D, LA);
                 rc = rt_jit_get(s->model->ctx, src, &s->jit_fn, true, &s->jit_compile_s);
             }
             ++T;
@@ -1026,7 +1034,7 @@ extern "C" int rt_jit_source(int64_t nnodes, const int64_t *idx, const int64_t *
                              getenv("RAOTEH_JIT_SOURCE_STATES") != nullptr)
         : n <= 32 ? rt_jit_mfma_source(m.ops, (int)n, (int)nobs, T, (int)prefetch, 1,
                                        getenv("RAOTEH_JIT_QUAD") && atoi(getenv("RAOTEH_JIT_QUAD")) != 0)
-                  : rt_jit_mfma_split_source(m.ops, (int)n, (int)nobs, std::min(T, 3),
+                  : split_source(m.ops, (int)n, (int)nobs, std::min(T, 3),
                                              (int)prefetch, 1);
     RT_REQUIRE((int64_t)src.size() + 1 <= capacity, "buffer too small: %lld bytes needed",
                (long long)src.size() + 1);

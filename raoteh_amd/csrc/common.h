@@ -226,6 +226,8 @@ std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int 
                                bool quad = false);
 std::string rt_jit_mfma_split_source(const std::vector<rt_op> &ops, int n, int K, int T, int D,
                                      int LA);
+std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, int n, int K, int T,
+                                               int D, int LA);
 int rt_jit_get(rt_ctx *ctx, const std::string &src, void **fn, bool mfma = false,
                double *compile_s = nullptr);
 void rt_jit_ref(const rt_ctx *ctx, void *fn, int delta);

@@ -185,7 +185,7 @@ forest_sample_kernel(int n, long ntrees, const long *__restrict__ off,
             // zero likelihood: at the root the reference raises StructuralZeroProb /
             // NumericalZeroProb (_sample_mc0_dense.py:57-62); below the root it cannot
             // happen with a consistent L, and is reported the same way
-            st = v == lo ? 1 : 2;
+            if (st == 0) st = v == lo ? 1 : 2;     // the first failure names the cause
         }
         if (lane == 0) states[v] = pick;
         __threadfence();     // every lane reads the parent's state back

@@ -301,6 +301,29 @@ class Context(object):
         W[0] = 0.0
         return W, root_post, status
 
+    def frechet_statistics(self, Qs, q_index, t, W):
+        """rt_mjp_frechet_statistics: per edge e the Frechet derivative
+        M_e = L(t[e] Q[q_index[e]]^T, W[e]) on the device, contracted over the edges:
+        returns (dwell f64[n], trans f64[n, n])."""
+        Qs = _f64(Qs)
+        if Qs.ndim == 2:
+            Qs = Qs[None]
+        W = _f64(W)
+        t = np.atleast_1d(_f64(t))
+        nq, n = Qs.shape[0], Qs.shape[1]
+        nedges = t.shape[0]
+        if Qs.shape[1:] != (n, n) or W.shape != (nedges, n, n):
+            raise ValueError('expected Q [nq, n, n], W [nedges, n, n], t [nedges]')
+        qi = _i64(q_index)
+        if qi.shape != (nedges,):
+            raise ValueError('one rate-matrix index per edge expected')
+        dwell = np.zeros(n, dtype=np.float64)
+        trans = np.zeros((n, n), dtype=np.float64)
+        _lib.check(_lib.lib().rt_mjp_frechet_statistics(
+            self._h, n, nedges, _ptr(Qs, c_double), nq, _ptr(qi, c_int64), _ptr(t, c_double),
+            _ptr(W, c_double), _ptr(dwell, c_double), _ptr(trans, c_double)))
+        return dwell, trans
+
     # ---- multi-GPU ---------------------------------------------------------
 
     @staticmethod

@@ -240,45 +240,80 @@ def test_tree_specialised_mfma_source_is_generated_on_the_host(monkeypatch):
 
 
 def test_frechet_block_assembly_is_the_adjoint_of_expm_frechet():
-    """Host logic of the expected history statistics (raoteh_amd/_mjp_dense.py): the
-    2n x 2n blocks handed to the device expm, with scipy standing in for the device
-    here, give M = L(t Q^T, W), and <W, L(tQ, E_cd)> = M[c, d] for every direction
-    E_cd -- the n + nnz(Q) expm_frechet calls of _mjp_dense.py:483-533 in one
-    exponential; W of any size (it is scaled before it enters the block)."""
+    """The identity the device's expected-history-statistics path rests on
+    (csrc/expect.hip): with M = the upper right block of expm([[t Q^T, W], [0, t Q^T]]),
+    <W, L(tQ, E_cd)> = M[c, d] for every direction E_cd -- the n + nnz(Q) expm_frechet
+    calls of _mjp_dense.py:483-533 in one exponential, W of any size (it is scaled before
+    it enters the block).  scipy stands in for the device here; the host plumbing
+    (_edge_rates, _history_statistics_from_weights) is the product's."""
     import scipy.linalg
     from raoteh_amd import _mjp_dense
 
-    class ScipyExpm(object):
+    class ScipyDevice(object):
         @staticmethod
-        def expm(Q, t):
-            return np.stack([scipy.linalg.expm(q * x) for q, x in zip(Q, t)])
+        def frechet_statistics(Qs, q_index, t, W):
+            n = Qs.shape[1]
+            dwell, trans = np.zeros(n), np.zeros((n, n))
+            for e in range(len(t)):
+                Q = Qs[q_index[e]]
+                sc = np.abs(W[e]).max() or 1.0
+                B = np.zeros((2 * n, 2 * n))
+                B[:n, :n] = B[n:, n:] = t[e] * Q.T
+                B[:n, n:] = W[e] / sc
+                M = scipy.linalg.expm(B)[:n, n:] * sc
+                dwell += t[e] * np.diag(M)
+                trans += np.where(Q != 0, t[e] * Q * M, 0.0)
+            return dwell, trans
 
     rng = np.random.RandomState(5)
     for n in (2, 3, 5, 8):
-        Qs, Ws = [], []
-        ts = rng.uniform(0.05, 2.0, size=3)
+        T = nx.Graph()
+        mats = []
         for e in range(3):
             R = rng.exponential(size=(n, n))
             R[rng.uniform(size=(n, n)) < 0.3] = 0.0
             np.fill_diagonal(R, 0.0)
-            Qs.append(R - np.diag(R.sum(axis=1)))
-            Ws.append(rng.exponential(size=(n, n)) * 10.0 ** rng.randint(-6, 7))
-        Ws[1][:] = 0.0                                   # an edge nothing was seen on
-        M = _mjp_dense._frechet_contractions(ScipyExpm(), Qs, ts, np.stack(Ws))
-        assert not M[1].any()
-        for e in (0, 2):
+            mats.append(R - np.diag(R.sum(axis=1)))
+        ts = rng.uniform(0.05, 2.0, size=4)
+        T.add_edge(0, 1, weight=ts[0], Q=mats[0])
+        T.add_edge(0, 2, weight=ts[1])                  # Q_default
+        T.add_edge(2, 3, weight=ts[2], Q=mats[2])
+        T.add_edge(2, 4, weight=ts[3], Q=mats[0])       # the same matrix object twice
+        edges, distinct, q_index, tt = _mjp_dense._edge_rates(T, 0, mats[1])
+        assert len(distinct) == 3 and len(edges) == 4
+        for e, (na, nb) in enumerate(edges):
+            assert distinct[q_index[e]] is not None
+            np.testing.assert_array_equal(distinct[q_index[e]], T[na][nb].get('Q', mats[1]))
+            assert tt[e] == T[na][nb]['weight']
+        Ws = rng.exponential(size=(4, n, n)) * 10.0 ** rng.randint(-6, 7, size=(4, 1, 1))
+        Ws[1] = 0.0                                      # an edge nothing was seen on
+        dwell, trans = _mjp_dense._history_statistics_from_weights(
+            ScipyDevice(), n, distinct, q_index, tt, Ws)
+        # the reference's way: one expm_frechet per direction, contracted with W
+        want_d, want_t = np.zeros(n), np.zeros((n, n))
+        for e in range(4):
+            Q = distinct[q_index[e]]
             for c in range(n):
                 for d in range(n):
+                    if c != d and Q[c, d] == 0:
+                        continue
                     C = np.zeros((n, n))
                     C[c, d] = 1.0
-                    L = scipy.linalg.expm_frechet(ts[e] * Qs[e], C, compute_expm=False)
-                    assert M[e][c, d] == pytest.approx(np.sum(Ws[e] * L), rel=1e-11)
-        dwell, trans = _mjp_dense._accumulate(n, Qs, ts, M)
-        np.testing.assert_allclose(dwell, sum(ts[e] * np.diag(M[e]) for e in range(3)))
-        assert not trans[(Qs[0] == 0) & (Qs[1] == 0) & (Qs[2] == 0)].any()
+                    L = scipy.linalg.expm_frechet(tt[e] * Q, C, compute_expm=False)
+                    v = np.sum(Ws[e] * L)
+                    if c == d:
+                        want_d[c] += tt[e] * v
+                    if Q[c, d] != 0:
+                        want_t[c, d] += tt[e] * Q[c, d] * v
+        np.testing.assert_allclose(dwell, want_d, rtol=1e-10)
+        np.testing.assert_allclose(trans, want_t, rtol=1e-10, atol=1e-300)
     with pytest.raises(ValueError):
-        _mjp_dense._frechet_contractions(ScipyExpm(), [np.zeros((32, 32))], [1.0],
-                                         np.zeros((1, 32, 32)))
+        _mjp_dense._history_statistics_from_weights(
+            ScipyDevice(), 65, [np.zeros((65, 65))], np.zeros(1, dtype=np.int64), np.ones(1),
+            np.zeros((1, 65, 65)))
+    d0, t0 = _mjp_dense._history_statistics_from_weights(
+        ScipyDevice(), 3, [], np.zeros(0, dtype=np.int64), np.zeros(0), np.zeros((0, 3, 3)))
+    assert not d0.any() and not t0.any()
 
 
 def test_observed_states_are_range_checked_not_wrapped():
