@@ -60,6 +60,11 @@ def main():
                               chain=float(np.mean((t2 - t1)[sel])),
                               tail=float(np.mean((nxt - t2)[sel])),
                               step=float(np.mean((nxt - t0)[sel])))
+        # the pipelined generator has no separate prelude: "issue" = step start to last
+        # MFMA issued (chain + everything in its shadow), "sync" = from there to the next
+        # step's start (barrier + whatever ran serially)
+        rows['issue_to_last_mfma'] = float(np.mean((t2 - t0)[ok]))
+        rows['sync_after_last_mfma'] = float(np.mean((nxt - t2)[ok]))
         rows['total_cycles'] = int(tr[w, nrec, 0] - tr[w, 0, 0])
         out['waves'].append(rows)
     print(json.dumps(out, indent=1))
