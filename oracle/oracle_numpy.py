@@ -175,13 +175,13 @@ def expm_taylor(Q, t):
 
 
 def device_expm_restated(Q, t):
-    """What the device computes for this size: Pade below 5 states (lane kernel),
-    Taylor above."""
-    return expm_pade(Q, t) if np.asarray(Q).shape[0] <= 4 else expm_taylor(Q, t)
+    """What the device computes by default: the Taylor scheme at every size (the Pade
+    kernels remain behind RAOTEH_EXPM=pade)."""
+    return expm_taylor(Q, t)
 
 
 def device_expm_order_and_squarings(n, norm1):
-    return pade_order_and_squarings(norm1) if n <= 4 else taylor_order_and_squarings(norm1)
+    return taylor_order_and_squarings(norm1)
 
 
 # ---------------------------------------------------------------------------

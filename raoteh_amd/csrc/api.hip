@@ -877,16 +877,13 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
             // (one workgroup per CU): worth it once the batch is several rounds deep
             if (s->model->n > 64) return RT_OK;
             const int64_t ntiles = (s->nsites + 15) / 16;
-            // tiles per workgroup.  A batch of at most three tiles per CU runs as ONE
-            // workgroup per CU with all of a CU's tiles in it (config 3: 625 tiles, T = 3,
-            // 209 workgroups): the A fragments of a step are fetched once per CU instead of
-            // once per tile, and with the pipelined generator one wave per SIMD keeps the
-            // matrix pipe busy on its own (220 us against 245 us as 625 one-tile
-            // workgroups).  Larger batches: T = 2 (two workgroups per CU).
-            const int64_t ncu = std::max(1, s->model->ctx->num_cus);
-            int T = ntiles <= ncu ? 1
-                  : ntiles <= 3 * ncu ? (int)((ntiles + ncu - 1) / ncu)
-                  : (ntiles >= 2048 && s->ops.size() <= 300) ? 2 : 1;
+            // tiles per workgroup: T = 2 (one A fetch and one barrier per two chains, two
+            // workgroups per CU) once the batch is several rounds deep; below that one tile
+            // per workgroup, three workgroups per CU.  Measured with the pipelined
+            // generator: config 3 (625 tiles) 205 us at T = 1, 211 us at T = 3 (209
+            // workgroups, one per CU), 253 us at T = 2; a config-4 shard (7 813 tiles)
+            // 1 984 us at T = 2, 2 040 us at T = 1, 2 303 us at T = 3.
+            int T = (ntiles >= 2048 && s->ops.size() <= 300) ? 2 : 1;
             if (const char *v = getenv("RAOTEH_JIT_TILES")) T = std::min(3, std::max(1, atoi(v)));
             int D = 2, LA = 1;     // leaves fetched ahead (the pipelined generator needs >= 2)
             if (const char *v = getenv("RAOTEH_JIT_PREFETCH")) D = std::max(1, atoi(v));

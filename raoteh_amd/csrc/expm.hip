@@ -934,6 +934,111 @@ expm_small_kernel(int count, const double *__restrict__ Q, const int *__restrict
         }
 }
 
+// n <= 4, default: the Taylor / Paterson-Stockmeyer scheme of expm_taylor_kernel per lane
+// (A^2, A^3, Horner in A^3, squarings): at most 6 small products and no solve, against
+// up to 6 products plus an LU factorisation with predicated row swaps for the Pade form
+// above -- this kernel is one wave of dependent register arithmetic, and on config 2 it
+// sits in front of a 34 us pruning kernel in every step.
+template <int N>
+__global__ void __launch_bounds__(256)
+expm_small_taylor_kernel(int count, const double *__restrict__ Q, const int *__restrict__ qidx,
+                         const double *__restrict__ tt, double *__restrict__ P,
+                         int *__restrict__ info, const int *__restrict__ step_of_node,
+                         double *__restrict__ Pfrag, rt_reduce_args red)
+{
+    if (red.partial && blockIdx.x == gridDim.x - 1) {      // the carried reduction
+        rt_reduce_partials_body(red.partial, red.npartials, red.totals, red.nsites);
+        return;
+    }
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= count) return;
+    constexpr int NN = N * N;
+    double *Pb = P + (long)b * NN;
+    const int qi = qidx[b];
+    const int step = step_of_node ? step_of_node[b] : -1;
+    if (qi < 0) {                              // root slot: zeros (_density.py:171)
+#pragma unroll
+        for (int e = 0; e < NN; ++e) Pb[e] = 0.0;
+        if (info) { info[2 * b] = 0; info[2 * b + 1] = 0; }
+        if (step >= 0)
+#pragma unroll
+            for (int e = 0; e < NN; ++e) Pfrag[(long)step * NN + e] = 0.0;
+        return;
+    }
+    const double *Qb = Q + (long)qi * NN;
+    const double t = tt[b];
+    SmallMat<N> A;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) A.a[i][j] = Qb[i * N + j] * t;
+    double nrm = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double cs = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) cs += fabs(A.a[i][j]);
+        nrm = fmax(nrm, cs);
+    }
+    int m = 15, s = 0;
+    if (!(nrm < 1e300)) m = -1;
+    else if (nrm <= c_theta_taylor[0]) m = 3;
+    else if (nrm <= c_theta_taylor[1]) m = 6;
+    else if (nrm <= c_theta_taylor[2]) m = 9;
+    else if (nrm <= c_theta_taylor[3]) m = 12;
+    else if (nrm > c_theta_taylor[4]) {
+        int e;
+        const double f = frexp(nrm / c_theta_taylor[4], &e);
+        s = (f == 0.5) ? e - 1 : e;
+        if (s < 0) s = 0;
+    }
+    if (info) { info[2 * b] = m; info[2 * b + 1] = s; }
+    SmallMat<N> X;
+    if (m < 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) X.a[i][j] = __builtin_nan("");
+    } else {
+        if (s > 0) {
+            const double sc = ldexp(1.0, -s);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) A.a[i][j] *= sc;
+        }
+        SmallMat<N> A2, A3;
+        sm_mul(A, A, A2);
+        sm_mul(A, A2, A3);
+        const int q = m / 3;
+        {
+            const int base = 3 * (q - 1);
+            sm_comb(X, c_inv_fact[base + 1], A, c_inv_fact[base + 2], A2, c_inv_fact[m], A3,
+                    c_inv_fact[base]);
+        }
+        for (int jj = q - 2; jj >= 0; --jj) {
+            SmallMat<N> Y;
+            sm_mul(A3, X, Y);
+            // X = Y + c A + c A^2 + c I
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                    X.a[i][j] = Y.a[i][j] + (c_inv_fact[3 * jj + 1] * A.a[i][j] +
+                                             c_inv_fact[3 * jj + 2] * A2.a[i][j] +
+                                             (i == j ? c_inv_fact[3 * jj] : 0.0));
+        }
+        for (int r = 0; r < s; ++r) sm_mul(X, X, X);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            Pb[i * N + j] = X.a[i][j];
+            if (step >= 0) Pfrag[(long)step * NN + i * N + j] = X.a[i][j];
+        }
+}
+
 }  // namespace
 
 int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
@@ -961,9 +1066,27 @@ int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
     }
     if (n <= 4 && !getenv("RAOTEH_EXPM_NO_SMALL")) {
         hipEvent_t ev = nullptr;
-        rt_time_begin(ctx, RT_K_EXPM, "expm_small_lane_per_matrix", &ev);
+        const char *wh = getenv("RAOTEH_EXPM");
+        const bool pade = wh && strcmp(wh, "pade") == 0;
+        rt_time_begin(ctx, RT_K_EXPM, pade ? "expm_small_lane_per_matrix_pade"
+                                           : "expm_small_lane_per_matrix", &ev);
         const unsigned grid = (unsigned)((count + 255) / 256) + extra;
         const int *son = frag_kind == 0 ? d_step_of_node : nullptr;
+        if (!pade) {
+#define RT_SMALLT(NV)                                                                \
+            RT_LAUNCH_TIMED(ctx, expm_small_taylor_kernel<NV>, dim3(grid), dim3(256), 0, \
+                            (int)count, d_Q, d_qidx, d_t, d_P, d_info, son, d_Pfrag, red)
+            switch ((int)n) {
+            case 1: RT_SMALLT(1); break;
+            case 2: RT_SMALLT(2); break;
+            case 3: RT_SMALLT(3); break;
+            default: RT_SMALLT(4); break;
+            }
+#undef RT_SMALLT
+            RT_HIP(hipGetLastError());
+            rt_time_end(ctx, RT_K_EXPM, ev);
+            return RT_OK;
+        }
 #define RT_SMALL(NV)                                                                 \
         RT_LAUNCH_TIMED(ctx, expm_small_kernel<NV>, dim3(grid), dim3(256), 0, \
                            (int)count, d_Q, d_qidx, d_t, d_P, d_info, son, d_Pfrag, red)

@@ -757,6 +757,57 @@ def test_expected_history_statistics(ra):
         assert strans.number_of_edges() == int(np.count_nonzero(wt))
 
 
+def test_tolerance_process_closed_forms(ra):
+    """The 3-state tolerance process entry points of pyfelscore (_linalg.py:41-69,
+    107-118; _tmjp_dense.py:339): the contract their call sites state is equality with
+    scipy.linalg.expm / expm_frechet (tests/test_expm.py:20-42 does that for the
+    blocks), in all three regimes of the closed forms."""
+    import scipy.linalg
+    pyf = ra.pyf
+    for a, w, r in ((0.7, 1.3, 0.4), (0.7, 0.0, 0.4), (0.9, 0.0, 0.9), (2.0, 5.0, 0.0)):
+        Q = np.array([[-a, a, 0.0], [w, -(w + r), r], [0.0, 0.0, 0.0]])
+        for t in (2.0 ** -5, 0.3, 1.0, 8.0):
+            Pw = scipy.linalg.expm(t * Q)
+            blk = pyf.get_mmpp_block(a, w, r, t) if w else pyf.get_mmpp_block_zero_off_rate(a, r, t)
+            np.testing.assert_allclose(blk, Pw[:2, :2], rtol=1e-11, atol=1e-15)
+            for ci in range(3):
+                for di in range(3):
+                    C = np.zeros((3, 3))
+                    C[ci, di] = 1.0
+                    L = scipy.linalg.expm_frechet(t * Q, t * C, compute_expm=False)
+                    for ai in range(3):
+                        for bi in range(3):
+                            if w:
+                                got = pyf.get_mmpp_frechet_all_positive(a, w, r, t, ai, bi, ci, di)
+                            elif a != r:
+                                got = pyf.get_mmpp_frechet_diagonalizable_w_zero(
+                                    a, r, t, ai, bi, ci, di)
+                            else:
+                                got = pyf.get_mmpp_frechet_defective_w_zero(a, t, ai, bi, ci, di)
+                            assert got == pytest.approx(L[ai, bi], rel=1e-9, abs=1e-14)
+            # one edge of the tolerance expectations against the general formula
+            rng = np.random.RandomState(3)
+            J = rng.uniform(size=(3, 3)) * (Pw > 0)
+            J /= J.sum()
+            dwell, trans = np.zeros(2), np.zeros((2, 2))
+            absorb = pyf.get_tolerance_expectations(t, Q, Pw, J, dwell, trans)
+            live = J != 0
+            ratio = np.zeros((3, 3))
+            ratio[live] = J[live] / Pw[live]
+
+            def contract(c, d):
+                C = np.zeros((3, 3))
+                C[c, d] = 1.0
+                return float(np.sum(ratio * scipy.linalg.expm_frechet(
+                    t * Q, t * C, compute_expm=False)))
+            assert dwell[0] == pytest.approx(contract(0, 0), rel=1e-9, abs=1e-14)
+            assert dwell[1] == pytest.approx(contract(1, 1), rel=1e-9, abs=1e-14)
+            assert trans[0, 1] == pytest.approx(a * contract(0, 1), rel=1e-9, abs=1e-14)
+            assert trans[1, 0] == pytest.approx(w * contract(1, 0), rel=1e-9, abs=1e-14)
+            assert absorb == pytest.approx(r * contract(1, 2), rel=1e-9, abs=1e-14)
+            assert trans[0, 0] == 0 and trans[1, 1] == 0
+
+
 def test_expected_history_statistics_codon_model(ra):
     """61 states: the Frechet blocks have order 122 (the global-scratch Taylor kernel);
     block assembly and the contraction over the edges run on the device.  A 9-node tree,
