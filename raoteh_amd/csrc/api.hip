@@ -407,8 +407,7 @@ extern "C" int rt_model_create(rt_ctx *ctx, int64_t nnodes, int64_t n,
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_Pfrag, pfrag_doubles(m) * 8);
     if (e == hipSuccess) e = hipMemset(m->d_Pfrag, 0, pfrag_doubles(m) * 8);
     if (e == hipSuccess && n > 4 && n <= 32) {
-        const size_t ks = (size_t)((n + 3) / 4);
-        const size_t bytes = m->ops.size() * ks * ks * 16 * 8;
+        const size_t bytes = m->ops.size() * (size_t)rt_quad_stride((int)n) * 8;
         e = hipMalloc((void **)&m->d_Pquad, bytes);
         if (e == hipSuccess) e = hipMemset(m->d_Pquad, 0, bytes);
     }
@@ -926,12 +925,13 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
         s->jit_lookahead = LA;
         // built on v_mfma_f64_4x4x4_4b (4 rows x 16 sites per instruction: no padding of
         // n to a multiple of 16 rows) unless RAOTEH_JIT_QUAD=0
-        // (off by default: measured on config 5 it changes nothing -- 86.9 us against
-        // 83.9 us at T = 4, and it is slower at fewer tiles per wave, where the 25 replicated
-        // A fetches per step of this form weigh more -- because that kernel is not bound by
-        // the matrix pipe but by what one wave per SIMD can keep in flight)
-        const bool quad = s->model->d_Pquad != nullptr && getenv("RAOTEH_JIT_QUAD") &&
-                          atoi(getenv("RAOTEH_JIT_QUAD")) != 0;
+        // (RAOTEH_JIT_QUAD=0 keeps the 16x16x4 form.  Config 5: 71 us against 84 us at T = 4
+        // with the blocks of P_e passing through LDS; with every block fetched replicated
+        // from global memory the 4x4x4 form gained nothing)
+        // ... where it saves matrix-pipe time: ceil(n/4)^2 x 16.5 cycles against
+        // ceil(n/16) ceil(n/4) x 67 (none at n = 16 or 29..32; RAOTEH_JIT_QUAD=1 forces it)
+        bool quad = s->model->d_Pquad != nullptr && KS * KS * 16.5 <= 0.8 * NT * KS * 67.0;
+        if (const char *v = getenv("RAOTEH_JIT_QUAD")) quad = s->model->d_Pquad && atoi(v) != 0;
         int rc = RT_ERR_UNSUPPORTED;
         for (; T >= 1 && rc == RT_ERR_UNSUPPORTED; --T) {         // fewer tiles if it spills
             const std::string src =
@@ -1039,7 +1039,7 @@ extern "C" int rt_jit_source(int64_t nnodes, const int64_t *idx, const int64_t *
         ? rt_jit_lane_source(m.ops, (int)n, (int)nobs, (int)prefetch, LA, 64, 4,
                              getenv("RAOTEH_JIT_SOURCE_STATES") != nullptr)
         : n <= 32 ? rt_jit_mfma_source(m.ops, (int)n, (int)nobs, T, (int)prefetch, 1,
-                                       getenv("RAOTEH_JIT_QUAD") && atoi(getenv("RAOTEH_JIT_QUAD")) != 0)
+                                       !(getenv("RAOTEH_JIT_QUAD") && atoi(getenv("RAOTEH_JIT_QUAD")) == 0))
                   : split_source(m.ops, (int)n, (int)nobs, std::min(T, 3),
                                              (int)prefetch, 1);
     RT_REQUIRE((int64_t)src.size() + 1 <= capacity, "buffer too small: %lld bytes needed",

@@ -243,3 +243,10 @@ int rt_sites_pack(rt_sites *s, int kind, const int64_t *obs_order,
                   const void *data);
 
 static inline int64_t rt_round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+// doubles per step of the quad-block table (rt_model::d_Pquad): ceil(n/4)^2 blocks of 16,
+// rounded up to whole 1 KiB wave loads (64 lanes x 16 bytes)
+__host__ __device__ static inline int rt_quad_stride(int n)
+{
+    const int ks = (n + 3) / 4;
+    return (ks * ks * 16 + 127) / 128 * 128;
+}

@@ -184,7 +184,7 @@ expm_kernel(int n, const double *__restrict__ Q, const int *__restrict__ qidx,
             const int total = NT * ((KS + 1) / 2) * 128;
             for (int e = tid; e < total; e += TPB) Pfrag[(long)step * total + e] = 0.0;
             if (Pquad)
-                for (int e = tid; e < KS * KS * 16; e += TPB) Pquad[(long)step * KS * KS * 16 + e] = 0.0;
+                for (int e = tid; e < KS * KS * 16; e += TPB) Pquad[(long)step * rt_quad_stride(n) + e] = 0.0;
         }
         return;
     }
@@ -454,7 +454,7 @@ expm_kernel(int n, const double *__restrict__ Q, const int *__restrict__ qidx,
             for (int e = tid; e < tq; e += TPB) {
                 const int i = e & 3, k = (e >> 2) & 3, blk = e >> 4;
                 const int row = 4 * (blk / KS) + i, col = 4 * (blk % KS) + k;
-                Pquad[(long)step * tq + e] = (row < n && col < n) ? Xb[row * ld + col] : 0.0;
+                Pquad[(long)step * rt_quad_stride(n) + e] = (row < n && col < n) ? Xb[row * ld + col] : 0.0;
             }
         }
     }
@@ -620,7 +620,7 @@ expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ 
             for (int e = tid; e < total; e += TPB) Pfrag[(long)step * total + e] = 0.0;
             if (Pquad)
                 for (int e = tid; e < KSn * KSn * 16; e += TPB)
-                    Pquad[(long)step * KSn * KSn * 16 + e] = 0.0;
+                    Pquad[(long)step * rt_quad_stride(n) + e] = 0.0;
         }
         return;
     }
@@ -733,7 +733,7 @@ expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ 
             for (int e = tid; e < tq; e += TPB) {
                 const int i = e & 3, k = (e >> 2) & 3, blk = e >> 4;
                 const int row = 4 * (blk / KSn) + i, col = 4 * (blk % KSn) + k;
-                Pquad[(long)step * tq + e] = Xb[row * LD + col];
+                Pquad[(long)step * rt_quad_stride(n) + e] = Xb[row * LD + col];
             }
         }
     }

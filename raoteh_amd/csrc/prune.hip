@@ -1081,7 +1081,7 @@ __global__ void pack_p_quad_kernel(const double *__restrict__ P,
         const int row = 4 * (blk / KS) + r, col = 4 * (blk % KS) + k;
         double v = 0.0;
         if (op.dst >= 0 && row < n && col < n) v = P[(long)op.node * n * n + row * n + col];
-        Pquad[(long)i * total + e] = v;
+        Pquad[(long)i * rt_quad_stride(n) + e] = v;
     }
 }
 
