@@ -662,6 +662,280 @@ apply_obs_kernel(int nnodes, int n, long nsites, int nobs, const int *__restrict
     }
 }
 
+// ---------------------------------------------------------------------------
+// n <= 8: the whole chain -- both boolean passes, the upward pass, the downward pass
+// and the per-edge site sums of J / P -- in ONE kernel with a LANE PER SITE, on the
+// resident layout [node][state][site] (a wave touches 64 consecutive sites of one
+// (node, state) row: every access is a coalesced 512-byte row).  Allowed sets are one
+// byte per node and site; the matrices are wave-uniform (scalar loads).  The kernels
+// above put (site slot, state) on the lanes of the reference's [site][node][state]
+// arrays and synchronise per node: 1.2-1.45 ms per pass and 100 000 4-state sites
+// against the ~0.1 ms their bytes cost, plus 6.7 ms for the site sums.  Here: three
+// arrays (message to the parent M, subtree likelihood L, posterior D) are written once
+// and read once or twice, and a site's arithmetic is the same fma chains in the same
+// order as in pmap_kernel / distn_kernel, so the numbers are those of the old path.
+// The site sums: per edge and (a, b) one wave reduction over the 64 sites, one partial
+// per wave, then sum_parts_kernel adds the waves in index order (fixed rounding).
+// ---------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256)
+sets_from_mask_kernel(int nnodes, int n, long nsites, long S, const long *__restrict__ mask,
+                      unsigned char *__restrict__ sets)
+{
+    const long total = (long)nnodes * S;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long v = i / S, site = i - v * S;
+        unsigned m = 0;
+        if (site < nsites)
+            for (int s = 0; s < n; ++s)
+                m |= (mask[((size_t)site * nnodes + v) * n + s] != 0 ? 1u : 0u) << s;
+        else
+            m = (1u << n) - 1u;
+        sets[i] = (unsigned char)m;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+sets_fill_kernel(long total, int n, unsigned char *__restrict__ sets)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256)
+        sets[i] = (unsigned char)((1u << n) - 1u);
+}
+
+__global__ void __launch_bounds__(256)
+sets_apply_obs_kernel(int n, long nsites, long S, int nobs, const int *__restrict__ obs_nodes,
+                      int kind, const void *__restrict__ data, unsigned char *__restrict__ sets)
+{
+    const long total = nsites * nobs;
+    const unsigned full = (1u << n) - 1u;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int j = (int)(i % nobs);
+        const long site = i / nobs;
+        unsigned m;
+        if (kind == RT_OBS_STATE) {
+            const unsigned v = ((const unsigned char *)data)[i];
+            m = v >= (unsigned)n ? full : 1u << v;
+        } else {
+            m = (unsigned)(((const unsigned long long *)data)[i]) & full;
+        }
+        sets[(size_t)obs_nodes[j] * S + site] = (unsigned char)m;
+    }
+}
+
+template <int N>
+__global__ void __launch_bounds__(64)
+expect_lane_kernel(int nnodes, long nsites, long S, const int *__restrict__ parent,
+                   const long *__restrict__ cidx, const long *__restrict__ cptr,
+                   const double *__restrict__ esd, const unsigned char *__restrict__ rowbits,
+                   const unsigned char *__restrict__ colbits, const double *__restrict__ root_distn,
+                   const double *__restrict__ weights, unsigned char *__restrict__ sets,
+                   double *__restrict__ M, double *__restrict__ Lb, double *__restrict__ Dn,
+                   double *__restrict__ part, int *__restrict__ status)
+{
+    const int lane = threadIdx.x;
+    const long site = (long)blockIdx.x * 64 + lane;
+    const bool live = site < nsites;
+    const size_t row = (size_t)S;                     // doubles per (node, state) row
+    // ---- backward boolean pass (pyfelscore.mcy_esd_get_node_to_pset) ----
+    for (int v = nnodes - 1; v >= 1; --v) {
+        const unsigned sv = sets[(size_t)v * S + site];
+        unsigned keep = 0;
+#pragma unroll
+        for (int a = 0; a < N; ++a) keep |= (rowbits[v * N + a] & sv) ? 1u << a : 0u;
+        sets[(size_t)parent[v] * S + site] &= (unsigned char)keep;
+    }
+    // ---- forward boolean pass (pyfelscore.esd_get_node_to_set) ----
+    for (int v = 1; v < nnodes; ++v) {
+        const unsigned pv = sets[(size_t)parent[v] * S + site];
+        unsigned reach = 0;
+#pragma unroll
+        for (int b = 0; b < N; ++b) reach |= (colbits[v * N + b] & pv) ? 1u << b : 0u;
+        sets[(size_t)v * S + site] &= (unsigned char)reach;
+    }
+    // ---- upward pass (pyfelscore.mcy_esd_get_node_to_pmap) ----
+    for (int v = nnodes - 1; v >= 0; --v) {
+        double acc[N];
+#pragma unroll
+        for (int a = 0; a < N; ++a) acc[a] = 1.0;
+        for (long e = cptr[v]; e < cptr[v + 1]; ++e) {
+            const size_t c = (size_t)cidx[e];
+#pragma unroll
+            for (int a = 0; a < N; ++a) acc[a] *= M[(c * N + a) * row + site];
+        }
+        const unsigned sv = sets[(size_t)v * S + site];
+        double l[N];
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            l[a] = (sv >> a) & 1u ? acc[a] : 0.0;
+            Lb[((size_t)v * N + a) * row + site] = l[a];
+        }
+        if (v > 0) {
+            const double *Pv = esd + (size_t)v * N * N;
+#pragma unroll
+            for (int a = 0; a < N; ++a) {
+                double sum = 0.0;
+#pragma unroll
+                for (int b = 0; b < N; ++b) sum = fma(Pv[a * N + b], l[b], sum);
+                M[((size_t)v * N + a) * row + site] = sum;
+            }
+        }
+    }
+    // ---- downward pass (pyfelscore.mc0_esd_get_node_to_distn) + site sums ----
+    const double wt = (live && weights) ? weights[site] : (live ? 1.0 : 0.0);
+    double *out = part + (size_t)blockIdx.x * nnodes * N * N;
+    bool bad = false;
+    {
+        double w[N], tot = 0.0;
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            w[a] = Lb[(size_t)a * row + site] * (root_distn ? root_distn[a] : 1.0);
+            tot += w[a];
+        }
+        if (!(tot > 0.0)) bad = true;
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            const double d = tot > 0.0 ? w[a] / tot : 0.0;
+            Dn[(size_t)a * row + site] = d;
+            // slot 0 of the output: the weighted sum of the root posteriors, column 0
+            double r = live ? wt * d : 0.0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
+#pragma unroll
+            for (int b = 0; b < N; ++b)
+                if (lane == 0) out[a * N + b] = b == 0 ? r : 0.0;
+        }
+    }
+    for (int v = 1; v < nnodes; ++v) {
+        const size_t p = (size_t)parent[v];
+        const double *Pv = esd + (size_t)v * N * N;
+        double u[N], lv[N];
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            const double pa = Dn[(p * N + a) * row + site];
+            const double den = M[((size_t)v * N + a) * row + site];
+            u[a] = 0.0;
+            if (pa != 0.0) {
+                if (den > 0.0) u[a] = pa / den;
+                else bad = true;
+            }
+            lv[a] = Lb[((size_t)v * N + a) * row + site];
+        }
+#pragma unroll
+        for (int b = 0; b < N; ++b) {
+            double acc = 0.0;
+#pragma unroll
+            for (int a = 0; a < N; ++a) acc = fma(u[a], Pv[a * N + b], acc);
+            Dn[((size_t)v * N + b) * row + site] = acc * lv[b];
+        }
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            const double ua = live ? wt * u[a] : 0.0;
+#pragma unroll
+            for (int b = 0; b < N; ++b) {
+                double x = ua * lv[b];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+                if (lane == 0) out[((size_t)v * N + a) * N + b] = Pv[a * N + b] != 0.0 ? x : 0.0;
+            }
+        }
+    }
+    if (status && live) status[site] = bad ? 2 : 0;
+}
+
+int expectation_weights_lane(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t nsites,
+        const int64_t *idx, const int64_t *ptr, const double *esd, const double *root_distn,
+        const int64_t *state_mask, int64_t nobs, const std::vector<int> &obs_idx, int kind,
+        const void *data, const double *site_weights, double *edge_weights, int32_t *status)
+{
+    const size_t nn = (size_t)n * n, wcount = (size_t)nnodes * nn;
+    const long S = (long)((nsites + 63) / 64 * 64);
+    const int G = (int)(S / 64);                       // waves = partial sums
+    std::vector<int> parent((size_t)nnodes, 0);
+    for (int64_t v = 0; v < nnodes; ++v)
+        for (int64_t e = ptr[v]; e < ptr[v + 1]; ++e) parent[(size_t)idx[e]] = (int)v;
+    std::vector<unsigned char> rowbits((size_t)nnodes * n, 0), colbits((size_t)nnodes * n, 0);
+    for (int64_t v = 1; v < nnodes; ++v)
+        for (int64_t a = 0; a < n; ++a)
+            for (int64_t b = 0; b < n; ++b)
+                if (esd[(size_t)v * nn + a * n + b] > 0.0) {
+                    rowbits[(size_t)v * n + a] |= (unsigned char)(1u << b);
+                    colbits[(size_t)v * n + b] |= (unsigned char)(1u << a);
+                }
+    const size_t arr = (size_t)nnodes * n * S * 8;
+    const size_t ni = (size_t)(nnodes > 1 ? nnodes - 1 : 1);
+    scratch_plan plan;
+    const size_t o_idx = plan.take(ni * 8), o_ptr = plan.take((size_t)(nnodes + 1) * 8);
+    const size_t o_esd = plan.take(wcount * 8), o_par = plan.take((size_t)nnodes * 4);
+    const size_t o_rb = plan.take((size_t)nnodes * n), o_cb = plan.take((size_t)nnodes * n);
+    const size_t o_sets = plan.take((size_t)nnodes * S);
+    const size_t o_M = plan.take(arr), o_L = plan.take(arr), o_D = plan.take(arr);
+    const size_t o_root = plan.take((size_t)n * 8), o_w = plan.take((size_t)nsites * 8);
+    const size_t o_st = plan.take((size_t)S * 4);
+    const size_t o_part = plan.take((size_t)G * wcount * 8), o_out = plan.take(wcount * 8);
+    const size_t mask_bytes = state_mask ? (size_t)nsites * nnodes * n * 8 : 0;
+    const size_t data_bytes = state_mask ? 0 : (size_t)nsites * nobs * (kind == RT_OBS_STATE ? 1 : 8);
+    const size_t o_data = plan.take(std::max<size_t>(std::max(data_bytes, mask_bytes), 8));
+    const size_t o_obsn = plan.take(std::max<size_t>((size_t)nobs * 4, 8));
+    RT_TRY(scratch_reserve(ctx, plan.total));
+    unsigned char *base = ctx->d_scratch;
+    long *d_idx = (long *)(base + o_idx), *d_ptr = (long *)(base + o_ptr);
+    double *d_esd = (double *)(base + o_esd);
+    int *d_par = (int *)(base + o_par), *d_st = (int *)(base + o_st);
+    unsigned char *d_rb = base + o_rb, *d_cb = base + o_cb, *d_sets = base + o_sets;
+    double *d_M = (double *)(base + o_M), *d_L = (double *)(base + o_L), *d_D = (double *)(base + o_D);
+    double *d_root = root_distn ? (double *)(base + o_root) : nullptr;
+    double *d_w = site_weights ? (double *)(base + o_w) : nullptr;
+    double *d_part = (double *)(base + o_part), *d_out = (double *)(base + o_out);
+    hipStream_t st = ctx->stream;
+    if (nnodes > 1)
+        RT_HIP(hipMemcpyAsync(d_idx, idx, (size_t)(nnodes - 1) * 8, hipMemcpyHostToDevice, st));
+    RT_HIP(hipMemcpyAsync(d_ptr, ptr, (size_t)(nnodes + 1) * 8, hipMemcpyHostToDevice, st));
+    RT_HIP(hipMemcpyAsync(d_esd, esd, wcount * 8, hipMemcpyHostToDevice, st));
+    RT_HIP(hipMemcpyAsync(d_par, parent.data(), (size_t)nnodes * 4, hipMemcpyHostToDevice, st));
+    RT_HIP(hipMemcpyAsync(d_rb, rowbits.data(), rowbits.size(), hipMemcpyHostToDevice, st));
+    RT_HIP(hipMemcpyAsync(d_cb, colbits.data(), colbits.size(), hipMemcpyHostToDevice, st));
+    if (d_root) RT_HIP(hipMemcpyAsync(d_root, root_distn, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    if (d_w) RT_HIP(hipMemcpyAsync(d_w, site_weights, (size_t)nsites * 8, hipMemcpyHostToDevice, st));
+    void *d_data = base + o_data;
+    int *d_obsn = (int *)(base + o_obsn);
+    if (state_mask) {
+        RT_HIP(hipMemcpyAsync(d_data, state_mask, mask_bytes, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(sets_from_mask_kernel, dim3(2048), dim3(256), 0, st, (int)nnodes, (int)n,
+                           (long)nsites, S, (const long *)d_data, d_sets);
+    } else {
+        if (data_bytes) RT_HIP(hipMemcpyAsync(d_data, data, data_bytes, hipMemcpyHostToDevice, st));
+        if (nobs)
+            RT_HIP(hipMemcpyAsync(d_obsn, obs_idx.data(), (size_t)nobs * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(sets_fill_kernel, dim3(2048), dim3(256), 0, st, (long)nnodes * S, (int)n,
+                           d_sets);
+        if (nobs)
+            hipLaunchKernelGGL(sets_apply_obs_kernel, dim3(2048), dim3(256), 0, st, (int)n,
+                               (long)nsites, S, (int)nobs, d_obsn, kind, d_data, d_sets);
+    }
+#define RT_EXPECT_LANE(NV)                                                                   \
+    hipLaunchKernelGGL(expect_lane_kernel<NV>, dim3((unsigned)G), dim3(64), 0, st, (int)nnodes, \
+                       (long)nsites, S, d_par, d_idx, d_ptr, d_esd, d_rb, d_cb, d_root, d_w,   \
+                       d_sets, d_M, d_L, d_D, d_part, d_st)
+    switch ((int)n) {
+    case 1: RT_EXPECT_LANE(1); break;
+    case 2: RT_EXPECT_LANE(2); break;
+    case 3: RT_EXPECT_LANE(3); break;
+    case 4: RT_EXPECT_LANE(4); break;
+    case 5: RT_EXPECT_LANE(5); break;
+    case 6: RT_EXPECT_LANE(6); break;
+    case 7: RT_EXPECT_LANE(7); break;
+    default: RT_EXPECT_LANE(8); break;
+    }
+#undef RT_EXPECT_LANE
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((wcount + 255) / 256)), dim3(256), 0,
+                       st, G, (long)wcount, d_part, d_out);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipMemcpyAsync(edge_weights, d_out, wcount * 8, hipMemcpyDeviceToHost, st));
+    if (status) RT_HIP(hipMemcpyAsync(status, d_st, (size_t)nsites * 4, hipMemcpyDeviceToHost, st));
+    RT_HIP(hipStreamSynchronize(st));
+    return RT_OK;
+}
+
 int expectation_weights_impl(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t nsites,
         const int64_t *idx, const int64_t *ptr, const double *esd, const double *root_distn,
         const int64_t *state_mask, int64_t nobs, const int64_t *obs_nodes, int kind,
@@ -690,6 +964,12 @@ int expectation_weights_impl(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t nsi
         memset(edge_weights, 0, wcount * 8);
         return RT_OK;
     }
+    // n <= 8: the fused lane-per-site kernel on the resident layout
+    // (RAOTEH_EXPECT_LEGACY=1: the per-pass kernels below, for A/B runs)
+    if (n <= 8 && !getenv("RAOTEH_EXPECT_LEGACY"))
+        return expectation_weights_lane(ctx, nnodes, n, nsites, idx, ptr, esd, root_distn,
+                                        state_mask, nobs, obs_idx, kind, data, site_weights,
+                                        edge_weights, status);
     std::vector<int> parent((size_t)nnodes, 0);
     for (int64_t v = 0; v < nnodes; ++v)
         for (int64_t e = ptr[v]; e < ptr[v + 1]; ++e) parent[(size_t)idx[e]] = (int)v;
