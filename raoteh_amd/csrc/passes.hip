@@ -616,6 +616,22 @@ ratio_sum_small_kernel(int nnodes, int n, int nsites, const int *__restrict__ pa
     }
 }
 
+// the same with one workgroup per 4 outputs and 64 threads per output: thread t of an
+// output adds partials t, t + 64, ... in that order, then a fixed tree over the 64 sums
+// (1 563 partials per output at 100 000 sites: one thread per output is a serial chain)
+__global__ void __launch_bounds__(256)
+sum_parts_wide_kernel(int G, long count, const double *__restrict__ part, double *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= count) return;
+    double s = 0.0;
+    for (int g = lane; g < G; g += 64) s += part[(size_t)g * count + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) out[i] = s;
+}
+
 __global__ void __launch_bounds__(256)
 sum_parts_kernel(int G, long count, const double *__restrict__ part, double *__restrict__ out)
 {
@@ -720,6 +736,30 @@ sets_apply_obs_kernel(int n, long nsites, long S, int nobs, const int *__restric
         }
         sets[(size_t)obs_nodes[j] * S + site] = (unsigned char)m;
     }
+}
+
+// Sum P = 2^k values per lane over the 64 lanes of a wave: in each of the first k steps a
+// lane hands half of its values to its partner (lane ^ 32, ^ 16, ...) and keeps the sums of
+// the other half -- P - 1 exchanged values in all instead of 6 P for P separate butterfly
+// reductions; the remaining 6 - k steps finish the one value left.  Afterwards x[0] of
+// lane l is the total of entry (l >> (6 - k)) & (P - 1); the lanes whose low 6 - k bits
+// are zero own distinct entries.  Fixed order: deterministic sums.
+template <int P>
+__device__ __forceinline__ void wave_sum_many(double (&x)[P], int lane)
+{
+    int h = 32;
+#pragma unroll
+    for (int cnt = P; cnt > 1; cnt >>= 1, h >>= 1) {
+        const bool up = (lane & h) != 0;
+#pragma unroll
+        for (int i = 0; i < cnt / 2; ++i) {
+            const double send = up ? x[i] : x[i + cnt / 2];
+            const double keep = up ? x[i + cnt / 2] : x[i];
+            x[i] = keep + __shfl_xor(send, h, 64);
+        }
+    }
+#pragma unroll
+    for (; h > 0; h >>= 1) x[0] += __shfl_xor(x[0], h, 64);
 }
 
 template <int N>
@@ -827,16 +867,25 @@ expect_lane_kernel(int nnodes, long nsites, long S, const int *__restrict__ pare
             for (int a = 0; a < N; ++a) acc = fma(u[a], Pv[a * N + b], acc);
             Dn[((size_t)v * N + b) * row + site] = acc * lv[b];
         }
+        {
+            constexpr int V = N * N;
+            constexpr int P = V <= 1 ? 1 : V <= 2 ? 2 : V <= 4 ? 4 : V <= 8 ? 8 : V <= 16 ? 16
+                              : V <= 32 ? 32 : 64;
+            constexpr int K = P == 1 ? 0 : P == 2 ? 1 : P == 4 ? 2 : P == 8 ? 3 : P == 16 ? 4
+                              : P == 32 ? 5 : 6;
+            double x[P];
 #pragma unroll
-        for (int a = 0; a < N; ++a) {
-            const double ua = live ? wt * u[a] : 0.0;
+            for (int e = 0; e < P; ++e) x[e] = 0.0;
 #pragma unroll
-            for (int b = 0; b < N; ++b) {
-                double x = ua * lv[b];
+            for (int a = 0; a < N; ++a) {
+                const double ua = live ? wt * u[a] : 0.0;
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-                if (lane == 0) out[((size_t)v * N + a) * N + b] = Pv[a * N + b] != 0.0 ? x : 0.0;
+                for (int b = 0; b < N; ++b) x[a * N + b] = ua * lv[b];
             }
+            wave_sum_many<P>(x, lane);
+            const int ent = (lane >> (6 - K)) & (P - 1);
+            if ((lane & ((1 << (6 - K)) - 1)) == 0 && ent < V)
+                out[(size_t)v * V + ent] = Pv[ent] != 0.0 ? x[0] : 0.0;
         }
     }
     if (status && live) status[site] = bad ? 2 : 0;
@@ -927,7 +976,7 @@ int expectation_weights_lane(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t nsi
     default: RT_EXPECT_LANE(8); break;
     }
 #undef RT_EXPECT_LANE
-    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((wcount + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(sum_parts_wide_kernel, dim3((unsigned)((wcount + 3) / 4)), dim3(256), 0,
                        st, G, (long)wcount, d_part, d_out);
     RT_HIP(hipGetLastError());
     RT_HIP(hipMemcpyAsync(edge_weights, d_out, wcount * 8, hipMemcpyDeviceToHost, st));

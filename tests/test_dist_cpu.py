@@ -107,3 +107,29 @@ def test_bench_reduce_grouping_covers_every_step_once():
                     reduced.append(pending.pop(k))
             assert not pending, (nb, steps, pending)
             assert sorted(reduced) == list(range(steps))
+
+
+def test_bench_shards_are_slices_of_one_batch():
+    """bench.py at N > 1: the weak workloads shard ONE global batch of N x (configuration
+    size) sites by dist.shard_range, config 4 shards the one million-site batch; the
+    ranks' blocks tile the batch in order whatever the rank count."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from raoteh_amd import synth
+    whole, total = bench.shard_config('c2', 0, 1, 600)
+    assert total == 600 and whole['leaf_states'].shape == (600, 64)
+    for world in (2, 3):
+        parts = [bench.shard_config('c2', r, world, 200)[0]['leaf_states'] for r in range(world)]
+        ref = synth.make_config('c2', nsites=200 * world)['leaf_states']
+        np.testing.assert_array_equal(np.concatenate(parts), ref)
+        assert bench.shard_config('c2', 0, world, 200)[1] == 200 * world
+    # config 4 (strong scaling): total fixed, the rank blocks are slices of the same batch
+    full = synth.make_config('c4', site_range=(0, 40000))['leaf_states']
+    got = [bench.shard_config('c4', r, 4, 40000) for r in range(4)]
+    assert all(t == 40000 for _, t in got)
+    np.testing.assert_array_equal(np.concatenate([c['leaf_states'] for c, _ in got]), full)
+    lo, hi = shard_range(synth.C4_NSITES, 3, 8)
+    assert (lo, hi) == (375000, 500000)
+    assert bench.WORKLOADS['c4']['scaling'] == 'strong' and bench.WORKLOADS['c3']['scaling'] == 'weak'
