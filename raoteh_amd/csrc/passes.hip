@@ -744,22 +744,30 @@ sets_apply_obs_kernel(int n, long nsites, long S, int nobs, const int *__restric
 // reductions; the remaining 6 - k steps finish the one value left.  Afterwards x[0] of
 // lane l is the total of entry (l >> (6 - k)) & (P - 1); the lanes whose low 6 - k bits
 // are zero own distinct entries.  Fixed order: deterministic sums.
+template <int CNT, int H, int P>
+__device__ __forceinline__ void wave_sum_many_step(double (&x)[P], int lane)
+{
+    // (a template recursion: written as one loop over cnt and h the compiler does not
+    // unroll it and indexes the register array with selects, 1 300 instructions per call)
+    if constexpr (CNT > 1) {
+        const bool up = (lane & H) != 0;
+#pragma unroll
+        for (int i = 0; i < CNT / 2; ++i) {
+            const double send = up ? x[i] : x[i + CNT / 2];
+            const double keep = up ? x[i + CNT / 2] : x[i];
+            x[i] = keep + __shfl_xor(send, H, 64);
+        }
+        wave_sum_many_step<CNT / 2, H / 2, P>(x, lane);
+    } else if constexpr (H > 0) {
+        x[0] += __shfl_xor(x[0], H, 64);
+        wave_sum_many_step<1, H / 2, P>(x, lane);
+    }
+}
+
 template <int P>
 __device__ __forceinline__ void wave_sum_many(double (&x)[P], int lane)
 {
-    int h = 32;
-#pragma unroll
-    for (int cnt = P; cnt > 1; cnt >>= 1, h >>= 1) {
-        const bool up = (lane & h) != 0;
-#pragma unroll
-        for (int i = 0; i < cnt / 2; ++i) {
-            const double send = up ? x[i] : x[i + cnt / 2];
-            const double keep = up ? x[i + cnt / 2] : x[i];
-            x[i] = keep + __shfl_xor(send, h, 64);
-        }
-    }
-#pragma unroll
-    for (; h > 0; h >>= 1) x[0] += __shfl_xor(x[0], h, 64);
+    wave_sum_many_step<P, 32, P>(x, lane);
 }
 
 template <int N>
@@ -891,6 +899,289 @@ expect_lane_kernel(int nnodes, long nsites, long S, const int *__restrict__ pare
     if (status && live) status[site] = bad ? 2 : 0;
 }
 
+// ---------------------------------------------------------------------------
+// The same computation with every dependent access in LDS.  In the kernel above a wave
+// walks the tree through global memory: each node of each pass waits for one global load
+// that the previous node's store may alias (0.8 ms for ONE wave of the 127-node tree,
+// 1.3 us per node and pass).  Here the host schedules the two numeric passes as a stack
+// program over a few LDS slots (one N-vector per lane each):
+//   up   -- post-order, heaviest child first; a finished message is written to a slot or
+//           multiplied into the product of its earlier siblings, so the slots in use never
+//           exceed log2(nodes) + 1;
+//   down -- the reverse order (parents first, heaviest child last); a node's posterior
+//           lives in a slot until its last child has read it (that child may reuse it).
+// The boolean passes run on an LDS copy of the wave's state sets; topology, the row /
+// column supports and (when it fits) the transition matrices are LDS copies too.  Global
+// traffic per site: the subtree likelihoods L[node][state] written once (up) and read once
+// (down, prefetched four nodes ahead: the addresses come from the schedule, not from data);
+// the message M = P L is recomputed in the down pass with the fma order of the up pass.
+// ---------------------------------------------------------------------------
+struct lane_plan {
+    std::vector<int> ops;        // 4 ints per op: node, in | out << 8 | merge << 16, pslot | oslot << 8, 0
+    int nslots = 1;
+};
+
+static bool build_lane_plan(int64_t nnodes, const int64_t *idx, const int64_t *ptr,
+                            const std::vector<int> &parent, lane_plan &plan)
+{
+    const size_t nn = (size_t)nnodes;
+    std::vector<int> size(nn, 1), first(nn, 0), nch(nn, 0);
+    for (int64_t v = nnodes - 1; v >= 1; --v) size[(size_t)parent[(size_t)v]] += size[(size_t)v];
+    std::vector<std::vector<int>> kids(nn);
+    for (int64_t v = 0; v < nnodes; ++v) {
+        for (int64_t e = ptr[v]; e < ptr[v + 1]; ++e) kids[(size_t)v].push_back((int)idx[e]);
+        std::stable_sort(kids[(size_t)v].begin(), kids[(size_t)v].end(),
+                         [&](int a, int b) { return size[(size_t)a] > size[(size_t)b]; });
+        nch[(size_t)v] = (int)kids[(size_t)v].size();
+        if (!kids[(size_t)v].empty()) first[(size_t)kids[(size_t)v][0]] = 1;
+    }
+    std::vector<int> order;
+    order.reserve(nn);
+    {
+        std::vector<std::pair<int, int>> stack;      // node, next child position
+        stack.emplace_back(0, 0);
+        while (!stack.empty()) {
+            auto &top = stack.back();
+            if (top.second < nch[(size_t)top.first]) {
+                const int c = kids[(size_t)top.first][(size_t)top.second++];
+                stack.emplace_back(c, 0);
+            } else {
+                order.push_back(top.first);
+                stack.pop_back();
+            }
+        }
+    }
+    if (order.size() != nn) return false;
+    plan.ops.assign(nn * 4, 0);
+    int sp = 0, hi = 0;
+    for (size_t i = 0; i < nn; ++i) {
+        const int v = order[i];
+        int in = 255, out = 255, merge = 0;
+        if (nch[(size_t)v] > 0) in = --sp;
+        if (v != 0) {
+            if (first[(size_t)v]) out = sp++;
+            else { out = sp - 1; merge = 1; }
+        }
+        hi = std::max(hi, sp);
+        if (sp < 0 || hi > 250) return false;
+        plan.ops[i * 4 + 0] = v;
+        plan.ops[i * 4 + 1] = in | out << 8 | merge << 16;
+    }
+    std::vector<int> slot(nn, 255), remaining(nch);
+    std::vector<char> used;
+    auto alloc = [&]() {
+        for (size_t k = 0; k < used.size(); ++k)
+            if (!used[k]) { used[k] = 1; return (int)k; }
+        used.push_back(1);
+        return (int)used.size() - 1;
+    };
+    for (size_t r = 0; r < nn; ++r) {
+        const size_t i = nn - 1 - r;
+        const int v = order[i];
+        int ps = 255;
+        if (v != 0) {
+            const int p = parent[(size_t)v];
+            ps = slot[(size_t)p];
+            if (--remaining[(size_t)p] == 0) used[(size_t)ps] = 0;
+        }
+        if (nch[(size_t)v] > 0) slot[(size_t)v] = alloc();
+        if (used.size() > 250) return false;
+        plan.ops[i * 4 + 2] = ps | slot[(size_t)v] << 8;
+    }
+    plan.nslots = std::max<int>(std::max<int>(hi, (int)used.size()), 1);
+    return true;
+}
+
+template <int N, bool PLDS>
+__global__ void __launch_bounds__(64)
+expect_lane_lds_kernel(int nnodes, long nsites, long S, int nslots, const int4 *__restrict__ ops,
+                       const int *__restrict__ parent, const double *__restrict__ esd,
+                       const unsigned char *__restrict__ rowbits,
+                       const unsigned char *__restrict__ colbits,
+                       const double *__restrict__ root_distn, const double *__restrict__ weights,
+                       const unsigned char *__restrict__ sets, double *__restrict__ Lb,
+                       double *__restrict__ part, int *__restrict__ status,
+                       unsigned long long *__restrict__ trace)
+{
+#define RT_STAMP(k)                                                                   \
+    if (trace && blockIdx.x == 0 && threadIdx.x == 0) trace[k] = __builtin_readcyclecounter()
+    RT_STAMP(0);
+    constexpr int NN = N * N;
+    extern __shared__ double lds_raw[];
+    double *slots = lds_raw;                                        // [slot][state][lane]
+    double *lP = slots + (size_t)nslots * N * 64;                   // [node][a][b] when PLDS
+    int4 *lops = (int4 *)(lP + (PLDS ? ((size_t)nnodes * NN + 1) / 2 * 2 : 0));   // 16 B aligned
+    int *lpar = (int *)(lops + nnodes);
+    unsigned char *lrb = (unsigned char *)(lpar + nnodes);
+    unsigned char *lcb = lrb + (size_t)nnodes * N;
+    unsigned char *lsets = lcb + (size_t)nnodes * N;                 // [node][lane]
+    const int lane = threadIdx.x;
+    const long site = (long)blockIdx.x * 64 + lane;
+    const bool live = site < nsites;
+    const size_t row = (size_t)S;
+    for (int i = lane; i < nnodes; i += 64) {
+        lops[i] = ops[i];
+        lpar[i] = parent[i];
+    }
+    for (int i = lane; i < nnodes * N; i += 64) {
+        lrb[i] = rowbits[i];
+        lcb[i] = colbits[i];
+    }
+    if (PLDS)
+        for (int i = lane; i < nnodes * NN; i += 64) lP[i] = esd[i];
+    for (int v = 0; v < nnodes; ++v) lsets[v * 64 + lane] = sets[(size_t)v * S + site];
+    __syncthreads();
+    RT_STAMP(1);
+    // ---- backward / forward boolean passes on the LDS copy ----
+    for (int v = nnodes - 1; v >= 1; --v) {
+        const unsigned sv = lsets[v * 64 + lane];
+        unsigned keep = 0;
+#pragma unroll
+        for (int a = 0; a < N; ++a) keep |= (lrb[v * N + a] & sv) ? 1u << a : 0u;
+        lsets[lpar[v] * 64 + lane] &= (unsigned char)keep;
+    }
+    for (int v = 1; v < nnodes; ++v) {
+        const unsigned pv = lsets[lpar[v] * 64 + lane];
+        unsigned reach = 0;
+#pragma unroll
+        for (int b = 0; b < N; ++b) reach |= (lcb[v * N + b] & pv) ? 1u << b : 0u;
+        lsets[v * 64 + lane] &= (unsigned char)reach;
+    }
+    RT_STAMP(2);
+    // ---- upward pass: post-order stack program ----
+    double lroot[N];
+#pragma unroll
+    for (int a = 0; a < N; ++a) lroot[a] = 0.0;
+    for (int i = 0; i < nnodes; ++i) {
+        const int4 op = lops[i];
+        const int v = __builtin_amdgcn_readfirstlane(op.x);
+        const int up = __builtin_amdgcn_readfirstlane(op.y);
+        const int in = up & 255, outs = (up >> 8) & 255;
+        const unsigned sv = lsets[v * 64 + lane];
+        double l[N];
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            const double acc = in == 255 ? 1.0 : slots[((size_t)in * N + a) * 64 + lane];
+            l[a] = (sv >> a) & 1u ? acc : 0.0;
+            Lb[((size_t)v * N + a) * row + site] = l[a];
+        }
+        if (outs == 255) {
+#pragma unroll
+            for (int a = 0; a < N; ++a) lroot[a] = l[a];
+            continue;
+        }
+        const double *Pv = PLDS ? lP + (size_t)v * NN : esd + (size_t)v * NN;
+        const bool merge = (up >> 16) & 1;
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            double sum = 0.0;
+#pragma unroll
+            for (int b = 0; b < N; ++b) sum = fma(Pv[a * N + b], l[b], sum);
+            double *dst = slots + ((size_t)outs * N + a) * 64 + lane;
+            *dst = merge ? *dst * sum : sum;
+        }
+    }
+    RT_STAMP(3);
+    // ---- downward pass (reverse order) + site sums ----
+    const double wt = (live && weights) ? weights[site] : (live ? 1.0 : 0.0);
+    double *out = part + (size_t)blockIdx.x * nnodes * NN;
+    bool bad = false;
+    {
+        const int rs = (__builtin_amdgcn_readfirstlane(lops[nnodes - 1].z) >> 8) & 255;
+        double w[N], tot = 0.0;
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            w[a] = lroot[a] * (root_distn ? root_distn[a] : 1.0);
+            tot += w[a];
+        }
+        if (!(tot > 0.0)) bad = true;
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            const double d = tot > 0.0 ? w[a] / tot : 0.0;
+            if (rs != 255) slots[((size_t)rs * N + a) * 64 + lane] = d;
+            double r = live ? wt * d : 0.0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
+#pragma unroll
+            for (int b = 0; b < N; ++b)
+                if (lane == 0) out[a * N + b] = b == 0 ? r : 0.0;
+        }
+    }
+    RT_STAMP(4);
+    constexpr int PF = 4;                     // nodes of L in flight ahead of the one in work
+    double pre[PF][N];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+        const int i = nnodes - 2 - j;
+        const int v = i >= 0 ? __builtin_amdgcn_readfirstlane(lops[i].x) : 0;
+#pragma unroll
+        for (int a = 0; a < N; ++a) pre[j][a] = Lb[((size_t)v * N + a) * row + site];
+    }
+    for (int base = nnodes - 2; base >= 0; base -= PF) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int i = base - j;
+            if (i < 0) break;
+            const int4 op = lops[i];
+            const int v = __builtin_amdgcn_readfirstlane(op.x);
+            const int dn = __builtin_amdgcn_readfirstlane(op.z);
+            const int ps = dn & 255, os = (dn >> 8) & 255;
+            double lv[N];
+#pragma unroll
+            for (int a = 0; a < N; ++a) lv[a] = pre[j][a];
+            {
+                const int nx = i - PF;
+                const int vn = nx >= 0 ? __builtin_amdgcn_readfirstlane(lops[nx].x) : 0;
+#pragma unroll
+                for (int a = 0; a < N; ++a) pre[j][a] = Lb[((size_t)vn * N + a) * row + site];
+            }
+            const double *Pv = PLDS ? lP + (size_t)v * NN : esd + (size_t)v * NN;
+            double u[N];
+#pragma unroll
+            for (int a = 0; a < N; ++a) {
+                double den = 0.0;
+#pragma unroll
+                for (int b = 0; b < N; ++b) den = fma(Pv[a * N + b], lv[b], den);
+                const double pa = slots[((size_t)ps * N + a) * 64 + lane];
+                u[a] = 0.0;
+                if (pa != 0.0) {
+                    if (den > 0.0) u[a] = pa / den;
+                    else bad = true;
+                }
+            }
+            if (os != 255) {
+#pragma unroll
+                for (int b = 0; b < N; ++b) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int a = 0; a < N; ++a) acc = fma(u[a], Pv[a * N + b], acc);
+                    slots[((size_t)os * N + b) * 64 + lane] = acc * lv[b];
+                }
+            }
+            constexpr int P = NN <= 1 ? 1 : NN <= 2 ? 2 : NN <= 4 ? 4 : NN <= 8 ? 8 : NN <= 16 ? 16
+                              : NN <= 32 ? 32 : 64;
+            constexpr int K = P == 1 ? 0 : P == 2 ? 1 : P == 4 ? 2 : P == 8 ? 3 : P == 16 ? 4
+                              : P == 32 ? 5 : 6;
+            double x[P];
+#pragma unroll
+            for (int e = 0; e < P; ++e) x[e] = 0.0;
+#pragma unroll
+            for (int a = 0; a < N; ++a) {
+                const double ua = live ? wt * u[a] : 0.0;
+#pragma unroll
+                for (int b = 0; b < N; ++b) x[a * N + b] = ua * lv[b];
+            }
+            wave_sum_many<P>(x, lane);
+            const int ent = (lane >> (6 - K)) & (P - 1);
+            if ((lane & ((1 << (6 - K)) - 1)) == 0 && ent < NN)
+                out[(size_t)v * NN + ent] = Pv[ent] != 0.0 ? x[0] : 0.0;
+        }
+    }
+    if (status && live) status[site] = bad ? 2 : 0;
+    RT_STAMP(5);
+#undef RT_STAMP
+}
+
 int expectation_weights_lane(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t nsites,
         const int64_t *idx, const int64_t *ptr, const double *esd, const double *root_distn,
         const int64_t *state_mask, int64_t nobs, const std::vector<int> &obs_idx, int kind,
@@ -912,12 +1203,27 @@ int expectation_weights_lane(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t nsi
                 }
     const size_t arr = (size_t)nnodes * n * S * 8;
     const size_t ni = (size_t)(nnodes > 1 ? nnodes - 1 : 1);
+    // the LDS-resident kernel when its working set fits the default 64 KB of a workgroup
+    // (RAOTEH_EXPECT_GLOBAL=1: the global-memory kernel, for A/B runs)
+    lane_plan lp;
+    size_t lds_bytes = 0;
+    bool use_lds = !getenv("RAOTEH_EXPECT_GLOBAL") && build_lane_plan(nnodes, idx, ptr, parent, lp);
+    bool p_in_lds = false;
+    if (use_lds) {
+        const size_t fixed = (size_t)lp.nslots * n * 512 + (size_t)nnodes * (16 + 4 + 2 * n + 64);
+        const size_t pbytes = ((size_t)nnodes * nn + 1) / 2 * 2 * 8;
+        if (fixed > 65536) use_lds = false;
+        else if (fixed + pbytes <= 65536) { p_in_lds = true; lds_bytes = fixed + pbytes; }
+        else lds_bytes = fixed;
+    }
     scratch_plan plan;
+    const size_t o_ops = plan.take((size_t)nnodes * 16), o_trace = plan.take(64);
     const size_t o_idx = plan.take(ni * 8), o_ptr = plan.take((size_t)(nnodes + 1) * 8);
     const size_t o_esd = plan.take(wcount * 8), o_par = plan.take((size_t)nnodes * 4);
     const size_t o_rb = plan.take((size_t)nnodes * n), o_cb = plan.take((size_t)nnodes * n);
     const size_t o_sets = plan.take((size_t)nnodes * S);
-    const size_t o_M = plan.take(arr), o_L = plan.take(arr), o_D = plan.take(arr);
+    const size_t o_M = plan.take(use_lds ? 8 : arr), o_L = plan.take(arr);
+    const size_t o_D = plan.take(use_lds ? 8 : arr);
     const size_t o_root = plan.take((size_t)n * 8), o_w = plan.take((size_t)nsites * 8);
     const size_t o_st = plan.take((size_t)S * 4);
     const size_t o_part = plan.take((size_t)G * wcount * 8), o_out = plan.take(wcount * 8);
@@ -936,6 +1242,12 @@ int expectation_weights_lane(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t nsi
     double *d_w = site_weights ? (double *)(base + o_w) : nullptr;
     double *d_part = (double *)(base + o_part), *d_out = (double *)(base + o_out);
     hipStream_t st = ctx->stream;
+    int4 *d_ops = (int4 *)(base + o_ops);
+    // RAOTEH_EXPECT_TRACE=1: shader-clock stamps of workgroup 0 at the phase boundaries
+    unsigned long long *d_trace =
+        (use_lds && getenv("RAOTEH_EXPECT_TRACE")) ? (unsigned long long *)(base + o_trace) : nullptr;
+    if (use_lds)
+        RT_HIP(hipMemcpyAsync(d_ops, lp.ops.data(), (size_t)nnodes * 16, hipMemcpyHostToDevice, st));
     if (nnodes > 1)
         RT_HIP(hipMemcpyAsync(d_idx, idx, (size_t)(nnodes - 1) * 8, hipMemcpyHostToDevice, st));
     RT_HIP(hipMemcpyAsync(d_ptr, ptr, (size_t)(nnodes + 1) * 8, hipMemcpyHostToDevice, st));
@@ -961,8 +1273,20 @@ int expectation_weights_lane(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t nsi
             hipLaunchKernelGGL(sets_apply_obs_kernel, dim3(2048), dim3(256), 0, st, (int)n,
                                (long)nsites, S, (int)nobs, d_obsn, kind, d_data, d_sets);
     }
+#define RT_EXPECT_LDS(NV)                                                                    \
+    do {                                                                                      \
+        if (p_in_lds)                                                                         \
+            hipLaunchKernelGGL((expect_lane_lds_kernel<NV, true>), dim3((unsigned)G), dim3(64), \
+                               lds_bytes, st, (int)nnodes, (long)nsites, S, lp.nslots, d_ops,  \
+                               d_par, d_esd, d_rb, d_cb, d_root, d_w, d_sets, d_L, d_part, d_st, d_trace); \
+        else                                                                                  \
+            hipLaunchKernelGGL((expect_lane_lds_kernel<NV, false>), dim3((unsigned)G), dim3(64), \
+                               lds_bytes, st, (int)nnodes, (long)nsites, S, lp.nslots, d_ops,  \
+                               d_par, d_esd, d_rb, d_cb, d_root, d_w, d_sets, d_L, d_part, d_st, d_trace); \
+    } while (0)
 #define RT_EXPECT_LANE(NV)                                                                   \
-    hipLaunchKernelGGL(expect_lane_kernel<NV>, dim3((unsigned)G), dim3(64), 0, st, (int)nnodes, \
+    if (use_lds) RT_EXPECT_LDS(NV);                                                          \
+    else hipLaunchKernelGGL(expect_lane_kernel<NV>, dim3((unsigned)G), dim3(64), 0, st, (int)nnodes, \
                        (long)nsites, S, d_par, d_idx, d_ptr, d_esd, d_rb, d_cb, d_root, d_w,   \
                        d_sets, d_M, d_L, d_D, d_part, d_st)
     switch ((int)n) {
@@ -976,12 +1300,20 @@ int expectation_weights_lane(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t nsi
     default: RT_EXPECT_LANE(8); break;
     }
 #undef RT_EXPECT_LANE
+#undef RT_EXPECT_LDS
     hipLaunchKernelGGL(sum_parts_wide_kernel, dim3((unsigned)((wcount + 3) / 4)), dim3(256), 0,
                        st, G, (long)wcount, d_part, d_out);
     RT_HIP(hipGetLastError());
     RT_HIP(hipMemcpyAsync(edge_weights, d_out, wcount * 8, hipMemcpyDeviceToHost, st));
     if (status) RT_HIP(hipMemcpyAsync(status, d_st, (size_t)nsites * 4, hipMemcpyDeviceToHost, st));
     RT_HIP(hipStreamSynchronize(st));
+    if (d_trace) {
+        unsigned long long t[6];
+        RT_HIP(hipMemcpy(t, d_trace, sizeof t, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[raoteh_amd] expect trace (clocks): fill %llu, sets %llu, up %llu, root %llu, "
+                "down %llu; %d slots, %zu B of LDS\n", t[1] - t[0], t[2] - t[1], t[3] - t[2],
+                t[4] - t[3], t[5] - t[4], lp.nslots, lds_bytes);
+    }
     return RT_OK;
 }
 

@@ -992,6 +992,76 @@ def test_expected_history_statistics_batch(ra):
     np.testing.assert_array_equal(d3, d4)
 
 
+def _random_csr(rng, nnodes, shape):
+    """children lists of a random tree with parent < child labels."""
+    parent = np.zeros(nnodes, dtype=np.int64)
+    for v in range(1, nnodes):
+        if shape == 'caterpillar':
+            parent[v] = v - 1 if v % 2 else max(v - 2, 0)     # spine of even labels, one leaf each
+        elif shape == 'star':
+            half = max(2, nnodes // 2)
+            parent[v] = 0 if v < half else rng.randint(1, half)
+        else:
+            parent[v] = rng.randint(max(0, v - 6), v)
+    kids = [[] for _ in range(nnodes)]
+    for v in range(1, nnodes):
+        kids[parent[v]].append(v)
+    indices = np.array([c for k in kids for c in k], dtype=np.int64)
+    indptr = np.cumsum([0] + [len(k) for k in kids]).astype(np.int64)
+    return indices, indptr, parent
+
+
+@pytest.mark.parametrize('shape', ['random', 'caterpillar', 'star'])
+def test_expectation_weights_kernels_agree_on_ragged_trees(ra, shape, monkeypatch):
+    """The three device forms of rt_mjp_esd_expectation_weights -- the LDS stack
+    program (heaviest child first), the global-memory lane kernel and the per-pass
+    kernels -- on multifurcating, caterpillar and star trees, sparse transition
+    supports, restricted internal nodes and a site the data exclude; and the
+    per-pass form is the one checked against the oracle above."""
+    rng = np.random.RandomState({'random': 1, 'caterpillar': 2, 'star': 3}[shape])
+    for n, nnodes, nb in ((2, 9, 70), (3, 40, 130), (4, 127, 200), (5, 33, 64), (7, 21, 65),
+                          (8, 60, 129), (4, 1, 5), (4, 2, 64)):
+        indices, indptr, parent = _random_csr(rng, nnodes, shape)
+        esd = rng.uniform(0.05, 1.0, size=(nnodes, n, n))
+        esd[rng.uniform(size=esd.shape) < 0.2] = 0.0
+        esd[:, np.arange(n), np.arange(n)] += 0.5
+        esd /= esd.sum(axis=2, keepdims=True)
+        esd[0] = 0.0
+        mask = np.ones((nb, nnodes, n), dtype=np.int64)
+        leaves = np.setdiff1d(np.arange(nnodes), parent[1:]) if nnodes > 1 else np.array([0])
+        st = rng.randint(n, size=(nb, len(leaves)))
+        mask[:, leaves, :] = 0
+        mask[np.arange(nb)[:, None], leaves[None, :], st] = 1
+        mask[::5, leaves[0], :] |= rng.randint(2, size=n)          # ambiguous leaves
+        if nnodes > 3:
+            mask[::3, 1, : n // 2] = 0                                 # a restricted internal node
+        if nb > 9:
+            mask[9, leaves[-1], :] = 0                                 # an impossible site
+        root_distn = rng.dirichlet(np.ones(n))
+        w = rng.uniform(0.5, 2.0, size=nb)
+        got = {}
+        for name, env in (('lds', None), ('global', 'RAOTEH_EXPECT_GLOBAL'),
+                          ('legacy', 'RAOTEH_EXPECT_LEGACY')):
+            if env:
+                monkeypatch.setenv(env, '1')
+            got[name] = ra.ctx.expectation_weights(indices, indptr, esd, root_distn, mask.copy(),
+                                                   site_weights=w)
+            if env:
+                monkeypatch.delenv(env)
+        W, rp, status = got['legacy']
+        assert status[9] == 2 if nb > 9 else not status.any()
+        ok = status == 0
+        assert ok.any()
+        for name in ('lds', 'global'):
+            W2, rp2, st2 = got[name]
+            np.testing.assert_array_equal(st2, status, err_msg='%s n=%d' % (name, n))
+            scale = np.abs(W).max() or 1.0
+            np.testing.assert_allclose(W2, W, rtol=1e-11, atol=1e-13 * scale,
+                                       err_msg='%s n=%d nnodes=%d' % (name, n, nnodes))
+            np.testing.assert_allclose(rp2, rp, rtol=1e-12, atol=1e-300)
+            assert not W2[0].any()
+
+
 @pytest.mark.parametrize('nsites', [100000, 400001, 3000])
 def test_relaunch_and_clone_give_the_same_totals(ra, nsites):
     """Totals are bitwise reproducible launch after launch, and a clone used the

@@ -207,6 +207,19 @@ def test_tree_specialised_mfma_source_is_generated_on_the_host(monkeypatch):
     obs = np.array([ta.node_to_index[v] for v in leaves], dtype=np.int64)
     p64 = ctypes.POINTER(ctypes.c_int64)
     buf = ctypes.create_string_buffer(1 << 22)
+    # 4x4x4-block variant (the default where its MFMA count is below the 16x16x4
+    # family's padded one): KS * KS block MFMAs per step and tile
+    monkeypatch.setenv('RAOTEH_JIT_QUAD', '1')
+    for n, tiles in ((5, 1), (20, 2), (32, 2)):
+        monkeypatch.setenv('RAOTEH_JIT_TILES', str(tiles))
+        _lib.check(_lib.lib().rt_jit_source(
+            ta.nnodes, ta.indices.ctypes.data_as(p64), ta.indptr.ctypes.data_as(p64),
+            n, len(obs), obs.ctypes.data_as(p64), 2, buf, len(buf)))
+        src = buf.value.decode()
+        ks = (n + 3) // 4
+        assert src.count('__builtin_amdgcn_mfma_f64_4x4x4f64') == (ta.nnodes - 1) * ks * ks * tiles
+        assert '__builtin_amdgcn_mfma_f64_16x16x4f64' not in src
+    monkeypatch.setenv('RAOTEH_JIT_QUAD', '0')
     for n, tiles in ((5, 1), (20, 3), (32, 2)):
         monkeypatch.setenv('RAOTEH_JIT_TILES', str(tiles))
         _lib.check(_lib.lib().rt_jit_source(
