@@ -79,6 +79,18 @@ void emit_matvec(std::ostringstream &o, int n, int rec, const std::string &x,
 
 }  // namespace
 
+// A pair load (rt_d2) of which only .x is used -- the last k-pair when the number of
+// k-steps is odd -- is emitted as an 8-byte load.  Loading the dead half too is not
+// harmless: the register allocator hands the dead registers to another value while the
+// load is still in flight, and the write-after-write hazard costs an s_waitcnt vmcnt(0)
+// behind the prefetches just issued -- one full memory round trip per leaf step of the
+// 20-state kernel (found with the step stamps of tools/trace_c5.py).
+static std::string half_pair_load(const std::string &addr, bool nontemporal)
+{
+    const std::string p = "(const __attribute__((address_space(1))) double *)&" + addr;
+    return "{" + (nontemporal ? "__builtin_nontemporal_load(" + p + ")" : "*(" + p + ")") + ", 0.0}";
+}
+
 // Source of the kernel for one schedule.  ops: post-order schedule with .obs
 // filled in (rt_sites::ops); D: prefetch distance in stream positions.
 // compact = 1 / 2: the batch is resident as one byte per observed node and site --
@@ -188,9 +200,15 @@ std::string rt_jit_lane_source(const std::vector<rt_op> &ops, int n, int K, int 
                   << (long)(k / 4) * S << "]);\n";
             return;
         }
-        for (int h = 0; h < hp; ++h)
-            o << "    const rt_d2 o" << k << "_" << h << " = " << (nt ? "__builtin_nontemporal_load(&g[" : "g[")
-              << ((long)(noload ? 0 : k) * hp + h) * S << (nt ? "]);\n" : "];\n");
+        for (int h = 0; h < hp; ++h) {
+            const long at = ((long)(noload ? 0 : k) * hp + h) * S;
+            if ((n & 1) && h == hp - 1)
+                o << "    const rt_d2 o" << k << "_" << h << " = "
+                  << half_pair_load("g[" + std::to_string(at) + "]", nt) << ";\n";
+            else
+                o << "    const rt_d2 o" << k << "_" << h << " = "
+                  << (nt ? "__builtin_nontemporal_load(&g[" : "g[") << at << (nt ? "]);\n" : "];\n");
+        }
     };
     // Between two steps stands a scheduling barrier (no instruction): the
     // compiler's scheduler, left alone, sinks every LDS read to just before its
@@ -396,6 +414,18 @@ std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int 
       << " leaves / " << LA << " P records\n";
     o << "typedef double rt_d2 __attribute__((ext_vector_type(2)));\n";
     o << "typedef double rt_d4 __attribute__((ext_vector_type(4)));\n";
+    // RAOTEH_JIT_TRACE=<workgroup>: diagnostics (tools/trace_c5.py) -- that wave stamps the
+    // shader clock at the start of every step, before its first MFMA and after its last
+    // MFMA has been issued: rt_trace[step][3]
+    const char *trace_env = getenv("RAOTEH_JIT_TRACE");
+    const bool trace = trace_env != nullptr;
+    const long trace_wg = trace ? atol(trace_env) : 0;
+    if (trace) o << "__device__ unsigned long long rt_trace[" << (nrec + 1) * 3 << "];\n";
+    auto stamp = [&](int i, int which) {
+        if (!trace) return;
+        o << "    if (blockIdx.x == " << trace_wg << " && lane == 0) rt_trace[" << i * 3 + which
+          << "] = __builtin_readcyclecounter();\n";
+    };
     // up to two tiles per wave: two waves per SIMD (256 VGPRs); more tiles: one wave
     // per SIMD and the whole 512-register file (accumulators of T tiles)
     const char *weu = getenv("RAOTEH_JIT_WAVES_EU");      // diagnostics: "1, 1" / "2, 2"
@@ -427,8 +457,11 @@ std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int 
     for (int t = 0; t < T; ++t) {
         o << "    const long tile" << t << " = tbase + " << t << ";\n";
         // tiles past the end re-read the last one; their results are dropped
+        // RAOTEH_JIT_FAKE_LEAFMAJOR: timing experiment only (wrong results): address the
+        // observations as if they were stored [leaf][tile] instead of [tile][leaf]
         o << "    rt_glb2 g" << t << " = (rt_glb2)obs + (size_t)(tile" << t << " < nblocks ? tile" << t
-          << " : nblocks - 1) * " << (long)K * KP * 64 << " + lane;\n";
+          << " : nblocks - 1) * " << (getenv("RAOTEH_JIT_FAKE_LEAFMAJOR") ? (long)KP * 64 : (long)K * KP * 64)
+          << " + lane;\n";
     }
     // the root weights are loaded where the root step uses them, not here: KS doubles
     // that stay live through the whole walk are the first values the register allocator
@@ -452,6 +485,16 @@ std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int 
     auto emit_obs_load = [&](int k) {
         for (int t = 0; t < T; ++t)
             for (int q = 0; q < KP; ++q)
+                if (getenv("RAOTEH_JIT_FAKE_LEAFMAJOR"))
+                    o << "    const rt_d2 o" << k << "_" << t << "_" << q
+                      << " = __builtin_nontemporal_load(&g" << t << "[" << (long)k * KP * 64
+                      << " * nblocks + " << q * 64 << "]);\n";
+                else if ((KS & 1) && q == KP - 1)
+                    o << "    const rt_d2 o" << k << "_" << t << "_" << q << " = "
+                      << half_pair_load("g" + std::to_string(t) + "[" +
+                                        std::to_string(((long)k * KP + q) * 64) + "]", true)
+                      << ";\n";
+                else
                 o << "    const rt_d2 o" << k << "_" << t << "_" << q
                   << " = __builtin_nontemporal_load(&g" << t << "[" << ((long)k * KP + q) * 64
                   << "]);\n";     // read once: keep L2 for the A fragments
@@ -464,9 +507,14 @@ std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int 
             return;
         }
         for (int m = 0; m < NT; ++m)
-            for (int q = 0; q < KP; ++q)
-                o << "    const rt_d2 A" << i << "_" << m << "_" << q << " = ag["
-                  << (((long)i * NT + m) * KP + q) * 64 << "];\n";
+            for (int q = 0; q < KP; ++q) {
+                const long at = (((long)i * NT + m) * KP + q) * 64;
+                if ((KS & 1) && q == KP - 1)
+                    o << "    const rt_d2 A" << i << "_" << m << "_" << q << " = "
+                      << half_pair_load("ag[" + std::to_string(at) + "]", false) << ";\n";
+                else
+                    o << "    const rt_d2 A" << i << "_" << m << "_" << q << " = ag[" << at << "];\n";
+            }
     };
     for (int k = 0; k < std::min(D, K); ++k) emit_obs_load(k);
     for (int i = 0; i < std::min(LA, nrec); ++i)
@@ -493,6 +541,7 @@ std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int 
         }
         if (!getenv("RAOTEH_JIT_NO_SCHED_BARRIER"))
             o << "    __builtin_amdgcn_sched_barrier(0);\n";
+        stamp(i, 0);
         if (i + LA < nrec && ops[(size_t)(i + LA)].dst >= 0) emit_a_load(i + LA);
         if (op.obs >= 0 && op.obs + D < K) emit_obs_load(op.obs + D);
         if (op.dst >= 0) dep = "a" + std::to_string(op.dst & 255) + "_0_0";
@@ -535,15 +584,38 @@ std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int 
             // chains advance side by side, k-step outermost
             for (int t = 0; t < T; ++t)
                 for (int rq = 0; rq < KS; ++rq) o << "    double c" << t << "_" << rq << " = 0.0;\n";
-            for (int kk = 0; kk < KS; ++kk)
-                for (int rq = 0; rq < KS; ++rq) {
-                    o << "    const double Q" << i << "_" << rq << "_" << kk << " = qa" << (i & 1)
-                      << "[" << (rq * KS + kk) * 16 << " + alane];\n";
-                    for (int t = 0; t < T; ++t)
-                        o << "    c" << t << "_" << rq << " = __builtin_amdgcn_mfma_f64_4x4x4f64(Q"
-                          << i << "_" << rq << "_" << kk << ", x" << t << "_" << kk << ", c" << t
-                          << "_" << rq << ", 0, 0, 0);\n";
-                }
+            // The block reads are issued QA blocks ahead of their MFMAs and pinned there
+            // (sched_barrier(0) after every block): left to itself the scheduler, with the
+            // register file full, put each read right in front of its use and the wave
+            // waited out an LDS round trip 13 times per step with the matrix pipe drained
+            // (2 650 cycles per step against 1 650 of MFMA work at T = 4).
+            // RAOTEH_JIT_QAHEAD=0: the old placement.
+            const char *qa_env = getenv("RAOTEH_JIT_QAHEAD");
+            const int QA = qa_env ? atoi(qa_env) : 4;
+            const int NB = KS * KS;
+            auto emit_q_read = [&](int b) {
+                const int kk = b / KS, rq = b % KS;
+                o << "    const double Q" << i << "_" << rq << "_" << kk << " = qa" << (i & 1)
+                  << "[" << (rq * KS + kk) * 16 << " + alane];\n";
+            };
+            for (int b = 0; b < std::min(QA, NB); ++b) emit_q_read(b);
+            if (QA > 0) o << "    __builtin_amdgcn_sched_barrier(0);\n";
+            if (trace) {
+                // the stamp after the operands: x of every tile is in registers here
+                o << "    asm volatile(\"\" :: \"v\"(x" << T - 1 << "_" << KS - 1 << "));\n";
+                stamp(i, 1);
+            }
+            for (int b = 0; b < NB; ++b) {
+                const int kk = b / KS, rq = b % KS;
+                if (QA <= 0) emit_q_read(b);
+                else if (b + QA < NB) emit_q_read(b + QA);
+                for (int t = 0; t < T; ++t)
+                    o << "    c" << t << "_" << rq << " = __builtin_amdgcn_mfma_f64_4x4x4f64(Q"
+                      << i << "_" << rq << "_" << kk << ", x" << t << "_" << kk << ", c" << t
+                      << "_" << rq << ", 0, 0, 0);\n";
+                if (QA > 0) o << "    __builtin_amdgcn_sched_barrier(0);\n";
+            }
+            stamp(i, 2);
             // the next step's blocks (fetched at the top of this step) go to the other buffer
             if (i + LA < nrec && ops[(size_t)(i + LA)].dst >= 0) emit_q_park(i + LA);
             const int d = op.dst & 255;
@@ -574,6 +646,7 @@ std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int 
         o << "    }\n";
     }
 
+    stamp(nrec, 0);
     // lanes 0..15 own the 16 sites of a tile (finish_site / wave_sum of prune.hip)
     for (int t = 0; t < T; ++t) {
         o << "    {\n"
@@ -687,9 +760,14 @@ std::string rt_jit_mfma_split_source(const std::vector<rt_op> &ops, int n, int K
         }
     };
     auto emit_a_load = [&](int i) {
-        for (int q = 0; q < KP; ++q)
-            o << "    const rt_d2 A" << i << "_" << q << " = ag[" << ((long)i * NT * KP + q) * 64
-              << "];\n";
+        for (int q = 0; q < KP; ++q) {
+            const long at = ((long)i * NT * KP + q) * 64;
+            if ((KS & 1) && q == KP - 1)
+                o << "    const rt_d2 A" << i << "_" << q << " = "
+                  << half_pair_load("ag[" + std::to_string(at) + "]", false) << ";\n";
+            else
+                o << "    const rt_d2 A" << i << "_" << q << " = ag[" << at << "];\n";
+        }
     };
     for (int k = 0; k < std::min(D, K); ++k) emit_obs_load(k);
     for (int i = 0; i < std::min(LA, nrec); ++i)
@@ -1013,9 +1091,14 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
     }
     auto emit_a_load = [&](std::ostream &os, int k) {           // k = issue index
         const int rec = rec_of_node[(size_t)st[(size_t)k].op.node];
-        for (int q = 0; q < KP; ++q)
-            os << "    const rt_d2 A" << k << "_" << q << " = ag[" << ((long)rec * NT * KP + q) * 64
-               << "];\n";
+        for (int q = 0; q < KP; ++q) {
+            const long at = ((long)rec * NT * KP + q) * 64;
+            if ((KS & 1) && q == KP - 1)
+                os << "    const rt_d2 A" << k << "_" << q << " = "
+                   << half_pair_load("ag[" + std::to_string(at) + "]", false) << ";\n";
+            else
+                os << "    const rt_d2 A" << k << "_" << q << " = ag[" << at << "];\n";
+        }
     };
     // own rows of x for issue step k
     auto emit_x = [&](std::ostream &os, int k) {
