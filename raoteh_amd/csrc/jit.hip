@@ -395,9 +395,271 @@ std::string rt_jit_lane_source(const std::vector<rt_op> &ops, int n, int K, int 
 // quad-block table (rt_model::d_Pquad), each lane fetching element (lane >> 4, lane & 3)
 // of a 16-double block.  (The instruction's A-broadcast controls cbsz / abid have no
 // effect on the f64 form -- probed -- so the block is fetched replicated.)
+// ---------------------------------------------------------------------------
+// 4x4x4-block form, two tile groups in turn ("ping-pong", T even)
+// ---------------------------------------------------------------------------
+// One wave, one step: chain (T * KS^2 block MFMAs), then fold the result into the parent's
+// accumulator, prepare the next operands (accumulator x observation), park the next blocks
+// of P -- 450 to 900 cycles of the 2 500 a step took at T = 4 with the matrix pipe idle
+// (step stamps, tools/trace_c5.py).  Two waves per SIMD (T = 2) did not hide it: both run
+// the same program from the same start and stay in phase -- both in their chains (sharing
+// the pipe), then both outside (pipe idle): 2 C + E per pair of steps, the same as one
+// wave with twice the tiles (measured: 68 us either way; 60 us with the observations
+// served from L2, so the HBM stream is not what holds it).  Here the wave's T tiles are
+// two groups, and the program itself is out of phase: while group A's chain of step i
+// runs, the statements of group B's fold (step i - 1) and operand preparation (step i)
+// are issued one or two behind each block of MFMAs; under group B's chain, group A's
+// fold of step i, the park of the next blocks of P and group A's operands of step i + 1.
+// Any step order works (the other group's chain always stands between a group's chain
+// and its next one).  Same k order and fold order per tile as rt_jit_mfma_source:
+// bit-identical results.
+// RESULT: correct (the probe verification and the tests pass with it) and the tail between
+// chains is gone (80 cycles), but a chain of 2-MFMA blocks with a statement behind each
+// runs at 20-24 cycles per MFMA instead of 17.5, and a step takes the same 2 200 cycles.
+// Kept behind RAOTEH_JIT_PINGPONG=1 as the record of the experiment.
+static std::string rt_jit_mfma_quad_pp_source(const std::vector<rt_op> &ops, int n, int K, int T,
+                                              int D)
+{
+    const int KS = (n + 3) / 4;
+    const int KP = (KS + 1) / 2;
+    const int TG = T / 2;
+    const int NB = KS * KS;
+    const int nrec = (int)ops.size();
+    int nslots = 1;
+    for (const rt_op &op : ops) {
+        if (op.pop >= 0) nslots = std::max(nslots, op.pop + 1);
+        if (op.dst >= 0) nslots = std::max(nslots, (op.dst & 255) + 1);
+    }
+    const int QS = ((KS * KS * 16 + 127) / 128) * 128;    // rt_quad_stride(n)
+    const int QL = QS / 128;
+    const char *qa_env = getenv("RAOTEH_JIT_QAHEAD");
+    const int QA = std::max(1, qa_env ? atoi(qa_env) : 4);
+    const char *pd_env = getenv("RAOTEH_JIT_PARKDELAY");
+    const int PD = pd_env ? std::max(0, atoi(pd_env)) : 1;
+    std::ostringstream o;
+    o << "// generated by raoteh_amd/csrc/jit.hip (MFMA family, 4x4x4 blocks, two tile groups in "
+         "turn): " << nrec << " steps, " << n << " states, " << K << " observed nodes, " << T
+      << " tiles per wave, prefetch " << D << " leaves\n";
+    o << "typedef double rt_d2 __attribute__((ext_vector_type(2)));\n";
+    const char *trace_env = getenv("RAOTEH_JIT_TRACE");
+    const bool trace = trace_env != nullptr;
+    const long trace_wg = trace ? atol(trace_env) : 0;
+    if (trace) o << "__device__ unsigned long long rt_trace[" << (nrec + 1) * 3 << "];\n";
+    auto stamp = [&](int i, int which) {
+        if (!trace) return;
+        o << "    if (blockIdx.x == " << trace_wg << " && lane == 0) rt_trace[" << i * 3 + which
+          << "] = __builtin_readcyclecounter();\n";
+    };
+    o << "extern \"C\" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu("
+      << (T <= 2 ? "2, 2" : "1, 1") << ")))\n"
+         "rt_jit_prune(const double *__restrict__ Pfrag, const rt_d2 *__restrict__ obs,\n"
+         "             const double *__restrict__ root_w, double *__restrict__ loglik,\n"
+         "             int *__restrict__ status, double *__restrict__ partial,\n"
+         "             long nsites, long nblocks)\n{\n";
+    o << "    const int lane = threadIdx.x;\n";
+    if (trace)      // the constant 100 MHz clock next to the shader clock: the core frequency
+        o << "    if (blockIdx.x == " << trace_wg << " && lane == 0) rt_trace[" << nrec * 3 + 1
+          << "] = __builtin_amdgcn_s_memrealtime();\n";
+    o << "    const long tbase = (long)blockIdx.x * " << T << ";\n";
+    o << "    typedef const __attribute__((address_space(1))) rt_d2 *rt_glb2;\n";
+    o << "    __shared__ __attribute__((aligned(16))) double qa0[" << QS << "];\n";
+    o << "    __shared__ __attribute__((aligned(16))) double qa1[" << QS << "];\n";
+    o << "    rt_glb2 ag = (rt_glb2)Pfrag + lane;          // [step][QS doubles]\n";
+    o << "    const int alane = (lane >> 4) * 4 + (lane & 3);\n";
+    for (int t = 0; t < T; ++t) {
+        o << "    const long tile" << t << " = tbase + " << t << ";\n";
+        o << "    rt_glb2 g" << t << " = (rt_glb2)obs + (size_t)(tile" << t << " < nblocks ? tile" << t
+          << " : nblocks - 1) * " << (long)K * KP * 64 << " + lane;\n";
+    }
+    for (int j = 0; j < KS; ++j)
+        o << "    const bool rowok" << j << " = " << 4 * j << " + (lane >> 4) < " << n << ";\n";
+    for (int t = 0; t < T; ++t) {
+        o << "    double lik" << t << " = 0.0;\n    bool negative" << t << " = false;\n";
+        for (int sl = 0; sl < nslots; ++sl)
+            for (int j = 0; j < KS; ++j)
+                o << "    double a" << sl << "_" << t << "_" << j << " = 1.0;\n";
+        for (int j = 0; j < KS; ++j)
+            o << "    double x" << t << "_" << j << " = 0.0, c" << t << "_" << j << " = 0.0;\n";
+    }
+    auto emit_obs_load = [&](int k) {
+        for (int t = 0; t < T; ++t)
+            for (int q = 0; q < KP; ++q) {
+                const std::string at = "g" + std::to_string(t) + "[" +
+                                       std::to_string(((long)k * KP + q) * 64) + "]";
+                if ((KS & 1) && q == KP - 1)
+                    o << "    const rt_d2 o" << k << "_" << t << "_" << q << " = "
+                      << half_pair_load(at, true) << ";\n";
+                else
+                    o << "    const rt_d2 o" << k << "_" << t << "_" << q
+                      << " = __builtin_nontemporal_load(&" << at << ");\n";
+            }
+    };
+    auto emit_a_load = [&](int i) {
+        for (int j = 0; j < QL; ++j)
+            o << "    const rt_d2 V" << i << "_" << j << " = ag[" << ((long)i * QS / 2 + j * 64)
+              << "];\n";
+    };
+    typedef std::vector<std::string> stmts;
+    auto park = [&](int i, stmts &out) {           // blocks of step i: registers -> qa<i & 1>
+        for (int j = 0; j < QL; ++j)
+            out.push_back("((rt_d2 *)qa" + std::to_string(i & 1) + ")[" + std::to_string(j * 64) +
+                          " + lane] = V" + std::to_string(i) + "_" + std::to_string(j) + ";");
+    };
+    auto operands = [&](int g, int i, stmts &out) {   // x of group g for step i
+        const rt_op &op = ops[(size_t)i];
+        for (int t = g * TG; t < (g + 1) * TG; ++t)
+            for (int j = 0; j < KS; ++j) {
+                std::ostringstream e;
+                e << "x" << t << "_" << j << " = ";
+                std::ostringstream obs_j;
+                if (op.obs >= 0)
+                    obs_j << "o" << op.obs << "_" << t << "_" << (j >> 1) << ((j & 1) ? ".y" : ".x");
+                if (op.pop >= 0) {
+                    e << "a" << op.pop << "_" << t << "_" << j;
+                    if (op.obs >= 0) e << " * " << obs_j.str();
+                } else if (op.obs >= 0) {
+                    e << obs_j.str();
+                } else {
+                    e << "1.0";
+                }
+                e << ";";
+                out.push_back(e.str());
+            }
+    };
+    auto fold = [&](int g, int i, stmts &out) {       // result of group g's chain of step i
+        const rt_op &op = ops[(size_t)i];
+        const int d = op.dst & 255;
+        const bool first = (op.dst >> 8) != 0;
+        for (int t = g * TG; t < (g + 1) * TG; ++t)
+            for (int j = 0; j < KS; ++j)
+                out.push_back("a" + std::to_string(d) + "_" + std::to_string(t) + "_" +
+                              std::to_string(j) + (first ? " = c" : " *= c") + std::to_string(t) +
+                              "_" + std::to_string(j) + ";");
+    };
+    // chain of group g for step i; the statements of `shadow` are spread behind its blocks
+    auto chain = [&](int g, int i, const stmts &shadow) {
+        auto q_read = [&](int b) {
+            const int kk = b / KS, rq = b % KS;
+            o << "    const double Q" << i << "_" << g << "_" << rq << "_" << kk << " = qa" << (i & 1)
+              << "[" << (rq * KS + kk) * 16 << " + alane];\n";
+        };
+        for (int b = 0; b < std::min(QA, NB); ++b) q_read(b);
+        o << "    __builtin_amdgcn_sched_barrier(0);\n";
+        size_t done = 0;
+        for (int b = 0; b < NB; ++b) {
+            const int kk = b / KS, rq = b % KS;
+            if (b + QA < NB) q_read(b + QA);
+            for (int t = g * TG; t < (g + 1) * TG; ++t) {
+                o << "    c" << t << "_" << rq << " = __builtin_amdgcn_mfma_f64_4x4x4f64(Q" << i << "_"
+                  << g << "_" << rq << "_" << kk << ", x" << t << "_" << kk << ", ";
+                if (kk == 0) o << "0.0";
+                else o << "c" << t << "_" << rq;
+                o << ", 0, 0, 0);\n";
+            }
+            const size_t upto = shadow.size() * (size_t)(b + 1) / (size_t)NB;
+            for (; done < upto; ++done) o << "    " << shadow[done] << "\n";
+            o << "    __builtin_amdgcn_sched_barrier(0);\n";
+        }
+    };
+    for (int k = 0; k < std::min(D, K); ++k) emit_obs_load(k);
+    for (int i = 0; i < std::min(1 + PD, nrec); ++i)
+        if (ops[(size_t)i].dst >= 0) emit_a_load(i);
+    {
+        stmts pre;
+        if (nrec > 0 && ops[0].dst >= 0) park(0, pre);
+        operands(0, 0, pre);
+        for (const std::string &st : pre) o << "    " << st << "\n";
+    }
+    stmts pending;                                 // group B's fold of the previous step
+    for (int i = 0; i < nrec; ++i) {
+        const rt_op &op = ops[(size_t)i];
+        o << "    // step " << i << ": node " << op.node << "\n";
+        if (!getenv("RAOTEH_JIT_NO_PINS")) {
+            o << "    asm volatile(\"\" : \"+v\"(ag)";
+            for (int t = 0; t < T; ++t) o << ", \"+v\"(g" << t << ")";
+            o << " : \"v\"(x0_0));\n";
+        }
+        o << "    __builtin_amdgcn_sched_barrier(0);\n";
+        stamp(i, 0);
+        if (i + 1 + PD < nrec && ops[(size_t)(i + 1 + PD)].dst >= 0) emit_a_load(i + 1 + PD);
+        if (op.obs >= 0 && op.obs + D < K) emit_obs_load(op.obs + D);
+        if (op.dst < 0) {
+            // root reduction (_mc0_dense.py:184-209): flush what is pending, then all tiles
+            stmts rest = pending;
+            pending.clear();
+            operands(1, i, rest);
+            for (const std::string &st : rest) o << "    " << st << "\n";
+            for (int j = 0; j < KS; ++j)
+                o << "    const double w" << j << " = rowok" << j << " ? root_w[" << 4 * j
+                  << " + (lane >> 4)] : 0.0;\n";
+            for (int t = 0; t < T; ++t) {
+                o << "    {\n    double sacc = 0.0;\n";
+                for (int j = 0; j < KS; ++j) {
+                    o << "    negative" << t << " |= rowok" << j << " && (x" << t << "_" << j
+                      << " < 0.0);\n";
+                    o << "    sacc += w" << j << " * fmax(x" << t << "_" << j << ", 0.0);\n";
+                }
+                o << "    sacc += __shfl_xor(sacc, 16, 64);\n"
+                     "    sacc += __shfl_xor(sacc, 32, 64);\n"
+                     "    lik" << t << " = sacc;\n    }\n";
+            }
+            continue;
+        }
+        stmts under_a = pending;
+        pending.clear();
+        operands(1, i, under_a);
+        chain(0, i, under_a);
+        stamp(i, 1);
+        stmts under_b;
+        fold(0, i, under_b);
+        if (i + 1 < nrec && ops[(size_t)(i + 1)].dst >= 0) park(i + 1, under_b);
+        if (i + 1 < nrec) operands(0, i + 1, under_b);
+        chain(1, i, under_b);
+        stamp(i, 2);
+        fold(1, i, pending);
+    }
+    for (const std::string &st : pending) o << "    " << st << "\n";
+    stamp(nrec, 0);
+    if (trace)
+        o << "    if (blockIdx.x == " << trace_wg << " && lane == 0) rt_trace[" << nrec * 3 + 2
+          << "] = __builtin_amdgcn_s_memrealtime();\n";
+    for (int t = 0; t < T; ++t) {
+        o << "    {\n"
+             "    const long site = tile" << t << " * 16 + (lane & 15);\n"
+             "    const bool ok = lik" << t << " > 0.0;\n"
+             "    double sum = 0.0, nzero = 0.0;\n"
+             "    if (lane < 16 && tile" << t << " < nblocks && site < nsites) {\n"
+             "        loglik[site] = ok ? log(lik" << t << ") : -__builtin_inf();\n"
+             "        status[site] = (ok ? " << RT_SITE_OK << " : " << RT_SITE_ZERO_PROB
+          << ") | (negative" << t << " ? " << RT_SITE_NEGATIVE << " : 0);\n"
+             "        sum = ok ? log(lik" << t << ") : 0.0;\n"
+             "        nzero = ok ? 0.0 : 1.0;\n"
+             "    }\n"
+             "    for (int off = 32; off > 0; off >>= 1) {\n"
+             "        sum += __shfl_xor(sum, off, 64);\n"
+             "        nzero += __shfl_xor(nzero, off, 64);\n"
+             "    }\n"
+             "    if (lane == 0 && tile" << t << " < nblocks) {\n"
+             "        partial[tile" << t << " * 2] = sum;\n"
+             "        partial[tile" << t << " * 2 + 1] = nzero;\n"
+             "    }\n"
+             "    }\n";
+    }
+    o << "}\n";
+    return o.str();
+}
+
 std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int T, int D, int LA,
                                bool quad)
 {
+    // RAOTEH_JIT_PINGPONG=1: two tile groups in turn (T even).  Not the default: measured
+    // no faster (C5, T = 4: 69.8 us against 67.4; T = 2 on 2 048 tiles: 44.8 against 40.4)
+    {
+        const char *pp_env = getenv("RAOTEH_JIT_PINGPONG");
+        if (quad && T >= 2 && T % 2 == 0 && pp_env && atoi(pp_env) != 0 &&
+            !getenv("RAOTEH_JIT_FAKE_LEAFMAJOR") && !getenv("RAOTEH_JIT_FAKE_ONETILE"))
+            return rt_jit_mfma_quad_pp_source(ops, n, K, T, D);
+    }
     const int NT = (n + 15) / 16;
     const int KS = (n + 3) / 4;
     const int KP = (KS + 1) / 2;
@@ -436,6 +698,9 @@ std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int 
          "             int *__restrict__ status, double *__restrict__ partial,\n"
          "             long nsites, long nblocks)\n{\n";
     o << "    const int lane = threadIdx.x;\n";
+    if (trace)      // the constant 100 MHz clock next to the shader clock: the core frequency
+        o << "    if (blockIdx.x == " << trace_wg << " && lane == 0) rt_trace[" << nrec * 3 + 1
+          << "] = __builtin_amdgcn_s_memrealtime();\n";
     o << "    const long tbase = (long)blockIdx.x * " << T << ";\n";
     o << "    typedef const __attribute__((address_space(1))) rt_d2 *rt_glb2;\n";
     const int QS = ((KS * KS * 16 + 127) / 128) * 128;    // rt_quad_stride(n)
@@ -459,8 +724,12 @@ std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int 
         // tiles past the end re-read the last one; their results are dropped
         // RAOTEH_JIT_FAKE_LEAFMAJOR: timing experiment only (wrong results): address the
         // observations as if they were stored [leaf][tile] instead of [tile][leaf]
-        o << "    rt_glb2 g" << t << " = (rt_glb2)obs + (size_t)(tile" << t << " < nblocks ? tile" << t
-          << " : nblocks - 1) * " << (getenv("RAOTEH_JIT_FAKE_LEAFMAJOR") ? (long)KP * 64 : (long)K * KP * 64)
+        // RAOTEH_JIT_FAKE_ONETILE: timing experiment only (wrong results): every wave reads
+        // the observations of tiles 0..T-1 (L2-resident) -- the kernel without its HBM stream
+        o << "    rt_glb2 g" << t << " = (rt_glb2)obs + (size_t)("
+          << (getenv("RAOTEH_JIT_FAKE_ONETILE") ? std::to_string(t) + " + 0 * tile" + std::to_string(t)
+              : "tile" + std::to_string(t) + " < nblocks ? tile" + std::to_string(t) + " : nblocks - 1")
+          << ") * " << (getenv("RAOTEH_JIT_FAKE_LEAFMAJOR") ? (long)KP * 64 : (long)K * KP * 64)
           << " + lane;\n";
     }
     // the root weights are loaded where the root step uses them, not here: KS doubles
@@ -516,8 +785,14 @@ std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int 
                     o << "    const rt_d2 A" << i << "_" << m << "_" << q << " = ag[" << at << "];\n";
             }
     };
+    // quad form: the blocks of step i + LA are parked at the end of step i and fetched PD
+    // steps before that (RAOTEH_JIT_PARKDELAY, default 1: with the fetch at the top of the
+    // same step the park waited on it at every step -- an L2 round trip is longer than
+    // one chain of 2 x 25 block MFMAs)
+    const char *pd_env = getenv("RAOTEH_JIT_PARKDELAY");
+    const int PD = quad ? (pd_env ? std::max(0, atoi(pd_env)) : 1) : 0;
     for (int k = 0; k < std::min(D, K); ++k) emit_obs_load(k);
-    for (int i = 0; i < std::min(LA, nrec); ++i)
+    for (int i = 0; i < std::min(LA + PD, nrec); ++i)
         if (ops[(size_t)i].dst >= 0) emit_a_load(i);
 
     auto emit_q_park = [&](int i) {        // blocks of step i: registers -> qa<i & 1>
@@ -542,7 +817,7 @@ std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int 
         if (!getenv("RAOTEH_JIT_NO_SCHED_BARRIER"))
             o << "    __builtin_amdgcn_sched_barrier(0);\n";
         stamp(i, 0);
-        if (i + LA < nrec && ops[(size_t)(i + LA)].dst >= 0) emit_a_load(i + LA);
+        if (i + LA + PD < nrec && ops[(size_t)(i + LA + PD)].dst >= 0) emit_a_load(i + LA + PD);
         if (op.obs >= 0 && op.obs + D < K) emit_obs_load(op.obs + D);
         if (op.dst >= 0) dep = "a" + std::to_string(op.dst & 255) + "_0_0";
         o << "    {   // step " << i << ": node " << op.node << "\n";
@@ -647,6 +922,9 @@ std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int 
     }
 
     stamp(nrec, 0);
+    if (trace)
+        o << "    if (blockIdx.x == " << trace_wg << " && lane == 0) rt_trace[" << nrec * 3 + 2
+          << "] = __builtin_amdgcn_s_memrealtime();\n";
     // lanes 0..15 own the 16 sites of a tile (finish_site / wave_sum of prune.hip)
     for (int t = 0; t < T; ++t) {
         o << "    {\n"

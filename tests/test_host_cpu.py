@@ -184,7 +184,9 @@ def test_tree_specialised_source_is_generated_on_the_host():
         assert src.count('// step ') == ta.nnodes
         assert 'extern "C" __global__' in src and 'rt_jit_prune' in src
         hp = (n + 1) // 2
-        assert len(re.findall(r'const rt_d2 o\d+_\d+ = (?:__builtin_nontemporal_load\(&)?g\[', src)) == len(obs) * hp
+        # (a pair of which only .x is used -- odd n -- is an 8-byte load: '{load(...), 0.0}')
+        assert len(re.findall(r'const rt_d2 o\d+_\d+ = [^;]*g\[', src)) == len(obs) * hp
+        assert src.count('), 0.0};') == (len(obs) if n % 2 else 0)
         # P records of the 14 non-root steps, n*n registers each
         assert len(set(re.findall(r'\bp(\d+)_0\b', src))) == ta.nnodes - 1
     # too small a buffer is an error, not a truncation
@@ -230,8 +232,10 @@ def test_tree_specialised_mfma_source_is_generated_on_the_host(monkeypatch):
         kp = (ks + 1) // 2
         steps = ta.nnodes - 1                      # the root step has no product
         assert src.count('__builtin_amdgcn_mfma_f64_16x16x4f64') == steps * nt * ks * tiles
-        assert len(re.findall(r'const rt_d2 A\d+_\d+_\d+ = ag\[', src)) == steps * nt * kp
-        assert len(re.findall(r'const rt_d2 o\d+_\d+_\d+ = __builtin_nontemporal_load\(&g\d+\[', src)) == len(obs) * kp * tiles
+        assert len(re.findall(r'const rt_d2 A\d+_\d+_\d+ = [^;]*ag\[', src)) == steps * nt * kp
+        assert len(re.findall(r'const rt_d2 o\d+_\d+_\d+ = [^;]*g\d+\[', src)) == len(obs) * kp * tiles
+        # odd number of k-steps: the last pair of every operand is an 8-byte load
+        assert src.count('), 0.0};') == ((steps * nt + len(obs) * tiles) if ks % 2 else 0)
     # 32 < n <= 64: split-M family, NT waves share T tiles; wave m owns KS MFMAs per
     # step and tile and loads only its own slice of P_e (KP pairs per step)
     for n, tiles in ((33, 1), (61, 2)):
@@ -244,7 +248,7 @@ def test_tree_specialised_mfma_source_is_generated_on_the_host(monkeypatch):
         kp = (ks + 1) // 2
         steps = ta.nnodes - 1
         assert src.count('__builtin_amdgcn_mfma_f64_16x16x4f64') == steps * ks * tiles
-        assert len(re.findall(r'const rt_d2 A\d+_\d+ = ag\[', src)) == steps * kp
+        assert len(re.findall(r'const rt_d2 A\d+_\d+ = [^;]*ag\[', src)) == steps * kp
         assert src.count('__syncthreads()') == steps + 1      # one per step + the root's
     rc = _lib.lib().rt_jit_source(
         ta.nnodes, ta.indices.ctypes.data_as(p64), ta.indptr.ctypes.data_as(p64),

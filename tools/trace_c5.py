@@ -54,6 +54,10 @@ def main():
                          chain=float(np.mean((t2 - t1)[sel])), tail=float(np.mean((nxt - t2)[sel])),
                          step=float(np.mean((nxt - t0)[sel])))
     out['total_cycles'] = int(tr[nrec, 0] - tr[0, 0])
+    real = int(tr[nrec, 2] - tr[nrec, 1])              # ticks of the constant 100 MHz clock
+    if real > 0:
+        out['wave_us'] = real / 100.0
+        out['core_clock_ghz'] = out['total_cycles'] / (real / 100.0) / 1e3
     print(json.dumps(out, indent=1))
     print('first 16 steps: (leaf?, operands, chain, tail)')
     for i in range(min(16, nrec - 1)):
