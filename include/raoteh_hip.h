@@ -353,6 +353,15 @@ int rt_forest_resample_states(rt_ctx *ctx, int64_t n, int64_t ntrees,
             const int64_t *tree_csr_indptr, const double *P, const double *root_distn,
             uint64_t *allowed_sets, uint64_t seed, uint64_t sweep, int32_t *states,
             int32_t *status, double *subtree_probability);
+/* The same with the topologies as ONE local parent index per node instead of the CSR
+ * (tree_parent int32[total]: -1 at each tree's node 0, else an index below the node's
+ * own) -- what a batched sweep has at hand after cutting its histories into chunks
+ * (raoteh_amd/_sampler.py; the chunk trees of _graph_transform.py:298-375 come out in
+ * that order), without a pass over the forest to build child lists.              */
+int rt_forest_resample_states_parents(rt_ctx *ctx, int64_t n, int64_t ntrees,
+            const int64_t *tree_node_offset, const int32_t *tree_parent, const double *P,
+            const double *root_distn, uint64_t *allowed_sets, uint64_t seed, uint64_t sweep,
+            int32_t *states, int32_t *status);
 
 #ifdef __cplusplus
 }

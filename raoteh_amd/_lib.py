@@ -127,6 +127,10 @@ SIGNATURES = {
                                           _p_f64, _p_f64, POINTER(ctypes.c_uint64),
                                           ctypes.c_uint64, ctypes.c_uint64, _p_i32, _p_i32,
                                           _p_f64]),
+    'rt_forest_resample_states_parents': (c_int, [c_void_p, c_int64, c_int64, _p_i64, _p_i32,
+                                                  _p_f64, _p_f64, POINTER(ctypes.c_uint64),
+                                                  ctypes.c_uint64, ctypes.c_uint64, _p_i32,
+                                                  _p_i32]),
 }
 
 _lib = None

@@ -284,14 +284,37 @@ int upload_matrix(int64_t n, const double *P, ell_matrix &M)
     return RT_OK;
 }
 
+// the same layout given as one local parent index per node (root: -1, parent < child)
+int forest_check_parents(int64_t ntrees, const int64_t *off, const int32_t *parent)
+{
+    RT_REQUIRE(ntrees >= 1 && off && parent, "null forest arrays");
+    RT_REQUIRE(off[0] == 0, "tree_node_offset[0] must be 0");
+    for (int64_t k = 0; k < ntrees; ++k) {
+        const int64_t lo = off[k], nn = off[k + 1] - off[k];
+        RT_REQUIRE(nn >= 1 && nn < (1ll << 30), "tree %lld has %lld nodes", (long long)k, (long long)nn);
+        RT_REQUIRE(parent[lo] == -1, "tree %lld: node 0 must be the root (parent -1)", (long long)k);
+        for (int64_t v = 1; v < nn; ++v)
+            RT_REQUIRE(parent[lo + v] >= 0 && parent[lo + v] < v,
+                       "tree %lld: parent %d of node %lld is not before it", (long long)k,
+                       parent[lo + v], (long long)v);
+    }
+    return RT_OK;
+}
+
 int forest_upload(rt_ctx *ctx, int64_t n, int64_t ntrees, const int64_t *off, const int64_t *idx,
-                  const int64_t *ptr, const double *P, forest_dev &f)
+                  const int64_t *ptr, const double *P, forest_dev &f,
+                  const int32_t *given_parent = nullptr)
 {
     RT_REQUIRE(ctx, "null context");
     RT_REQUIRE(n >= 1 && n <= 64, "the forest passes hold a state per lane: n <= 64");
     RT_REQUIRE(P, "null transition matrix");
     std::vector<int> parent;
-    RT_TRY(forest_parents(ntrees, off, idx, ptr, parent));
+    if (given_parent) {
+        RT_TRY(forest_check_parents(ntrees, off, given_parent));
+        parent.assign(given_parent, given_parent + off[ntrees]);
+    } else {
+        RT_TRY(forest_parents(ntrees, off, idx, ptr, parent));
+    }
     const int64_t total = off[ntrees];
     RT_HIP(hipSetDevice(ctx->device));
     std::vector<long> loff((size_t)ntrees + 1);
@@ -336,17 +359,17 @@ extern "C" int rt_forest_passes(rt_ctx *ctx, int64_t n, int64_t ntrees,
     return RT_OK;
 }
 
-extern "C" int rt_forest_resample_states(rt_ctx *ctx, int64_t n, int64_t ntrees,
-                                         const int64_t *tree_node_offset,
-                                         const int64_t *tree_csr_indices,
-                                         const int64_t *tree_csr_indptr, const double *P,
-                                         const double *root_distn, uint64_t *allowed_sets,
-                                         uint64_t seed, uint64_t sweep, int32_t *states,
-                                         int32_t *status, double *subtree_probability)
+static int forest_resample_impl(rt_ctx *ctx, int64_t n, int64_t ntrees,
+                                const int64_t *tree_node_offset, const int64_t *tree_csr_indices,
+                                const int64_t *tree_csr_indptr, const int32_t *tree_parent,
+                                const double *P, const double *root_distn, uint64_t *allowed_sets,
+                                uint64_t seed, uint64_t sweep, int32_t *states, int32_t *status,
+                                double *subtree_probability)
 {
     RT_REQUIRE(allowed_sets && states && status, "null output arrays");
     forest_dev f;
-    RT_TRY(forest_upload(ctx, n, ntrees, tree_node_offset, tree_csr_indices, tree_csr_indptr, P, f));
+    RT_TRY(forest_upload(ctx, n, ntrees, tree_node_offset, tree_csr_indices, tree_csr_indptr, P, f,
+                         tree_parent));
     const int64_t total = tree_node_offset[ntrees];
     hipStream_t st = ctx->stream;
     RT_HIP(hipMalloc((void **)&f.d_allowed, total * 8));
@@ -376,4 +399,29 @@ extern "C" int rt_forest_resample_states(rt_ctx *ctx, int64_t n, int64_t ntrees,
         RT_HIP(hipMemcpyAsync(subtree_probability, f.d_L, total * n * 8, hipMemcpyDeviceToHost, st));
     RT_HIP(hipStreamSynchronize(st));
     return RT_OK;
+}
+
+extern "C" int rt_forest_resample_states(rt_ctx *ctx, int64_t n, int64_t ntrees,
+                                         const int64_t *tree_node_offset,
+                                         const int64_t *tree_csr_indices,
+                                         const int64_t *tree_csr_indptr, const double *P,
+                                         const double *root_distn, uint64_t *allowed_sets,
+                                         uint64_t seed, uint64_t sweep, int32_t *states,
+                                         int32_t *status, double *subtree_probability)
+{
+    return forest_resample_impl(ctx, n, ntrees, tree_node_offset, tree_csr_indices, tree_csr_indptr,
+                                nullptr, P, root_distn, allowed_sets, seed, sweep, states, status,
+                                subtree_probability);
+}
+
+extern "C" int rt_forest_resample_states_parents(rt_ctx *ctx, int64_t n, int64_t ntrees,
+                                                 const int64_t *tree_node_offset,
+                                                 const int32_t *tree_parent, const double *P,
+                                                 const double *root_distn, uint64_t *allowed_sets,
+                                                 uint64_t seed, uint64_t sweep, int32_t *states,
+                                                 int32_t *status)
+{
+    RT_REQUIRE(tree_parent, "null parent array");
+    return forest_resample_impl(ctx, n, ntrees, tree_node_offset, nullptr, nullptr, tree_parent, P,
+                                root_distn, allowed_sets, seed, sweep, states, status, nullptr);
 }

@@ -1643,3 +1643,130 @@ def test_forest_rejects_bad_layouts(ra):
     sets, pmaps = _forest.get_node_to_set_and_pmap(forest, P, [{3: {1}}, {0: {0, 2}}])
     assert sets[0][3] == {1} and sets[1][0] == {0, 2}
     np.testing.assert_allclose(pmaps[0][0], 1.0 / 3, rtol=1e-13)
+
+
+def test_rao_teh_sweeps_reproduce_the_posterior_expectations(ra):
+    """The batched Rao-Teh sampler (raoteh_amd/_sampler.py around the device's forest
+    sampler) is a Gibbs sampler whose stationary law is the posterior over histories:
+    dwell times, transition counts and root states averaged over replicate chains must
+    match the expected history statistics of the same observation (the expectation path,
+    itself pinned to the oracle above).  Deterministic: fixed seeds, counter-based draws."""
+    from raoteh_amd import _mjp_dense, _sampler
+    cfg = ra.synth.make_config('c1', nsites=3)
+    T, root, n = cfg['T'], cfg['root'], cfg['nstates']
+    Q = cfg['Q_default']
+    full = set(range(n))
+    allowed = dict((v, full) for v in T)
+    for leaf, s in zip(cfg['leaves'], cfg['leaf_states'][1]):
+        allowed[leaf] = {int(s)}
+    allowed[cfg['leaves'][2]] = {0, 3}                     # an ambiguous leaf
+    want_dwell, want_root, want_trans = _mjp_dense.get_expected_history_statistics(
+        T, allowed, root, n, root_distn=cfg['root_distn'], Q_default=Q)
+    B, burn, keep = 3000, 8, 24
+    batch = _sampler.HistoryBatch(T, root, Q, node_to_allowed_states=allowed, nchains=B,
+                                  root_distn=cfg['root_distn'], seed=11, ctx=ra.ctx)
+    total = sum(d['weight'] for _, _, d in T.edges(data=True))
+    dwell = np.zeros((B, n))
+    trans = np.zeros((B, n, n))
+    roots = np.zeros((B, n))
+    for it in range(burn + keep):
+        batch.sweep()
+        if it < burn:
+            continue
+        d = batch.dwell_times()
+        np.testing.assert_allclose(d.sum(axis=1), total, rtol=1e-12)
+        dwell += d
+        trans += batch.transition_counts()
+        roots[np.arange(B), batch.root_states()] += 1
+        # leaves keep to their allowed sets, whatever the sweep did
+        for leaf in cfg['leaves']:
+            st = batch.node_states[:, batch.tree.node_to_index[leaf]]
+            assert set(np.unique(st).tolist()) <= allowed[leaf]
+    dwell /= keep
+    trans /= keep
+    roots /= keep
+
+    def close(sample, expected, what):
+        mean = sample.mean(axis=0)
+        se = sample.std(axis=0, ddof=1) / np.sqrt(B)
+        assert abs(mean - expected) <= 5 * se + 1e-3 * max(abs(expected), 1e-2), \
+            '%s: %.5f vs %.5f (se %.5f)' % (what, mean, expected, se)
+
+    for s in range(n):
+        close(dwell[:, s], want_dwell[s], 'dwell %d' % s)
+        close(roots[:, s], want_root[s], 'root %d' % s)
+    for a in range(n):
+        for b in range(n):
+            if a != b:
+                close(trans[:, a, b], want_trans[a][b]['weight'], 'transitions %d->%d' % (a, b))
+    assert batch.last_chunks >= B                          # a chunk tree per chain went by
+
+
+def test_rao_teh_batch_of_different_sites_and_the_generator(ra):
+    """One chain per site, sites with different observations: the sums over the batch
+    against the batched expectation call; and the reference's generator interface
+    (sparse rate matrix with labelled states) on top of a batch of one."""
+    import networkx as nx
+    from raoteh_amd import _mjp_dense, _sampler
+    cfg = ra.synth.make_config('c1', nsites=1500)
+    T, root, n = cfg['T'], cfg['root'], cfg['nstates']
+    Q = cfg['Q_default']
+    ta_index = _sampler.TreeArrays(T, root).node_to_index
+    masks = np.full((1500, len(ta_index)), (1 << n) - 1, dtype=np.uint64)
+    cols = [ta_index[v] for v in cfg['leaves']]
+    masks[:, cols] = np.uint64(1) << cfg['leaf_states'].astype(np.uint64)
+    want_d, want_i, want_t = _mjp_dense.get_expected_history_statistics_batch(
+        T, root, n, root_distn=cfg['root_distn'], Q_default=Q, obs_nodes=cfg['leaves'],
+        data=cfg['leaf_states'], kind='state')
+    batch = _sampler.HistoryBatch(T, root, Q, node_masks=masks, root_distn=cfg['root_distn'],
+                                  seed=5, ctx=ra.ctx)
+    burn, keep = 8, 40
+    dwell = np.zeros((1500, n))
+    trans = np.zeros((1500, n, n))
+    for it in range(burn + keep):
+        batch.sweep()
+        if it >= burn:
+            dwell += batch.dwell_times()
+            trans += batch.transition_counts()
+    dwell /= keep
+    trans /= keep
+    # sums over sites: independent chains, so the error adds in quadrature
+    for s in range(n):
+        se = np.sqrt(dwell[:, s].var(ddof=1) * 1500)
+        assert abs(dwell[:, s].sum() - want_d[s]) <= 5 * se + 1e-3 * want_d[s]
+    offdiag = ~np.eye(n, dtype=bool)
+    se = np.sqrt(trans.var(axis=0, ddof=1) * 1500)
+    assert (np.abs(trans.sum(axis=0) - want_t)[offdiag] <= (5 * se + 1e-3 * want_t + 0.05)[offdiag]).all()
+    # generator interface: states labelled by strings, rates as a digraph without loops
+    labels = ['A', 'C', 'G', 'T']
+    Qg = nx.DiGraph()
+    for a in range(n):
+        for b in range(n):
+            if a != b:
+                Qg.add_edge(labels[a], labels[b], weight=float(Q[a, b]))
+    obs = dict((leaf, {labels[int(s)]}) for leaf, s in zip(cfg['leaves'], cfg['leaf_states'][0]))
+    for v in T:
+        obs.setdefault(v, set(labels))
+    rd = dict((labels[s], float(p)) for s, p in enumerate(cfg['root_distn']))
+    total = sum(d['weight'] for _, _, d in T.edges(data=True))
+    count = 0
+    for h in _sampler.gen_restricted_histories(T, Qg, obs, root, root_distn=rd, nhistories=4,
+                                               seed=3, ctx=ra.ctx):
+        count += 1
+        assert nx.is_tree(h) and set(T) <= set(h)
+        assert sum(d['weight'] for _, _, d in h.edges(data=True)) == pytest.approx(total, rel=1e-12)
+        for v in h:
+            states = set(d['state'] for d in h[v].values())
+            if v in T:
+                assert len(states) == 1 and states <= obs[v]   # not an event node
+            else:
+                assert h.degree(v) == 2 and len(states) == 2   # a real transition
+    assert count == 4
+    with pytest.raises(ValueError):
+        next(_sampler.gen_restricted_histories(T, Qg, obs, root, uniformization_factor=1.0))
+    with pytest.raises(ValueError):
+        next(_sampler.gen_restricted_histories(T, Qg, {-5: {'A'}}, root))
+    impossible = dict(obs)
+    impossible[cfg['leaves'][0]] = set()
+    with pytest.raises(ra.pkg.StructuralZeroProb):
+        next(_sampler.gen_restricted_histories(T, Qg, impossible, root))

@@ -389,3 +389,101 @@ def test_forest_container_and_uniformization():
         get_uniformized_transition_matrix(Q, uniformization_factor=2, omega=7.0)
     with pytest.raises(ValueError):
         get_uniformized_transition_matrix(np.zeros((2, 3)))
+
+
+def _chunks_by_union_find(parent, edge_rows):
+    """Independent statement of _graph_transform.get_chunk_tree_type_b (:298-375) for one
+    chain: pieces are glued at non-event nodes; returns (piece -> chunk label, base node ->
+    chunk label, set of chunk-tree edges as frozensets of labels)."""
+    # elements: ('n', v) base nodes, ('p', v, k) pieces of edge v
+    uf = {}
+
+    def find(x):
+        uf.setdefault(x, x)
+        while uf[x] != x:
+            uf[x] = uf[uf[x]]
+            x = uf[x]
+        return x
+
+    def union(a, b):
+        uf[find(a)] = find(b)
+
+    for v, npieces in edge_rows.items():
+        union(('n', int(parent[v])), ('p', v, 0))             # the upper node is not an event
+        union(('n', v), ('p', v, npieces - 1))
+        for k in range(npieces):
+            find(('p', v, k))
+    events = set()
+    for v, npieces in edge_rows.items():
+        for k in range(1, npieces):
+            events.add(frozenset((find(('p', v, k - 1)), find(('p', v, k)))))
+    return find, events
+
+
+def test_chunk_forest_matches_a_union_find_statement():
+    """The vectorised chunk trees of a batch of histories (raoteh_amd/_sampler.py) against
+    a per-chain union-find statement of the reference's construction: same partition of
+    pieces and base nodes into chunks, same chunk adjacency, parents before children."""
+    from raoteh_amd import _sampler
+    rng = np.random.RandomState(5)
+    for N, C in ((2, 3), (7, 5), (15, 4), (31, 6)):
+        parent = np.full(N, -1, dtype=np.int64)
+        for v in range(1, N):
+            parent[v] = rng.randint(max(0, v - 4), v)
+        counts = rng.randint(1, 5, size=(C, N))
+        counts[:, 0] = 0
+        counts[rng.uniform(size=counts.shape) < 0.4] = 1      # many edges without events
+        counts[:, 0] = 0
+        chain = np.concatenate([np.full(counts[c, 1:].sum(), c) for c in range(C)]).astype(np.int64)
+        edge = np.concatenate([np.repeat(np.arange(1, N), counts[c, 1:]) for c in range(C)]).astype(np.int64)
+        offset, cparent, piece, node = _sampler.chunk_forest(parent, C, chain, edge)
+        assert offset[0] == 0 and offset[-1] == cparent.shape[0]
+        row = 0
+        for c in range(C):
+            lo, hi = int(offset[c]), int(offset[c + 1])
+            local_parent = cparent[lo:hi]
+            assert local_parent[0] == -1
+            assert all(0 <= local_parent[i] < i for i in range(1, hi - lo))
+            find, events = _chunks_by_union_find(parent, dict((v, int(counts[c, v])) for v in range(1, N)))
+            label_of = {}
+            for v in range(1, N):
+                for k in range(int(counts[c, v])):
+                    label_of.setdefault(find(('p', v, k)), set()).add(int(piece[row]) - lo)
+                    row += 1
+            for v in range(N):
+                label_of.setdefault(find(('n', v)), set()).add(int(node[c, v]))
+            # one chunk id per union-find class, and distinct classes get distinct ids
+            ids = [next(iter(s)) for s in label_of.values()]
+            assert all(len(s) == 1 for s in label_of.values())
+            assert sorted(ids) == list(range(hi - lo))
+            # the chunk tree's edges are the events
+            got = set(frozenset((i, int(local_parent[i]))) for i in range(1, hi - lo))
+            want = set(frozenset(next(iter(label_of[x])) for x in e) for e in events)
+            assert got == want
+        assert row == chain.shape[0]
+
+
+def test_poisson_split_and_merge_keep_lengths_and_order():
+    from raoteh_amd import _sampler
+    rng = np.random.Generator(np.random.PCG64(3))
+    seg_len = np.array([0.5, 2.0, 1e-3, 4.0, 0.25])
+    rate = np.array([3.0, 0.0, 10.0, 2.5, 8.0])
+    rep, sub = _sampler.poisson_split(rng, seg_len, rate)
+    assert rep.shape == (5,) and rep[1] == 1 and sub.shape[0] == rep.sum()
+    owner = np.repeat(np.arange(5), rep)
+    np.testing.assert_allclose(np.bincount(owner, weights=sub), seg_len, rtol=1e-13)
+    assert (sub > 0).all()
+    assert sub[owner == 1][0] == 2.0                      # an untouched segment is not rounded
+    # the number of events is Poisson(rate * length)
+    big = np.full(20000, 1.5)
+    rep, _ = _sampler.poisson_split(rng, big, np.full(20000, 2.0))
+    assert abs((rep - 1).mean() - 3.0) < 0.05 and abs((rep - 1).var() - 3.0) < 0.15
+    # merging: equal neighbours of one (chain, edge) fuse, nothing else does
+    chain = np.array([0, 0, 0, 0, 0, 1, 1])
+    edge = np.array([1, 1, 1, 2, 2, 1, 1])
+    length = np.array([.1, .2, .3, .4, .5, .6, .7])
+    state = np.array([2, 2, 1, 1, 1, 0, 0])
+    c, e, l, s = _sampler.merge_segments(chain, edge, length, state)
+    assert c.tolist() == [0, 0, 0, 1] and e.tolist() == [1, 1, 2, 1]
+    np.testing.assert_allclose(l, [.3, .3, .9, 1.3])
+    assert s.tolist() == [2, 1, 1, 0]

@@ -267,3 +267,47 @@ def test_blinking_builder_matches_the_reference_builder():
             liks.append(orc.mjp_dense_get_likelihood(T, allowed, 0, 20, root_distn=distn,
                                                      Q_default=Q))
         assert liks[0] == pytest.approx(liks[1], rel=1e-14) and liks[0] > 0
+
+
+def test_chunk_forest_against_the_reference_chunk_trees():
+    """raoteh_amd._sampler.chunk_forest (vectorised over chains) against the reference's
+    _graph_transform.get_chunk_tree_type_b on histories with degree-two event nodes
+    (tests/golden/chunk_trees.json, written by tools/gen_golden.py): the same partition
+    of the history's edges into chunks and the same chunk-tree edges, up to the naming of
+    the chunks (the reference numbers them in BFS order of the history, the batch in
+    preorder of the base edges).  All cases go through ONE call as a batch of chains on
+    a forest of different base trees is not what chunk_forest takes, so per base tree."""
+    import json
+    import os
+    from raoteh_amd import _sampler
+    path = os.path.join(os.path.dirname(__file__), 'golden', 'chunk_trees.json')
+    cases = json.load(open(path))['cases']
+    assert len(cases) >= 20
+    for rec in cases:
+        parent = np.array(rec['parent'], dtype=np.int64)
+        counts = np.array(rec['counts'], dtype=np.int64)
+        N = parent.shape[0]
+        # two chains with the same history: the batch dimension must not mix them
+        edge1 = np.repeat(np.arange(1, N), counts[1:]).astype(np.int64)
+        chain = np.concatenate([np.zeros_like(edge1), np.ones_like(edge1)])
+        edge = np.concatenate([edge1, edge1])
+        offset, cparent, piece, node = _sampler.chunk_forest(parent, 2, chain, edge)
+        nch = len(rec['chunk_nodes'])
+        assert offset.tolist() == [0, nch, 2 * nch]
+        ref_chunk = dict(((a, b), c) for a, b, c in rec['edge_to_chunk'])
+        for c in range(2):
+            lo = int(offset[c])
+            to_mine = {}
+            for row, (v, k, na, nb) in enumerate(rec['pieces']):
+                mine = int(piece[c * len(rec['pieces']) + row]) - lo
+                assert to_mine.setdefault(ref_chunk[(na, nb)], mine) == mine
+            assert sorted(to_mine.values()) == list(range(nch))        # a bijection
+            got = sorted(sorted((i, int(cparent[lo + i]))) for i in range(1, nch))
+            want = sorted(sorted((to_mine[a], to_mine[b])) for a, b in rec['chunk_edges'])
+            assert got == want
+            # the root's chunk is chunk 0 in both numberings, and base nodes sit in the
+            # chunk of the piece that ends at them
+            assert to_mine[rec['chunk_nodes'][0]] == 0 and int(node[c, 0]) == 0
+            for row, (v, k, na, nb) in enumerate(rec['pieces']):
+                if nb == v:
+                    assert int(node[c, v]) == int(piece[c * len(rec['pieces']) + row]) - lo

@@ -877,6 +877,46 @@ def fixture_forest(mods, ncases=24):
     return dict(cases=cases)
 
 
+def fixture_chunk_trees(mods, ncases=30):
+    """Histories as the sampler holds them between steps 2 and 3 of a sweep: a base tree
+    whose edges carry event nodes of degree two (the transitions kept from the last sweep
+    and the fresh Poisson events, _sampler.py:376-381), and the reference's chunk tree of
+    each (_graph_transform.get_chunk_tree_type_b, :298-375): which chunk every directed
+    edge of the history lies in, and the chunk tree's edges."""
+    _gt = importlib.import_module('raoteh.sampler._graph_transform')
+    rng = np.random.RandomState(977)
+    cases = []
+    for case in range(ncases):
+        N = int(rng.randint(2, 18))
+        parent = [-1] + [int(rng.randint(max(0, v - 5), v)) for v in range(1, N)]
+        counts = [0] + [int(rng.choice([1, 1, 1, 2, 3, 5])) for _ in range(1, N)]   # pieces
+        T = nx.Graph()
+        T.add_node(0)
+        nxt = N
+        pieces = []
+        events = set()
+        for v in range(1, N):
+            prev = parent[v]
+            for k in range(counts[v]):
+                if k == counts[v] - 1:
+                    nb = v
+                else:
+                    nb = nxt
+                    nxt += 1
+                    events.add(nb)
+                T.add_edge(prev, nb)
+                pieces.append([v, k, int(prev), int(nb)])
+                prev = nb
+        chunk_tree, edge_to_chunk, event_to_edge = _gt.get_chunk_tree_type_b(T, 0, events)
+        cases.append(dict(
+            parent=parent, counts=counts, pieces=pieces, event_nodes=sorted(events),
+            edge_to_chunk=[[int(a), int(b), int(c)] for (a, b), c in edge_to_chunk.items()],
+            chunk_nodes=sorted(int(v) for v in chunk_tree),
+            chunk_edges=sorted([int(a), int(b)] for a, b in
+                               (event_to_edge[e] for e in sorted(events)))))
+    return dict(cases=cases)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(os.path.dirname(HERE),
@@ -906,6 +946,7 @@ def main():
         config_c5=lambda: fixture_config(mods, 'c5', 4),
         blinking=lambda: fixture_blinking(mods),
         forest=lambda: fixture_forest(mods),
+        chunk_trees=lambda: fixture_chunk_trees(mods),
     )
     only = args.only.split(',') if args.only else list(makers)
     fixtures = dict((name, makers[name]()) for name in only)
