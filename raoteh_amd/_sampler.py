@@ -34,6 +34,7 @@ There is no CPU fallback for step 4.
 from __future__ import annotations
 
 import ctypes
+import time
 from ctypes import c_double, c_int32, c_int64, c_uint64
 
 import networkx as nx
@@ -73,8 +74,7 @@ def poisson_split(rng, seg_len, seg_rate):
     rep = (k + 1).astype(np.int64)
     owner = np.repeat(np.arange(seg_len.shape[0]), rep)
     gaps = rng.standard_exponential(owner.shape[0])
-    tot = np.zeros(seg_len.shape[0])
-    np.add.at(tot, owner, gaps)
+    tot = np.bincount(owner, weights=gaps, minlength=seg_len.shape[0])
     sub = gaps / tot[owner] * seg_len[owner]
     single = rep[owner] == 1
     sub[single] = seg_len[owner[single]]                  # untouched segments stay exact
@@ -102,8 +102,8 @@ def chunk_forest(parent, nchains, chain, edge):
     S = chain.shape[0]
     first = np.ones(S, dtype=bool)
     first[1:] = (chain[1:] != chain[:-1]) | (edge[1:] != edge[:-1])
-    M = np.zeros((nchains, N), dtype=np.int64)              # events per (chain, edge)
-    np.add.at(M, (chain[~first], edge[~first]), 1)
+    # events per (chain, edge)
+    M = np.bincount((chain * N + edge)[~first], minlength=nchains * N).reshape(nchains, N)
     csum = np.cumsum(M, axis=1)
     base = 1 + csum - M                                     # id of an edge's first own chunk
     node = np.zeros((nchains, N), dtype=np.int64)
@@ -218,6 +218,7 @@ class HistoryBatch(object):
         self.rng = np.random.Generator(np.random.PCG64(self.seed))
         self.nsweeps = 0
         self.last_chunks = 0
+        self.device_seconds = 0.0            # time inside the device call, all sweeps
         self._init_feasible()
 
     # -- device step ------------------------------------------------------------------
@@ -227,16 +228,20 @@ class HistoryBatch(object):
         offset, cparent, piece, node = chunk_forest(self.parent, C, chain, edge)
         total = int(offset[-1])
         masks = np.full(total, np.uint64((1 << n) - 1), dtype=np.uint64)
-        np.bitwise_and.at(masks, (offset[:-1, None] + node).ravel(), self.node_masks.ravel())
+        glob = offset[:-1, None] + node
+        for v in range(N):               # one base node at a time: distinct chunks per chain
+            masks[glob[:, v]] &= self.node_masks[:, v]
         states = np.empty(total, dtype=np.int32)
         status = np.empty(C, dtype=np.int32)
         rd = self.root_distn
+        t0 = time.perf_counter()
         _lib.check(_lib.lib().rt_forest_resample_states_parents(
             self.ctx._h, n, C, _ptr(offset, c_int64), _ptr(cparent, c_int32),
             _ptr(self.P, c_double), None if rd is None else _ptr(rd, c_double),
             _ptr(masks, c_uint64), c_uint64(self.seed & (2 ** 64 - 1)),
             c_uint64(self.nsweeps & (2 ** 64 - 1)), _ptr(states, c_int32),
             _ptr(status, c_int32)))
+        self.device_seconds += time.perf_counter() - t0
         self.last_chunks = total
         self.nsweeps += 1
         node_states = states[offset[:-1, None] + node]
@@ -280,8 +285,8 @@ class HistoryBatch(object):
     # -- summaries ----------------------------------------------------------------------
     def dwell_times(self):
         """f64[nchains, nstates]: time spent in each state (rows sum to the tree length)."""
-        out = np.zeros(self.nchains * self.nstates)
-        np.add.at(out, self.chain * self.nstates + self.state, self.length)
+        out = np.bincount(self.chain * self.nstates + self.state, weights=self.length,
+                          minlength=self.nchains * self.nstates)
         return out.reshape(self.nchains, self.nstates)
 
     def transition_counts(self):

@@ -74,6 +74,30 @@ __device__ __forceinline__ double philox_uniform(unsigned long long seed, unsign
 
 // ---- kernels -------------------------------------------------------------------------------
 
+// A tree's words that one lane writes and the whole wave reads back a few nodes later
+// (allowed sets, sampled states) live in a wave-private LDS image when the tree has at
+// most FOREST_CAP nodes: LDS operations of one wave execute in order.  Larger trees go
+// through global memory with relaxed agent-scope atomics (coherent at L2; memory
+// operations of one wave to one address stay in order) -- NOT with __threadfence(): on
+// this chip that is a write-back and invalidate of the L2, and with one per node the
+// boolean passes of 10 000 chunk trees took 12 ms and the sampling pass 6.4 ms next to
+// 0.2 ms for the upward pass that does the arithmetic.
+constexpr int FOREST_CAP = 1024;
+
+__device__ __forceinline__ unsigned long long coherent_load(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void coherent_store(unsigned long long *p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wave_lds_order()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // backward then forward boolean pass, in place on the allowed-set masks
 __global__ void __launch_bounds__(64 * FOREST_WAVES)
 forest_sets_kernel(int n, long ntrees, const long *__restrict__ off,
@@ -81,28 +105,45 @@ forest_sets_kernel(int n, long ntrees, const long *__restrict__ off,
                    const unsigned long long *__restrict__ colbits,
                    unsigned long long *__restrict__ allowed, int forward)
 {
+    __shared__ unsigned long long lset[FOREST_WAVES][FOREST_CAP];
     const int lane = threadIdx.x & 63;
-    const long tree = (long)blockIdx.x * FOREST_WAVES + (threadIdx.x >> 6);
+    const int w = threadIdx.x >> 6;
+    const long tree = (long)blockIdx.x * FOREST_WAVES + w;
     if (tree >= ntrees) return;
     const long lo = off[tree], hi = off[tree + 1];
+    const bool fits = hi - lo <= FOREST_CAP;
     const unsigned long long rb = lane < n ? rowbits[lane] : 0ull;
     const unsigned long long cb = lane < n ? colbits[lane] : 0ull;
+    if (fits) {
+        for (long i = lane; i < hi - lo; i += 64) lset[w][i] = allowed[lo + i];
+        wave_lds_order();
+    }
     // backward: a state stays at v only if it has a transition into every child's set
     for (long v = hi - 1; v > lo; --v) {
-        const unsigned long long cset = allowed[v];
+        const unsigned long long cset = fits ? lset[w][v - lo] : coherent_load(&allowed[v]);
         const unsigned long long keep = __ballot((rb & cset) != 0ull);
         const long p = lo + parent[v];
-        if (lane == 0) allowed[p] &= keep;
-        __threadfence();     // the other lanes read this word back (through L2) later
+        if (fits) {
+            if (lane == 0) lset[w][p - lo] &= keep;
+            wave_lds_order();
+        } else if (lane == 0) {
+            coherent_store(&allowed[p], coherent_load(&allowed[p]) & keep);
+        }
     }
-    if (!forward) return;
     // forward: a child state stays only if some state of the parent's set reaches it
-    for (long v = lo + 1; v < hi; ++v) {
-        const unsigned long long pset = allowed[lo + parent[v]];
+    for (long v = lo + 1; forward && v < hi; ++v) {
+        const long p = lo + parent[v];
+        const unsigned long long pset = fits ? lset[w][p - lo] : coherent_load(&allowed[p]);
         const unsigned long long reach = __ballot((cb & pset) != 0ull);
-        if (lane == 0) allowed[v] &= reach;
-        __threadfence();
+        if (fits) {
+            if (lane == 0) lset[w][v - lo] &= reach;
+            wave_lds_order();
+        } else if (lane == 0) {
+            coherent_store(&allowed[v], coherent_load(&allowed[v]) & reach);
+        }
     }
+    if (fits)
+        for (long i = lane; i < hi - lo; i += 64) allowed[lo + i] = lset[w][i];
 }
 
 // upward pass: L[v][s], every entry written
@@ -157,17 +198,23 @@ forest_sample_kernel(int n, long ntrees, const long *__restrict__ off,
                      unsigned long long seed, unsigned long long sweep,
                      int *__restrict__ states, int *__restrict__ status)
 {
+    __shared__ int lstate[FOREST_WAVES][FOREST_CAP];
     const int lane = threadIdx.x & 63;
-    const long tree = (long)blockIdx.x * FOREST_WAVES + (threadIdx.x >> 6);
+    const int w = threadIdx.x >> 6;
+    const long tree = (long)blockIdx.x * FOREST_WAVES + w;
     if (tree >= ntrees) return;
     const long lo = off[tree], hi = off[tree + 1];
+    const bool fits = hi - lo <= FOREST_CAP;
     const bool live = lane < n;
     int st = 0;
     for (long v = lo; v < hi; ++v) {
         double prior;
         if (v == lo) prior = live ? (root_distn ? root_distn[lane] : 1.0) : 0.0;
         else {
-            const int ps = states[lo + parent[v]];
+            const long p = lo + parent[v];
+            const int ps = fits ? lstate[w][p - lo]
+                                : __hip_atomic_load(&states[p], __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
             prior = (live && ps >= 0) ? P[(long)ps * n + lane] : 0.0;
         }
         const double wgt = live ? fmax(prior * L[v * n + lane], 0.0) : 0.0;
@@ -187,8 +234,16 @@ forest_sample_kernel(int n, long ntrees, const long *__restrict__ off,
             // happen with a consistent L, and is reported the same way
             if (st == 0) st = v == lo ? 1 : 2;     // the first failure names the cause
         }
-        if (lane == 0) states[v] = pick;
-        __threadfence();     // every lane reads the parent's state back
+        // every lane holds the same pick; the children read it back from the wave's image
+        if (fits) {
+            if (lane == 0) {
+                lstate[w][v - lo] = pick;
+                states[v] = pick;
+            }
+            wave_lds_order();
+        } else if (lane == 0) {
+            __hip_atomic_store(&states[v], pick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     if (lane == 0) status[tree] = st;
 }

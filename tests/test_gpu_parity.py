@@ -1770,3 +1770,66 @@ def test_rao_teh_batch_of_different_sites_and_the_generator(ra):
     impossible[cfg['leaves'][0]] = set()
     with pytest.raises(ra.pkg.StructuralZeroProb):
         next(_sampler.gen_restricted_histories(T, Qg, impossible, root))
+
+
+def test_forest_trees_beyond_the_lds_image(ra):
+    """Trees with more nodes than the wave-private LDS image holds (csrc/forest.hip,
+    FOREST_CAP = 1024) take the coherent global path: the boolean passes and the upward
+    pass against a plain numpy statement of _mcy.py:396-470, :611-682, the draws against
+    the support and the root's exact posterior; small trees ride in the same batch."""
+    from raoteh_amd import _forest
+    rng = np.random.RandomState(17)
+    n = 5
+    # two states that cannot be left for each other directly: structural zeros, but every
+    # state reaches every other within two steps, so sparse observations stay feasible
+    Q = rng.exponential(size=(n, n)) + 0.1
+    Q[0, 1] = Q[1, 0] = Q[3, 4] = 0.0
+    np.fill_diagonal(Q, 0.0)
+    Q -= np.diag(Q.sum(axis=1))
+    P = np.identity(n) + Q / (2.0 * (-np.diag(Q)).max())
+    nn = 1500
+    big = nx.Graph()
+    big.add_node(0)
+    for k in range(1, nn):
+        big.add_edge(int(rng.randint(max(0, k - 40), k)), k)
+    small = nx.path_graph(6)
+    allowed = dict((int(v), {int(rng.randint(n))}) for v in rng.choice(nn, size=25, replace=False))
+    allowed[0] = {0, 1, 2}
+    reps = 300
+    forest = _forest.Forest([(big, 0), (small, 0)] + [(big, 0)] * (reps - 1))
+    obs = [allowed, {5: {2}}] + [allowed] * (reps - 1)
+    sets, pmaps = _forest.get_node_to_set_and_pmap(forest, P, obs)
+    # numpy statement on the big tree
+    order = list(nx.dfs_preorder_nodes(big, 0))
+    par = dict((b, a) for a, b in nx.bfs_edges(big, 0))
+    S = dict((v, set(allowed.get(v, range(n)))) for v in big)
+    nz = P > 0
+    for v in reversed(order[1:]):
+        S[par[v]] &= set(s for s in range(n) if any(nz[s, t] for t in S[v]))
+    for v in order[1:]:
+        S[v] &= set(t for t in range(n) if any(nz[s, t] for s in S[par[v]]))
+    L = dict((v, np.array([1.0 if s in S[v] else 0.0 for s in range(n)])) for v in big)
+    for v in reversed(order[1:]):
+        L[par[v]] = L[par[v]] * P.dot(L[v])
+    for v in big:
+        assert sets[0][v] == S[v]
+        np.testing.assert_allclose(pmaps[0][v], L[v], rtol=1e-11, atol=0)
+    distn = rng.dirichlet(np.ones(n))
+    states, status = _forest.resample_states(forest, P, obs, root_distn=distn, seed=4, sweep=1,
+                                             return_status=True)
+    assert not status.any()
+    post = distn * L[0]
+    post /= post.sum()
+    got = np.bincount([states[k][0] for k in range(len(states)) if k != 1], minlength=n) / float(reps)
+    assert not got[post == 0].any()
+    assert np.all(np.abs(got - post) <= 5 * np.sqrt(np.maximum(post * (1 - post), 1e-12) / reps) + 1e-9)
+    for k in (0, 2, 7):
+        d = states[k]
+        for v in big:
+            assert d[v] in S[v]
+        for a, b in nx.bfs_edges(big, 0):
+            assert P[d[a], d[b]] > 0
+    assert states[1][5] == 2
+    again, _ = _forest.resample_states(forest, P, obs, root_distn=distn, seed=4, sweep=1,
+                                       return_status=True)
+    assert again == states

@@ -51,16 +51,19 @@ def main():
         batch.sweep()
     inner.clear()
     walls, chunks = [], []
+    batch.device_seconds = 0.0
     for _ in range(nsweeps):
         t = time.perf_counter()
         batch.sweep()
         walls.append(time.perf_counter() - t)
         chunks.append(batch.last_chunks)
     wall, dev = float(np.median(walls)), float(np.median(inner))
+    call = batch.device_seconds / nsweeps
     print(json.dumps(dict(
         workload=name, nchains=nchains, nstates=n, base_nodes=len(index),
         init_s=round(t_init, 3), sweep_ms=round(wall * 1e3, 2),
         chunk_trees_and_device_call_ms=round(dev * 1e3, 2),
+        device_call_ms=round(call * 1e3, 2),
         chunks_per_chain=round(float(np.mean(chunks)) / nchains, 1),
         segments_per_chain=round(batch.chain.shape[0] / nchains, 1),
         chain_sweeps_per_s=round(nchains / wall, 1),
