@@ -35,6 +35,7 @@ extern "C" {
 #define RT_ERR_NOMEM        -4   /* host or device allocation failed         */
 #define RT_ERR_RCCL         -5   /* RCCL missing or a collective failed      */
 #define RT_ERR_SINGULAR     -6   /* expm: Pade denominator singular          */
+#define RT_ERR_ZERO_PROB    -7   /* a chain's observations have likelihood 0 */
 
 #define RT_MAX_STATES       64   /* n <= 64 for the pruning kernels          */
 #define RT_MAX_EXPM_STATES 128   /* expm: n <= 64 LDS-resident, <= 128 through
@@ -362,6 +363,38 @@ int rt_forest_resample_states_parents(rt_ctx *ctx, int64_t n, int64_t ntrees,
             const int64_t *tree_node_offset, const int32_t *tree_parent, const double *P,
             const double *root_distn, uint64_t *allowed_sets, uint64_t seed, uint64_t sweep,
             int32_t *states, int32_t *status);
+
+/* ---- 5. Rao-Teh sweeps with the histories resident on the device ---------------
+ * A batch of `nchains` independent chains on ONE base tree (nnodes <= 1024 nodes in an
+ * order with parent[v] < v, parent[0] = -1; branch_lengths[v] = length of the edge above
+ * v) under ONE rate matrix, given as the caller computes it for the reference's sampler
+ * (_sampler.py:344-357): P = I + Q / omega (f64[n][n]), poisson_rates[s] = omega - q_s,
+ * root_distn (f64[n] or NULL = weights of one), node_masks uint64[nchains][nnodes]
+ * allowed-state sets of the base nodes.  A history is a run of rows (edge = index of the
+ * edge's lower node, length, state) sorted by (edge, position); rt_chains_create finds a
+ * first feasible one by bisecting the edges (_sampler.py:563-648; RT_ERR_ZERO_PROB when
+ * some chain has none), rt_chains_sweep runs whole sweeps (_sampler.py:366-390: Poisson
+ * events, chunk trees, posterior draw of the chunk states, removal of self transitions)
+ * without the rows leaving the device.  Draws are counter-based: (seed, batch) fixes
+ * every history.  rt_chains_get_statistics: per chain the time spent in each state
+ * (f64[nchains][n]), the transition counts (int64[nchains][n][n]) and the states of the
+ * base nodes (int32[nchains][nnodes]) of the CURRENT histories; any pointer may be NULL.
+ * rt_chains_get_rows: the histories themselves (chain_offset int64[nchains + 1], then
+ * `capacity` >= total rows entries of edge / length / state; rt_chains_get_sizes tells
+ * the total).                                                                        */
+typedef struct rt_chains rt_chains;
+int rt_chains_create(rt_ctx *ctx, int64_t nnodes, const int32_t *parent,
+            const double *branch_lengths, int64_t n, const double *P,
+            const double *poisson_rates, const double *root_distn, int64_t nchains,
+            const uint64_t *node_masks, uint64_t seed, rt_chains **out);
+int rt_chains_sweep(rt_chains *chains, int64_t nsweeps);
+int rt_chains_get_sizes(const rt_chains *chains, int64_t *rows, int64_t *chunks,
+            int64_t *sweeps);
+int rt_chains_get_statistics(rt_chains *chains, double *dwell, int64_t *transitions,
+            int32_t *node_states);
+int rt_chains_get_rows(rt_chains *chains, int64_t capacity, int64_t *chain_offset,
+            int32_t *edge, double *length, int32_t *state);
+int rt_chains_destroy(rt_chains *chains);
 
 #ifdef __cplusplus
 }

@@ -24,6 +24,7 @@ RT_ERR_UNSUPPORTED = -3
 RT_ERR_NOMEM = -4
 RT_ERR_RCCL = -5
 RT_ERR_SINGULAR = -6
+RT_ERR_ZERO_PROB = -7
 
 RT_OBS_DENSE, RT_OBS_STATE, RT_OBS_MASK = 0, 1, 2
 RT_K_EXPM, RT_K_PRUNE, RT_K_REDUCE = 0, 1, 2
@@ -131,6 +132,14 @@ SIGNATURES = {
                                                   _p_f64, _p_f64, POINTER(ctypes.c_uint64),
                                                   ctypes.c_uint64, ctypes.c_uint64, _p_i32,
                                                   _p_i32]),
+    'rt_chains_create': (c_int, [c_void_p, c_int64, _p_i32, _p_f64, c_int64, _p_f64, _p_f64,
+                                 _p_f64, c_int64, POINTER(ctypes.c_uint64), ctypes.c_uint64,
+                                 POINTER(c_void_p)]),
+    'rt_chains_sweep': (c_int, [c_void_p, c_int64]),
+    'rt_chains_get_sizes': (c_int, [c_void_p, _p_i64, _p_i64, _p_i64]),
+    'rt_chains_get_statistics': (c_int, [c_void_p, _p_f64, _p_i64, _p_i32]),
+    'rt_chains_get_rows': (c_int, [c_void_p, c_int64, _p_i64, _p_i32, _p_f64, _p_i32]),
+    'rt_chains_destroy': (c_int, [c_void_p]),
 }
 
 _lib = None

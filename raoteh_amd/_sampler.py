@@ -45,7 +45,7 @@ from ._tree import TreeArrays, check_square_dense
 from ._util import StructuralZeroProb
 from .device import get_context
 
-__all__ = ['HistoryBatch', 'gen_restricted_histories', 'gen_histories', 'get_total_rates',
+__all__ = ['HistoryBatch', 'DeviceHistoryBatch', 'gen_restricted_histories', 'gen_histories', 'get_total_rates',
            'poisson_split', 'chunk_forest', 'merge_segments']
 
 
@@ -156,6 +156,12 @@ class HistoryBatch(object):
 
     def __init__(self, T, root, Q, node_masks=None, node_to_allowed_states=None, nchains=None,
                  root_distn=None, uniformization_factor=2, seed=0, ctx=None):
+        self._setup(T, root, Q, node_masks, node_to_allowed_states, nchains, root_distn,
+                    uniformization_factor, seed, ctx)
+        self._init_feasible()
+
+    def _setup(self, T, root, Q, node_masks, node_to_allowed_states, nchains, root_distn,
+               uniformization_factor, seed, ctx):
         if uniformization_factor <= 1:
             raise ValueError('the uniformization factor must be greater than 1')
         Q = np.ascontiguousarray(Q, dtype=np.float64)
@@ -219,7 +225,8 @@ class HistoryBatch(object):
         self.nsweeps = 0
         self.last_chunks = 0
         self.device_seconds = 0.0            # time inside the device call, all sweeps
-        self._init_feasible()
+        if self.tree.nnodes == 1:
+            raise ValueError('the tree has no edges')
 
     # -- device step ------------------------------------------------------------------
     def _resample(self, chain, edge, length):
@@ -330,6 +337,102 @@ class HistoryBatch(object):
         return out
 
 
+class DeviceHistoryBatch(object):
+    """The same batch with the histories resident on the device (csrc/forest.hip,
+    ``rt_chains_*``): Poisson events, chunk trees, posterior draws and the removal of self
+    transitions all run as kernels; a sweep moves two words to the host (row total, status
+    flag).  Same constructor arguments, summaries and ``history(c)`` as HistoryBatch; the
+    draws are counter-based on the device, so the two classes do not produce the same
+    histories from the same seed -- they sample the same distribution."""
+
+    def __init__(self, T, root, Q, node_masks=None, node_to_allowed_states=None, nchains=None,
+                 root_distn=None, uniformization_factor=2, seed=0, ctx=None):
+        # argument handling shared with the host batch (no device work in there)
+        proto = HistoryBatch.__new__(HistoryBatch)
+        proto._setup(T, root, Q, node_masks, node_to_allowed_states, nchains, root_distn,
+                     uniformization_factor, seed, ctx)
+        self.__dict__.update(proto.__dict__)
+        parent = np.ascontiguousarray(self.parent, dtype=np.int32)
+        masks = np.ascontiguousarray(self.node_masks, dtype=np.uint64)
+        rd = self.root_distn
+        handle = ctypes.c_void_p()
+        code = _lib.lib().rt_chains_create(
+            self.ctx._h, self.tree.nnodes, _ptr(parent, c_int32), _ptr(self.branch, c_double),
+            self.nstates, _ptr(self.P, c_double), _ptr(self.poisson_rates, c_double),
+            None if rd is None else _ptr(rd, c_double), self.nchains, _ptr(masks, c_uint64),
+            c_uint64(self.seed & (2 ** 64 - 1)), ctypes.byref(handle))
+        if code == _lib.RT_ERR_ZERO_PROB:
+            raise StructuralZeroProb(_lib.last_error())
+        _lib.check(code)
+        self._h = handle
+        self.nsweeps = 0
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h:
+            try:
+                _lib.lib().rt_chains_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def sweep(self, nsweeps=1):
+        _lib.check(_lib.lib().rt_chains_sweep(self._h, int(nsweeps)))
+        self.nsweeps += int(nsweeps)
+        return self
+
+    def sizes(self):
+        """(rows of all histories, chunks of the last sweep, device steps so far)."""
+        rows, chunks, sweeps = c_int64(0), c_int64(0), c_int64(0)
+        _lib.check(_lib.lib().rt_chains_get_sizes(self._h, ctypes.byref(rows),
+                                                  ctypes.byref(chunks), ctypes.byref(sweeps)))
+        return rows.value, chunks.value, sweeps.value
+
+    @property
+    def last_chunks(self):
+        return self.sizes()[1]
+
+    def dwell_times(self):
+        out = np.empty((self.nchains, self.nstates), dtype=np.float64)
+        _lib.check(_lib.lib().rt_chains_get_statistics(self._h, _ptr(out, c_double), None, None))
+        return out
+
+    def transition_counts(self):
+        out = np.empty((self.nchains, self.nstates, self.nstates), dtype=np.int64)
+        _lib.check(_lib.lib().rt_chains_get_statistics(self._h, None, _ptr(out, c_int64), None))
+        return out
+
+    @property
+    def node_states(self):
+        out = np.empty((self.nchains, self.tree.nnodes), dtype=np.int32)
+        _lib.check(_lib.lib().rt_chains_get_statistics(self._h, None, None, _ptr(out, c_int32)))
+        return out
+
+    def root_states(self):
+        return self.node_states[:, 0].copy()
+
+    def rows(self):
+        """(chain int64[S], edge int64[S], length f64[S], state int64[S]) of all histories."""
+        total = self.sizes()[0]
+        off = np.empty(self.nchains + 1, dtype=np.int64)
+        edge = np.empty(max(total, 1), dtype=np.int32)
+        length = np.empty(max(total, 1), dtype=np.float64)
+        state = np.empty(max(total, 1), dtype=np.int32)
+        _lib.check(_lib.lib().rt_chains_get_rows(self._h, total, _ptr(off, c_int64),
+                                                 _ptr(edge, c_int32), _ptr(length, c_double),
+                                                 _ptr(state, c_int32)))
+        chain = np.repeat(np.arange(self.nchains, dtype=np.int64), np.diff(off))
+        return (chain, edge[:total].astype(np.int64), length[:total],
+                state[:total].astype(np.int64))
+
+    def history(self, c=0):
+        self.chain, self.edge, self.length, self.state = self.rows()
+        try:
+            return HistoryBatch.history(self, c)
+        finally:
+            del self.chain, self.edge, self.length, self.state
+
+
 # ---------------------------------------------------------------------------
 # the reference's generators
 # ---------------------------------------------------------------------------
@@ -372,9 +475,9 @@ def gen_restricted_histories(T, Q, node_to_allowed_states, root, root_distn=None
         raise ValueError('some of the nodes which have been annotated with state restrictions '
                          'are not even in the tree: ' + str(sorted(bad)))
     dense, allowed, rd, labels = _dense_problem(Q, node_to_allowed_states, root_distn)
-    batch = HistoryBatch(T, root, dense, node_to_allowed_states=allowed, nchains=1,
-                         root_distn=rd, uniformization_factor=uniformization_factor,
-                         seed=seed, ctx=ctx)
+    batch = DeviceHistoryBatch(T, root, dense, node_to_allowed_states=allowed, nchains=1,
+                               root_distn=rd, uniformization_factor=uniformization_factor,
+                               seed=seed, ctx=ctx)
     count = 0
     while True:
         h = batch.history(0)

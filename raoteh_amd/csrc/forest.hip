@@ -480,3 +480,639 @@ extern "C" int rt_forest_resample_states_parents(rt_ctx *ctx, int64_t n, int64_t
     return forest_resample_impl(ctx, n, ntrees, tree_node_offset, nullptr, nullptr, tree_parent, P,
                                 root_distn, allowed_sets, seed, sweep, states, status, nullptr);
 }
+
+// =================================================================================================
+// Device-resident Rao-Teh sweeps: the histories of a batch of chains stay in HBM
+// =================================================================================================
+// raoteh_amd/_sampler.py runs steps 1, 2, 3 and 5 of a sweep (_sampler.py:366-390) as numpy
+// passes over the segment rows around the kernels above: 108 ms per sweep of 10 000 chains on
+// a 127-node tree, 1.7 ms of it on the device.  Here the rows never leave the device.  A chain's
+// history is a run of rows (edge = preorder index of the edge's lower node, length, state) sorted
+// by (edge, position along the edge); two row buffers alternate.  One sweep is
+//
+//   count   one wave per chain: Poisson events of every row (exponential gaps at rate
+//           omega - q(state) until they pass the row's end, _sample_mjp_dense.py:47-61; Philox
+//           counter = (chain, row, gap), so the second pass regenerates the same gaps)
+//   scan    exclusive prefix sum of the new row counts over the chains (= where each chain's
+//           rows and, shifted, its chunks start)
+//   split   one wave per chain: write the new rows, count the events per edge (LDS), number the
+//           chunks -- the first piece of an edge lies in the chunk of its upper node, the last in
+//           the chunk of its lower node, pieces in between are chunks of their own
+//           (_graph_transform.py:298-375) -- in preorder of the base edges so that a chunk's
+//           parent precedes it, AND the allowed sets of the base nodes of a chunk together
+//   sets / pmap / sample   the three forest kernels above on the chunk trees
+//   merge   one wave per chain: rows take their chunk's state; neighbours of one edge with equal
+//           states fuse (the event between them was a self transition, _graph_transform.py:55-83)
+//
+// All sums are taken in a fixed order: a (seed, batch) pair gives the same histories every run.
+namespace {
+
+constexpr int SWEEP_WAVES = 4;             // chains per workgroup
+constexpr int SWEEP_MAX_NODES = 1024;      // base tree nodes (LDS tables per wave)
+constexpr int SWEEP_MAX_GAPS = 255;        // Poisson events per row (8 bits of the counter)
+
+struct chains_tables {                     // per wave, in dynamic LDS
+    int *rows;          // [N] new rows on the edge above node v
+    int *first;         // [N] index of the edge's first new row within the chain
+    int *node;          // [N] local chunk of base node v
+    unsigned long long *acc;   // [N] allowed sets ANDed over the event-free subtree below v
+};
+
+__device__ __forceinline__ int wave_inclusive_sum_int(int x, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    return x;
+}
+
+// events of one row: gaps ~ Exp(rate) until the row's end; returns their number and, through
+// `emit`, the piece lengths (k + 1 of them)
+template <class Emit>
+__device__ __forceinline__ int row_events(double rate, double len, unsigned long long seed,
+                                          unsigned long long stream, unsigned long long chain,
+                                          unsigned long long row, int per, Emit emit)
+{
+    if (per > 0) {                         // bisection mode: per equal pieces
+        for (int j = 0; j < per; ++j) emit(j, len / per);
+        return per - 1;
+    }
+    int k = 0;
+    double t = 0.0;
+    if (rate > 0.0) {
+        while (k < SWEEP_MAX_GAPS) {
+            const double u = philox_uniform(seed, stream, (chain << 40) | (row << 8) |
+                                                          (unsigned long long)k);
+            const double gap = -log1p(-u) / rate;
+            if (!(t + gap < len)) break;
+            emit(k, gap);
+            t += gap;
+            ++k;
+        }
+    }
+    emit(k, len - t);
+    return k;
+}
+
+__global__ void __launch_bounds__(64 * SWEEP_WAVES)
+sweep_count_kernel(long nchains, const long *__restrict__ start, const int *__restrict__ cnt,
+                   const double *__restrict__ len, const int *__restrict__ state,
+                   const double *__restrict__ rates, int per, unsigned long long seed,
+                   unsigned long long stream, long *__restrict__ newcnt)
+{
+    const int lane = threadIdx.x & 63;
+    const long c = (long)blockIdx.x * SWEEP_WAVES + (threadIdx.x >> 6);
+    if (c >= nchains) return;
+    const long lo = start[c];
+    int total = 0;
+    for (int i = lane; i < cnt[c]; i += 64) {
+        const int k = row_events(rates[state[lo + i]], len[lo + i], seed, stream,
+                                 (unsigned long long)c, (unsigned long long)i, per,
+                                 [](int, double) {});
+        total += k + 1;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
+    if (lane == 0) newcnt[c] = total;
+}
+
+// exclusive prefix sum of count[0 .. n) -> out[0 .. n], one workgroup
+__global__ void __launch_bounds__(1024)
+sweep_scan_kernel(long n, const long *__restrict__ count, long *__restrict__ out)
+{
+    __shared__ long part[1024];
+    const int t = threadIdx.x;
+    const long per = (n + 1023) / 1024;
+    const long lo = t * per < n ? t * per : n, hi = lo + per < n ? lo + per : n;
+    long s = 0;
+    for (long i = lo; i < hi; ++i) s += count[i];
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const long y = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += y;
+        __syncthreads();
+    }
+    long run = part[t] - s;
+    for (long i = lo; i < hi; ++i) {
+        out[i] = run;
+        run += count[i];
+    }
+    if (t == 1023) out[n] = part[1023];
+}
+
+__global__ void __launch_bounds__(64 * SWEEP_WAVES)
+sweep_split_kernel(long nchains, int N, int nbits, const int *__restrict__ parent,
+                   const long *__restrict__ start, const int *__restrict__ cnt,
+                   const int *__restrict__ edge, const double *__restrict__ len,
+                   const int *__restrict__ state, const double *__restrict__ rates, int per,
+                   unsigned long long seed, unsigned long long stream,
+                   const unsigned long long *__restrict__ node_masks,
+                   const long *__restrict__ newstart, int *__restrict__ edge_out,
+                   double *__restrict__ len_out, int *__restrict__ row_chunk,
+                   long *__restrict__ choff, int *__restrict__ cparent,
+                   unsigned long long *__restrict__ cmask, int *__restrict__ node_chunk)
+{
+    extern __shared__ unsigned long long sweep_lds[];
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const long c = (long)blockIdx.x * SWEEP_WAVES + w;
+    if (c >= nchains) return;
+    // tables of this wave: acc (8 B) first, then three int arrays
+    unsigned long long *acc = sweep_lds + (size_t)w * N * 3;           // N * 8 B
+    int *rows = (int *)(acc + N);                                       // 3 N ints = N * 12 B
+    int *first = rows + N;
+    int *node = first + N;
+    const unsigned long long full = nbits >= 64 ? ~0ull : (1ull << nbits) - 1ull;
+    const long lo = start[c], out = newstart[c];
+    const long ch = out - c * (long)(N - 2);        // chunks of a chain = its rows - (N - 2)
+    const int total = (int)(newstart[c + 1] - out);
+    if (lane == 0) choff[c] = ch;
+    if (c == nchains - 1 && lane == 0) choff[nchains] = newstart[nchains] - nchains * (long)(N - 2);
+    for (int v = lane; v < N; v += 64) rows[v] = 0;
+    wave_lds_order();
+    // pass 1: the new rows, in order; rows per edge
+    int running = 0;
+    const int n_old = cnt[c];
+    for (int base = 0; base < n_old; base += 64) {
+        const int i = base + lane;
+        const bool valid = i < n_old;
+        const int e = valid ? edge[lo + i] : 0;
+        const double l = valid ? len[lo + i] : 0.0;
+        const double r = valid ? rates[state[lo + i]] : 0.0;
+        int k = -1;
+        if (valid)
+            k = row_events(r, l, seed, stream, (unsigned long long)c, (unsigned long long)i, per,
+                           [](int, double) {});
+        const int incl = wave_inclusive_sum_int(k + 1, lane);
+        const long dst = out + running + incl - (k + 1);
+        if (valid) {
+            row_events(r, l, seed, stream, (unsigned long long)c, (unsigned long long)i, per,
+                       [&](int j, double piece) {
+                           edge_out[dst + j] = e;
+                           len_out[dst + j] = piece;
+                       });
+            atomicAdd(&rows[e], k + 1);
+        }
+        running += __shfl(incl, 63, 64);
+    }
+    wave_lds_order();
+    // first new row of every edge (exclusive prefix over the edges in preorder)
+    int carry = 0;
+    for (int base = 0; base < N; base += 64) {
+        const int v = base + lane;
+        const int x = v < N ? rows[v] : 0;
+        const int incl = wave_inclusive_sum_int(x, lane);
+        if (v < N) first[v] = carry + incl - x;
+        carry += __shfl(incl, 63, 64);
+    }
+    wave_lds_order();
+    // chunk of every base node (top-down) and the allowed sets of each event-free subtree
+    // (bottom-up): chains of dependent LDS accesses, done by the whole wave in step
+    for (int v = lane; v < N; v += 64) acc[v] = node_masks[c * N + v] & full;
+    wave_lds_order();
+    if (lane == 0) {
+        node[0] = 0;
+        for (int v = 1; v < N; ++v) {
+            const int m = rows[v] - 1;                       // events on the edge above v
+            node[v] = m > 0 ? first[v] - v + 2 + m - 1 : node[parent[v]];
+        }
+        for (int v = N - 1; v >= 1; --v)
+            if (rows[v] == 1) acc[parent[v]] &= acc[v];
+    }
+    wave_lds_order();
+    for (int v = lane; v < N; v += 64) node_chunk[c * N + v] = node[v];
+    if (lane == 0) {
+        cparent[ch] = -1;
+        cmask[ch] = acc[0];
+    }
+    // pass 2: chunk of every new row; parents and masks of the chunks the rows open
+    // (the rows were written by other lanes of this wave a moment ago, and a neighbouring
+    // chain's wave on this CU may have pulled the shared cache line into the vector L1 before
+    // that: read them at L2)
+    for (int j = lane; j < total; j += 64) {
+        const int v = __hip_atomic_load(&edge_out[out + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int k = j - first[v];
+        const int m = rows[v] - 1;
+        const int base_id = first[v] - v + 2;                // 1 + events on the edges before v
+        const int up = node[parent[v]];
+        const int local = k == 0 ? up : base_id + k - 1;
+        row_chunk[out + j] = local;            // local index; global = choff[c] + local
+        if (k >= 1) {
+            cparent[ch + local] = k == 1 ? up : local - 1;
+            cmask[ch + local] = k == m ? acc[v] : full;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64 * SWEEP_WAVES)
+sweep_merge_kernel(long nchains, int N, const long *__restrict__ newstart,
+                   const long *__restrict__ choff, const int *__restrict__ edge_in,
+                   const double *__restrict__ len_in, const int *__restrict__ row_chunk,
+                   const int *__restrict__ cstate, const int *__restrict__ node_chunk,
+                   int *__restrict__ edge_out, double *__restrict__ len_out,
+                   int *__restrict__ state_out, long *__restrict__ start, int *__restrict__ cnt,
+                   int *__restrict__ node_state)
+{
+    const int lane = threadIdx.x & 63;
+    const long c = (long)blockIdx.x * SWEEP_WAVES + (threadIdx.x >> 6);
+    if (c >= nchains) return;
+    const long lo = newstart[c], ch = choff[c];
+    const int total = (int)(newstart[c + 1] - lo);
+    auto st = [&](int j) { return cstate[ch + row_chunk[lo + j]]; };
+    auto is_start = [&](int j) {
+        return j == 0 || edge_in[lo + j] != edge_in[lo + j - 1] || st(j) != st(j - 1);
+    };
+    int written = 0;
+    for (int base = 0; base < total; base += 64) {
+        const int j = base + lane;
+        const bool head = j < total && is_start(j);
+        const int incl = wave_inclusive_sum_int(head ? 1 : 0, lane);
+        if (head) {
+            double sum = len_in[lo + j];
+            for (int jj = j + 1; jj < total && !is_start(jj); ++jj) sum += len_in[lo + jj];
+            const long dst = lo + written + incl - 1;
+            edge_out[dst] = edge_in[lo + j];
+            len_out[dst] = sum;
+            state_out[dst] = st(j);
+        }
+        written += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) {
+        start[c] = lo;
+        cnt[c] = written;
+    }
+    for (int v = lane; v < N; v += 64) node_state[c * N + v] = cstate[ch + node_chunk[c * N + v]];
+}
+
+// status of the forest pass -> one flag; per-chain statistics on request
+__global__ void __launch_bounds__(256)
+sweep_flag_kernel(long nchains, const int *__restrict__ status, int *__restrict__ flag)
+{
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c < nchains && status[c] != 0) atomicMax(flag, status[c]);
+}
+
+__global__ void __launch_bounds__(64 * SWEEP_WAVES)
+sweep_stats_kernel(long nchains, int n, const long *__restrict__ start, const int *__restrict__ cnt,
+                   const int *__restrict__ edge, const double *__restrict__ len,
+                   const int *__restrict__ state, double *__restrict__ dwell,
+                   long long *__restrict__ trans)
+{
+    const int lane = threadIdx.x & 63;
+    const long c = (long)blockIdx.x * SWEEP_WAVES + (threadIdx.x >> 6);
+    if (c >= nchains) return;
+    const long lo = start[c];
+    const int m = cnt[c];
+    if (dwell) {                 // lane = state: every lane walks the rows in order
+        double sum = 0.0;
+        for (int i = 0; i < m; ++i)
+            if (state[lo + i] == lane) sum += len[lo + i];
+        if (lane < n) dwell[c * n + lane] = sum;
+    }
+    if (trans) {                 // zeroed by the host; integer adds: order does not matter
+        for (int i = 1 + lane; i < m; i += 64)
+            if (edge[lo + i] == edge[lo + i - 1])
+                atomicAdd((unsigned long long *)&trans[(c * n + state[lo + i - 1]) * (long)n +
+                                                       state[lo + i]], 1ull);
+    }
+}
+
+}  // namespace
+
+struct rt_chains {
+    rt_ctx *ctx = nullptr;
+    int64_t nchains = 0, N = 0, n = 0;
+    uint64_t seed = 0, nsweeps = 0;
+    ell_matrix P;
+    int *d_parent = nullptr;               // base tree
+    double *d_branch = nullptr, *d_rates = nullptr, *d_root = nullptr;
+    unsigned long long *d_node_masks = nullptr;
+    // rows: buffer A holds the current histories, B the freshly split ones
+    int64_t cap_rows = 0, cap_chunks = 0;
+    int *d_edge_a = nullptr, *d_state_a = nullptr, *d_edge_b = nullptr, *d_row_chunk = nullptr;
+    double *d_len_a = nullptr, *d_len_b = nullptr;
+    long *d_start = nullptr, *d_newcnt = nullptr, *d_newstart = nullptr, *d_choff = nullptr;
+    int *d_cnt = nullptr, *d_node_chunk = nullptr, *d_node_state = nullptr;
+    int *d_cparent = nullptr, *d_cstate = nullptr, *d_status = nullptr, *d_flag = nullptr;
+    unsigned long long *d_cmask = nullptr;
+    double *d_L = nullptr;
+    int64_t last_rows = 0, last_chunks = 0;
+    ~rt_chains()
+    {
+        hipFree(P.d_col); hipFree(P.d_val); hipFree(P.d_rowbits); hipFree(P.d_colbits);
+        hipFree(P.d_dense);
+        hipFree(d_parent); hipFree(d_branch); hipFree(d_rates); hipFree(d_root);
+        hipFree(d_node_masks); hipFree(d_edge_a); hipFree(d_state_a); hipFree(d_edge_b);
+        hipFree(d_row_chunk); hipFree(d_len_a); hipFree(d_len_b); hipFree(d_start);
+        hipFree(d_newcnt); hipFree(d_newstart); hipFree(d_choff); hipFree(d_cnt);
+        hipFree(d_node_chunk); hipFree(d_node_state); hipFree(d_cparent); hipFree(d_cstate);
+        hipFree(d_status); hipFree(d_flag); hipFree(d_cmask); hipFree(d_L);
+    }
+};
+
+namespace {
+
+template <class T>
+int grow(T *&p, int64_t count, int64_t keep, hipStream_t st)
+{
+    T *q = nullptr;
+    RT_HIP(hipMalloc((void **)&q, (size_t)std::max<int64_t>(count, 1) * sizeof(T)));
+    if (p && keep > 0)
+        RT_HIP(hipMemcpyAsync(q, p, (size_t)keep * sizeof(T), hipMemcpyDeviceToDevice, st));
+    RT_HIP(hipStreamSynchronize(st));
+    hipFree(p);
+    p = q;
+    return RT_OK;
+}
+
+unsigned sweep_grid(int64_t nchains) { return (unsigned)((nchains + SWEEP_WAVES - 1) / SWEEP_WAVES); }
+
+// one sweep (per = 0) or one bisection attempt of the start-up (per = pieces per row);
+// `commit` false leaves buffer A as it was when the chunk trees turn out infeasible
+int chains_step(rt_chains *h, int per, int *flag_out)
+{
+    rt_ctx *ctx = h->ctx;
+    hipStream_t st = ctx->stream;
+    const int64_t C = h->nchains, N = h->N;
+    const dim3 grid(sweep_grid(C)), block(64 * SWEEP_WAVES);
+    const unsigned long long stream_events = 2 * h->nsweeps + 1, stream_states = 2 * h->nsweeps;
+    hipLaunchKernelGGL(sweep_count_kernel, grid, block, 0, st, (long)C, h->d_start, h->d_cnt,
+                       h->d_len_a, h->d_state_a, h->d_rates, per, (unsigned long long)h->seed,
+                       stream_events, h->d_newcnt);
+    hipLaunchKernelGGL(sweep_scan_kernel, dim3(1), dim3(1024), 0, st, (long)C, h->d_newcnt,
+                       h->d_newstart);
+    RT_HIP(hipGetLastError());
+    long total_rows = 0;
+    RT_HIP(hipMemcpyAsync(&total_rows, h->d_newstart + C, sizeof(long), hipMemcpyDeviceToHost, st));
+    RT_HIP(hipStreamSynchronize(st));
+    const int64_t total_chunks = total_rows - C * (N - 2);
+    RT_REQUIRE(total_rows < (1ll << 31) && total_chunks >= C, "row count out of range");
+    if (total_rows > h->cap_rows) {
+        const int64_t cap = total_rows + total_rows / 4 + 1024;
+        RT_TRY(grow(h->d_edge_a, cap, h->cap_rows, st));
+        RT_TRY(grow(h->d_len_a, cap, h->cap_rows, st));
+        RT_TRY(grow(h->d_state_a, cap, h->cap_rows, st));
+        RT_TRY(grow(h->d_edge_b, cap, 0, st));
+        RT_TRY(grow(h->d_len_b, cap, 0, st));
+        RT_TRY(grow(h->d_row_chunk, cap, 0, st));
+        h->cap_rows = cap;
+    }
+    if (total_chunks > h->cap_chunks) {
+        const int64_t cap = total_chunks + total_chunks / 4 + 1024;
+        RT_TRY(grow(h->d_cparent, cap, 0, st));
+        RT_TRY(grow(h->d_cstate, cap, 0, st));
+        RT_TRY(grow(h->d_cmask, cap, 0, st));
+        RT_TRY(grow(h->d_L, cap * h->n, 0, st));
+        h->cap_chunks = cap;
+    }
+    const size_t lds = (size_t)SWEEP_WAVES * N * 24;      // acc (8 B) + three int tables
+    hipLaunchKernelGGL(sweep_split_kernel, grid, block, lds, st, (long)C, (int)N, (int)h->n,
+                       h->d_parent, h->d_start, h->d_cnt, h->d_edge_a, h->d_len_a, h->d_state_a,
+                       h->d_rates, per, (unsigned long long)h->seed, stream_events, h->d_node_masks,
+                       h->d_newstart, h->d_edge_b, h->d_len_b, h->d_row_chunk, h->d_choff,
+                       h->d_cparent, h->d_cmask, h->d_node_chunk);
+    const dim3 fgrid(forest_grid(C)), fblock(64 * FOREST_WAVES);
+    hipLaunchKernelGGL(forest_sets_kernel, fgrid, fblock, 0, st, (int)h->n, (long)C, h->d_choff,
+                       h->d_cparent, h->P.d_rowbits, h->P.d_colbits, h->d_cmask, 1);
+    hipLaunchKernelGGL(forest_pmap_kernel, fgrid, fblock, 0, st, (int)h->n, (long)C, h->d_choff,
+                       h->d_cparent, h->P.width, h->P.d_col, h->P.d_val, h->d_cmask, h->d_L);
+    hipLaunchKernelGGL(forest_sample_kernel, fgrid, fblock, 0, st, (int)h->n, (long)C, h->d_choff,
+                       h->d_cparent, h->P.d_dense, h->d_root, h->d_L, (unsigned long long)h->seed,
+                       stream_states, h->d_cstate, h->d_status);
+    RT_HIP(hipMemsetAsync(h->d_flag, 0, sizeof(int), st));
+    hipLaunchKernelGGL(sweep_flag_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st,
+                       (long)C, h->d_status, h->d_flag);
+    RT_HIP(hipGetLastError());
+    int flag = 0;
+    RT_HIP(hipMemcpyAsync(&flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    RT_HIP(hipStreamSynchronize(st));
+    *flag_out = flag;
+    ++h->nsweeps;
+    if (flag != 0) return RT_OK;               // nothing committed: buffer A is untouched
+    hipLaunchKernelGGL(sweep_merge_kernel, grid, block, 0, st, (long)C, (int)N, h->d_newstart,
+                       h->d_choff, h->d_edge_b, h->d_len_b, h->d_row_chunk, h->d_cstate,
+                       h->d_node_chunk, h->d_edge_a, h->d_len_a, h->d_state_a, h->d_start,
+                       h->d_cnt, h->d_node_state);
+    RT_HIP(hipGetLastError());
+    h->last_rows = total_rows;
+    h->last_chunks = total_chunks;
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" int rt_chains_create(rt_ctx *ctx, int64_t nnodes, const int32_t *parent,
+                                const double *branch_lengths, int64_t n, const double *P,
+                                const double *poisson_rates, const double *root_distn,
+                                int64_t nchains, const uint64_t *node_masks, uint64_t seed,
+                                rt_chains **out)
+{
+    RT_REQUIRE(ctx && out, "null pointer");
+    *out = nullptr;
+    RT_REQUIRE(nnodes >= 2 && nnodes <= SWEEP_MAX_NODES, "the base tree needs 2..%d nodes",
+               SWEEP_MAX_NODES);
+    RT_REQUIRE(n >= 1 && n <= 64, "the forest passes hold a state per lane: n <= 64");
+    RT_REQUIRE(parent && branch_lengths && P && poisson_rates && node_masks && nchains >= 1,
+               "null array or no chains");
+    RT_REQUIRE(nchains < (1ll << 23), "at most 2^23 chains per batch");
+    RT_REQUIRE(parent[0] == -1, "node 0 must be the root (parent -1)");
+    for (int64_t v = 1; v < nnodes; ++v) {
+        RT_REQUIRE(parent[v] >= 0 && parent[v] < v, "parent %d of node %lld is not before it",
+                   parent[v], (long long)v);
+        RT_REQUIRE(branch_lengths[v] > 0.0, "branch length of node %lld is not positive",
+                   (long long)v);
+    }
+    RT_HIP(hipSetDevice(ctx->device));
+    rt_chains *h = new (std::nothrow) rt_chains();
+    if (!h) return RT_ERR_NOMEM;
+    h->ctx = ctx;
+    h->nchains = nchains;
+    h->N = nnodes;
+    h->n = n;
+    h->seed = seed;
+    hipStream_t st = ctx->stream;
+    const int64_t C = nchains, N = nnodes, E = N - 1;
+    int rc = upload_matrix(n, P, h->P);
+    auto fail = [&](int code) { delete h; return code; };
+    if (rc != RT_OK) return fail(rc);
+#define RT_CH(call) do { if ((call) != hipSuccess) { rt_set_error("HIP error in rt_chains_create: %s", hipGetErrorString(hipGetLastError())); return fail(RT_ERR_HIP); } } while (0)
+    RT_CH(hipMalloc((void **)&h->d_parent, N * 4));
+    RT_CH(hipMalloc((void **)&h->d_branch, N * 8));
+    RT_CH(hipMalloc((void **)&h->d_rates, n * 8));
+    RT_CH(hipMalloc((void **)&h->d_node_masks, C * N * 8));
+    RT_CH(hipMalloc((void **)&h->d_start, C * sizeof(long)));
+    RT_CH(hipMalloc((void **)&h->d_newcnt, C * sizeof(long)));
+    RT_CH(hipMalloc((void **)&h->d_newstart, (C + 1) * sizeof(long)));
+    RT_CH(hipMalloc((void **)&h->d_choff, (C + 1) * sizeof(long)));
+    RT_CH(hipMalloc((void **)&h->d_cnt, C * 4));
+    RT_CH(hipMalloc((void **)&h->d_node_chunk, C * N * 4));
+    RT_CH(hipMalloc((void **)&h->d_node_state, C * N * 4));
+    RT_CH(hipMalloc((void **)&h->d_status, C * 4));
+    RT_CH(hipMalloc((void **)&h->d_flag, 4));
+    RT_CH(hipMemcpyAsync(h->d_parent, parent, N * 4, hipMemcpyHostToDevice, st));
+    RT_CH(hipMemcpyAsync(h->d_branch, branch_lengths, N * 8, hipMemcpyHostToDevice, st));
+    RT_CH(hipMemcpyAsync(h->d_rates, poisson_rates, n * 8, hipMemcpyHostToDevice, st));
+    RT_CH(hipMemcpyAsync(h->d_node_masks, node_masks, C * N * 8, hipMemcpyHostToDevice, st));
+    if (root_distn) {
+        RT_CH(hipMalloc((void **)&h->d_root, n * 8));
+        RT_CH(hipMemcpyAsync(h->d_root, root_distn, n * 8, hipMemcpyHostToDevice, st));
+    }
+    // start-up rows: one per edge and chain
+    {
+        std::vector<int> edge((size_t)(C * E)), state((size_t)(C * E), 0), cnt((size_t)C, (int)E);
+        std::vector<double> len((size_t)(C * E));
+        std::vector<long> start((size_t)C);
+        for (int64_t c = 0; c < C; ++c) {
+            start[(size_t)c] = (long)(c * E);
+            for (int64_t v = 1; v < N; ++v) {
+                edge[(size_t)(c * E + v - 1)] = (int)v;
+                len[(size_t)(c * E + v - 1)] = branch_lengths[v];
+            }
+        }
+        h->cap_rows = C * E;
+        RT_CH(hipMalloc((void **)&h->d_edge_a, h->cap_rows * 4));
+        RT_CH(hipMalloc((void **)&h->d_state_a, h->cap_rows * 4));
+        RT_CH(hipMalloc((void **)&h->d_len_a, h->cap_rows * 8));
+        RT_CH(hipMalloc((void **)&h->d_edge_b, h->cap_rows * 4));
+        RT_CH(hipMalloc((void **)&h->d_len_b, h->cap_rows * 8));
+        RT_CH(hipMalloc((void **)&h->d_row_chunk, h->cap_rows * 4));
+        RT_CH(hipMemcpyAsync(h->d_edge_a, edge.data(), edge.size() * 4, hipMemcpyHostToDevice, st));
+        RT_CH(hipMemcpyAsync(h->d_state_a, state.data(), state.size() * 4, hipMemcpyHostToDevice, st));
+        RT_CH(hipMemcpyAsync(h->d_len_a, len.data(), len.size() * 8, hipMemcpyHostToDevice, st));
+        RT_CH(hipMemcpyAsync(h->d_start, start.data(), start.size() * sizeof(long), hipMemcpyHostToDevice, st));
+        RT_CH(hipMemcpyAsync(h->d_cnt, cnt.data(), cnt.size() * 4, hipMemcpyHostToDevice, st));
+        RT_CH(hipStreamSynchronize(st));
+    }
+#undef RT_CH
+    {
+        const size_t lds = (size_t)SWEEP_WAVES * N * 24;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)sweep_split_kernel,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) {
+                rt_set_error("cannot reserve %zu bytes of LDS for the split kernel", lds);
+                return fail(RT_ERR_HIP);
+            }
+        }
+    }
+    // a first feasible history: bisect the edges until every chunk tree has positive
+    // likelihood (_sampler.py:563-648); more events per edge than states cannot help
+    int flag = 1;
+    for (int per = 1; flag != 0; per *= 2) {
+        if (per > 1 && per - 1 > n) {
+            rt_set_error("failed to find a feasible history for some chain (zero likelihood)");
+            return fail(RT_ERR_ZERO_PROB);
+        }
+        rc = chains_step(h, per, &flag);
+        if (rc != RT_OK) return fail(rc);
+    }
+    *out = h;
+    return RT_OK;
+}
+
+extern "C" int rt_chains_sweep(rt_chains *h, int64_t nsweeps)
+{
+    RT_REQUIRE(h && nsweeps >= 0, "bad arguments");
+    RT_HIP(hipSetDevice(h->ctx->device));
+    for (int64_t i = 0; i < nsweeps; ++i) {
+        int flag = 0;
+        RT_TRY(chains_step(h, 0, &flag));
+        RT_REQUIRE(flag == 0, "a chunk tree has zero likelihood (status %d)", flag);
+    }
+    return RT_OK;
+}
+
+extern "C" int rt_chains_get_sizes(const rt_chains *h, int64_t *rows, int64_t *chunks,
+                                   int64_t *sweeps)
+{
+    RT_REQUIRE(h, "null pointer");
+    if (rows) {
+        std::vector<int> cnt((size_t)h->nchains);
+        RT_HIP(hipMemcpy(cnt.data(), h->d_cnt, cnt.size() * 4, hipMemcpyDeviceToHost));
+        int64_t total = 0;
+        for (int x : cnt) total += x;
+        *rows = total;
+    }
+    if (chunks) *chunks = h->last_chunks;
+    if (sweeps) *sweeps = (int64_t)h->nsweeps;
+    return RT_OK;
+}
+
+extern "C" int rt_chains_get_statistics(rt_chains *h, double *dwell, int64_t *transitions,
+                                        int32_t *node_states)
+{
+    RT_REQUIRE(h, "null pointer");
+    RT_HIP(hipSetDevice(h->ctx->device));
+    hipStream_t st = h->ctx->stream;
+    const int64_t C = h->nchains, n = h->n, N = h->N;
+    double *d_dwell = nullptr;
+    long long *d_trans = nullptr;
+    if (dwell) RT_HIP(hipMalloc((void **)&d_dwell, C * n * 8));
+    if (transitions) {
+        RT_HIP(hipMalloc((void **)&d_trans, C * n * n * 8));
+        RT_HIP(hipMemsetAsync(d_trans, 0, C * n * n * 8, st));
+    }
+    if (dwell || transitions) {
+        hipLaunchKernelGGL(sweep_stats_kernel, dim3(sweep_grid(C)), dim3(64 * SWEEP_WAVES), 0, st,
+                           (long)C, (int)n, h->d_start, h->d_cnt, h->d_edge_a, h->d_len_a,
+                           h->d_state_a, d_dwell, d_trans);
+        RT_HIP(hipGetLastError());
+    }
+    if (dwell) RT_HIP(hipMemcpyAsync(dwell, d_dwell, C * n * 8, hipMemcpyDeviceToHost, st));
+    if (transitions)
+        RT_HIP(hipMemcpyAsync(transitions, d_trans, C * n * n * 8, hipMemcpyDeviceToHost, st));
+    if (node_states)
+        RT_HIP(hipMemcpyAsync(node_states, h->d_node_state, C * N * 4, hipMemcpyDeviceToHost, st));
+    RT_HIP(hipStreamSynchronize(st));
+    hipFree(d_dwell);
+    hipFree(d_trans);
+    return RT_OK;
+}
+
+extern "C" int rt_chains_get_rows(rt_chains *h, int64_t capacity, int64_t *chain_offset,
+                                  int32_t *edge, double *length, int32_t *state)
+{
+    RT_REQUIRE(h && chain_offset && edge && length && state, "null pointer");
+    RT_HIP(hipSetDevice(h->ctx->device));
+    const int64_t C = h->nchains;
+    std::vector<long> start((size_t)C);
+    std::vector<int> cnt((size_t)C);
+    RT_HIP(hipMemcpy(start.data(), h->d_start, (size_t)C * sizeof(long), hipMemcpyDeviceToHost));
+    RT_HIP(hipMemcpy(cnt.data(), h->d_cnt, (size_t)C * 4, hipMemcpyDeviceToHost));
+    int64_t total = 0;
+    for (int64_t c = 0; c < C; ++c) {
+        chain_offset[c] = total;
+        total += cnt[(size_t)c];
+    }
+    chain_offset[C] = total;
+    RT_REQUIRE(total <= capacity, "the batch holds %lld rows, the arrays %lld", (long long)total,
+               (long long)capacity);
+    // the chains' runs are not contiguous on the device (each keeps the room of its split rows)
+    const int64_t span = h->cap_rows;
+    std::vector<int> e((size_t)span), s((size_t)span);
+    std::vector<double> l((size_t)span);
+    RT_HIP(hipMemcpy(e.data(), h->d_edge_a, (size_t)span * 4, hipMemcpyDeviceToHost));
+    RT_HIP(hipMemcpy(s.data(), h->d_state_a, (size_t)span * 4, hipMemcpyDeviceToHost));
+    RT_HIP(hipMemcpy(l.data(), h->d_len_a, (size_t)span * 8, hipMemcpyDeviceToHost));
+    for (int64_t c = 0; c < C; ++c)
+        for (int i = 0; i < cnt[(size_t)c]; ++i) {
+            const size_t src = (size_t)(start[(size_t)c] + i), dst = (size_t)(chain_offset[c] + i);
+            edge[dst] = e[src];
+            length[dst] = l[src];
+            state[dst] = s[src];
+        }
+    return RT_OK;
+}
+
+extern "C" int rt_chains_destroy(rt_chains *h)
+{
+    if (!h) return RT_OK;
+    hipSetDevice(h->ctx->device);
+    hipStreamSynchronize(h->ctx->stream);
+    delete h;
+    return RT_OK;
+}

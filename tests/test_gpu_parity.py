@@ -1645,7 +1645,8 @@ def test_forest_rejects_bad_layouts(ra):
     np.testing.assert_allclose(pmaps[0][0], 1.0 / 3, rtol=1e-13)
 
 
-def test_rao_teh_sweeps_reproduce_the_posterior_expectations(ra):
+@pytest.mark.parametrize('where', ['device', 'host'])
+def test_rao_teh_sweeps_reproduce_the_posterior_expectations(ra, where):
     """The batched Rao-Teh sampler (raoteh_amd/_sampler.py around the device's forest
     sampler) is a Gibbs sampler whose stationary law is the posterior over histories:
     dwell times, transition counts and root states averaged over replicate chains must
@@ -1663,8 +1664,9 @@ def test_rao_teh_sweeps_reproduce_the_posterior_expectations(ra):
     want_dwell, want_root, want_trans = _mjp_dense.get_expected_history_statistics(
         T, allowed, root, n, root_distn=cfg['root_distn'], Q_default=Q)
     B, burn, keep = 3000, 8, 24
-    batch = _sampler.HistoryBatch(T, root, Q, node_to_allowed_states=allowed, nchains=B,
-                                  root_distn=cfg['root_distn'], seed=11, ctx=ra.ctx)
+    cls = _sampler.DeviceHistoryBatch if where == 'device' else _sampler.HistoryBatch
+    batch = cls(T, root, Q, node_to_allowed_states=allowed, nchains=B,
+                root_distn=cfg['root_distn'], seed=11, ctx=ra.ctx)
     total = sum(d['weight'] for _, _, d in T.edges(data=True))
     dwell = np.zeros((B, n))
     trans = np.zeros((B, n, n))
@@ -1679,8 +1681,9 @@ def test_rao_teh_sweeps_reproduce_the_posterior_expectations(ra):
         trans += batch.transition_counts()
         roots[np.arange(B), batch.root_states()] += 1
         # leaves keep to their allowed sets, whatever the sweep did
+        node_states = batch.node_states
         for leaf in cfg['leaves']:
-            st = batch.node_states[:, batch.tree.node_to_index[leaf]]
+            st = node_states[:, batch.tree.node_to_index[leaf]]
             assert set(np.unique(st).tolist()) <= allowed[leaf]
     dwell /= keep
     trans /= keep
@@ -1702,7 +1705,8 @@ def test_rao_teh_sweeps_reproduce_the_posterior_expectations(ra):
     assert batch.last_chunks >= B                          # a chunk tree per chain went by
 
 
-def test_rao_teh_batch_of_different_sites_and_the_generator(ra):
+@pytest.mark.parametrize('where', ['device', 'host'])
+def test_rao_teh_batch_of_different_sites_and_the_generator(ra, where):
     """One chain per site, sites with different observations: the sums over the batch
     against the batched expectation call; and the reference's generator interface
     (sparse rate matrix with labelled states) on top of a batch of one."""
@@ -1718,8 +1722,8 @@ def test_rao_teh_batch_of_different_sites_and_the_generator(ra):
     want_d, want_i, want_t = _mjp_dense.get_expected_history_statistics_batch(
         T, root, n, root_distn=cfg['root_distn'], Q_default=Q, obs_nodes=cfg['leaves'],
         data=cfg['leaf_states'], kind='state')
-    batch = _sampler.HistoryBatch(T, root, Q, node_masks=masks, root_distn=cfg['root_distn'],
-                                  seed=5, ctx=ra.ctx)
+    cls = _sampler.DeviceHistoryBatch if where == 'device' else _sampler.HistoryBatch
+    batch = cls(T, root, Q, node_masks=masks, root_distn=cfg['root_distn'], seed=5, ctx=ra.ctx)
     burn, keep = 8, 40
     dwell = np.zeros((1500, n))
     trans = np.zeros((1500, n, n))
@@ -1833,3 +1837,71 @@ def test_forest_trees_beyond_the_lds_image(ra):
     again, _ = _forest.resample_states(forest, P, obs, root_distn=distn, seed=4, sweep=1,
                                        return_status=True)
     assert again == states
+
+
+def test_device_resident_histories_are_consistent_and_reproducible(ra):
+    """rt_chains_*: the rows of every chain stay sorted by edge, their lengths add up to
+    the branch lengths, neighbouring rows of an edge differ in state (self transitions are
+    removed), transitions are ones Q allows, the node states agree with the rows, the same
+    seed gives the same histories, and the statistics kernels agree with numpy on the rows."""
+    from raoteh_amd import _sampler
+    cfg = ra.synth.make_config('c2', nsites=700)
+    T, root, n = cfg['T'], cfg['root'], cfg['nstates']
+    Q = cfg['Q_default'].copy()
+    Q[0, 3] = Q[3, 0] = 0.0                                  # a structural zero in Q
+    np.fill_diagonal(Q, 0.0)
+    Q -= np.diag(Q.sum(axis=1))
+    index = _sampler.TreeArrays(T, root).node_to_index
+    masks = np.full((700, len(index)), (1 << n) - 1, dtype=np.uint64)
+    cols = [index[v] for v in cfg['leaves']]
+    masks[:, cols] = np.uint64(1) << cfg['leaf_states'].astype(np.uint64)
+    masks[::9, cols[3]] = 0b0110
+    batches = [_sampler.DeviceHistoryBatch(T, root, Q, node_masks=masks,
+                                           root_distn=cfg['root_distn'], seed=21, ctx=ra.ctx)
+               for _ in range(2)]
+    for b in batches:
+        b.sweep(7)
+    a, b = batches
+    rows_a, rows_b = a.rows(), b.rows()
+    for x, y in zip(rows_a, rows_b):
+        np.testing.assert_array_equal(x, y)
+    chain, edge, length, state = rows_a
+    assert a.sizes()[0] == chain.shape[0] and a.sizes()[1] >= 700
+    N = len(index)
+    # sorted by (chain, edge); every edge of every chain present; lengths add up
+    key = chain * N + edge
+    assert (np.diff(key) >= 0).all()
+    per_edge = np.bincount(key, weights=length, minlength=700 * N).reshape(700, N)
+    np.testing.assert_allclose(per_edge[:, 1:], np.broadcast_to(a.branch[1:], (700, N - 1)),
+                               rtol=1e-12)
+    assert (length > 0).all() and ((state >= 0) & (state < n)).all()
+    same_edge = key[1:] == key[:-1]
+    assert (state[1:][same_edge] != state[:-1][same_edge]).all()
+    assert (Q[state[:-1][same_edge], state[1:][same_edge]] > 0).all()
+    # node states: the lower node of an edge has the state of the edge's last row, the
+    # upper node that of its first row
+    ns = a.node_states
+    last = np.ones(chain.shape[0], dtype=bool)
+    last[:-1] = ~same_edge
+    first = np.ones(chain.shape[0], dtype=bool)
+    first[1:] = ~same_edge
+    np.testing.assert_array_equal(ns[chain[last], edge[last]], state[last])
+    np.testing.assert_array_equal(ns[chain[first], a.parent[edge[first]]], state[first])
+    assert ((masks[np.arange(700)[:, None], np.arange(N)[None, :]] >> ns.astype(np.uint64)) & 1).all()
+    # statistics kernels against numpy on the rows
+    dwell = np.bincount(chain * n + state, weights=length, minlength=700 * n).reshape(700, n)
+    np.testing.assert_allclose(a.dwell_times(), dwell, rtol=1e-13)
+    at = np.nonzero(same_edge)[0] + 1
+    trans = np.bincount((chain[at] * n + state[at - 1]) * n + state[at],
+                        minlength=700 * n * n).reshape(700, n, n)
+    np.testing.assert_array_equal(a.transition_counts(), trans)
+    # another seed: other histories
+    c = _sampler.DeviceHistoryBatch(T, root, Q, node_masks=masks, root_distn=cfg['root_distn'],
+                                    seed=22, ctx=ra.ctx)
+    c.sweep(7)
+    assert c.rows()[2].shape != length.shape or not np.array_equal(c.rows()[2], length)
+    # a chain without a feasible history is an error at creation, as in the reference
+    bad = masks.copy()
+    bad[5, cols[0]] = 0
+    with pytest.raises(ra.pkg.StructuralZeroProb):
+        _sampler.DeviceHistoryBatch(T, root, Q, node_masks=bad, ctx=ra.ctx)
