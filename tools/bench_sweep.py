@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """
 Time Rao-Teh sweeps of a batch of chains (raoteh_amd/_sampler.py):
-    python tools/bench_sweep.py [workload=c2] [nchains=10000] [nsweeps=10]
+    python tools/bench_sweep.py [workload=c2] [nchains=10000] [nsweeps=10] [device|host]
 Prints, per sweep: wall time, time inside the device call (upload + three kernels +
 download, rt_forest_resample_states_parents), chunks per chain, chain-sweeps per second.
 """
@@ -33,7 +33,27 @@ def main():
     else:
         table = np.array([sum(1 << x for x in ss) for ss in cfg['leaf_allowed']], dtype=np.uint64)
         masks[:, cols] = table[cfg['leaf_states']]
+    where = sys.argv[4] if len(sys.argv) > 4 else 'device'
     t0 = time.perf_counter()
+    if where == 'device':
+        batch = _sampler.DeviceHistoryBatch(T, root, cfg['Q_default'], node_masks=masks,
+                                            root_distn=cfg['root_distn'], seed=1, ctx=ctx)
+        t_init = time.perf_counter() - t0
+        batch.sweep(3)
+        ctx.sync()
+        t = time.perf_counter()
+        batch.sweep(nsweeps)
+        ctx.sync()
+        wall = (time.perf_counter() - t) / nsweeps
+        rows, chunks, _ = batch.sizes()
+        print(json.dumps(dict(
+            workload=name, where='device', nchains=nchains, nstates=n, base_nodes=len(index),
+            init_s=round(t_init, 3), sweep_ms=round(wall * 1e3, 3),
+            chunks_per_chain=round(chunks / nchains, 1),
+            segments_per_chain=round(rows / nchains, 1),
+            chain_sweeps_per_s=round(nchains / wall, 1),
+            chunk_nodes_per_s=round(chunks / wall, 1))))
+        return
     batch = _sampler.HistoryBatch(T, root, cfg['Q_default'], node_masks=masks,
                                   root_distn=cfg['root_distn'], seed=1, ctx=ctx)
     t_init = time.perf_counter() - t0
@@ -60,7 +80,7 @@ def main():
     wall, dev = float(np.median(walls)), float(np.median(inner))
     call = batch.device_seconds / nsweeps
     print(json.dumps(dict(
-        workload=name, nchains=nchains, nstates=n, base_nodes=len(index),
+        workload=name, where='host', nchains=nchains, nstates=n, base_nodes=len(index),
         init_s=round(t_init, 3), sweep_ms=round(wall * 1e3, 2),
         chunk_trees_and_device_call_ms=round(dev * 1e3, 2),
         device_call_ms=round(call * 1e3, 2),
