@@ -1030,6 +1030,8 @@ extern "C" int rt_chains_get_sizes(const rt_chains *h, int64_t *rows, int64_t *c
                                    int64_t *sweeps)
 {
     RT_REQUIRE(h, "null pointer");
+    RT_HIP(hipSetDevice(h->ctx->device));
+    RT_HIP(hipStreamSynchronize(h->ctx->stream));     // the last sweep's merge kernel
     if (rows) {
         std::vector<int> cnt((size_t)h->nchains);
         RT_HIP(hipMemcpy(cnt.data(), h->d_cnt, cnt.size() * 4, hipMemcpyDeviceToHost));
@@ -1078,6 +1080,7 @@ extern "C" int rt_chains_get_rows(rt_chains *h, int64_t capacity, int64_t *chain
 {
     RT_REQUIRE(h && chain_offset && edge && length && state, "null pointer");
     RT_HIP(hipSetDevice(h->ctx->device));
+    RT_HIP(hipStreamSynchronize(h->ctx->stream));     // the last sweep's merge kernel
     const int64_t C = h->nchains;
     std::vector<long> start((size_t)C);
     std::vector<int> cnt((size_t)C);
