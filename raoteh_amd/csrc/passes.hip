@@ -993,7 +993,7 @@ static bool build_lane_plan(int64_t nnodes, const int64_t *idx, const int64_t *p
 }
 
 template <int N, bool PLDS>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(512)
 expect_lane_lds_kernel(int nnodes, long nsites, long S, int nslots, const int4 *__restrict__ ops,
                        const int *__restrict__ parent, const double *__restrict__ esd,
                        const unsigned char *__restrict__ rowbits,
@@ -1007,30 +1007,39 @@ expect_lane_lds_kernel(int nnodes, long nsites, long S, int nslots, const int4 *
     if (trace && blockIdx.x == 0 && threadIdx.x == 0) trace[k] = __builtin_readcyclecounter()
     RT_STAMP(0);
     constexpr int NN = N * N;
+    // W waves per workgroup share the copies of P and of the topology; each wave has its
+    // own slots and state sets (40 KB for one wave alone allowed three waves per CU)
     extern __shared__ double lds_raw[];
-    double *slots = lds_raw;                                        // [slot][state][lane]
-    double *lP = slots + (size_t)nslots * N * 64;                   // [node][a][b] when PLDS
+    const int W = blockDim.x >> 6, wv = threadIdx.x >> 6;
+    double *lP = lds_raw;                                           // [node][a][b] when PLDS
     int4 *lops = (int4 *)(lP + (PLDS ? ((size_t)nnodes * NN + 1) / 2 * 2 : 0));   // 16 B aligned
     int *lpar = (int *)(lops + nnodes);
     unsigned char *lrb = (unsigned char *)(lpar + nnodes);
     unsigned char *lcb = lrb + (size_t)nnodes * N;
-    unsigned char *lsets = lcb + (size_t)nnodes * N;                 // [node][lane]
-    const int lane = threadIdx.x;
-    const long site = (long)blockIdx.x * 64 + lane;
+    const size_t shared_bytes = ((size_t)(lcb + (size_t)nnodes * N - (unsigned char *)lds_raw) + 15) & ~(size_t)15;
+    const size_t wave_bytes = (size_t)nslots * N * 512 + (((size_t)nnodes * 64 + 15) & ~(size_t)15);
+    double *slots = (double *)((unsigned char *)lds_raw + shared_bytes + wv * wave_bytes);   // [slot][state][lane]
+    unsigned char *lsets = (unsigned char *)(slots + (size_t)nslots * N * 64);   // [node][lane]
+    const int lane = threadIdx.x & 63;
+    const long wave_global = (long)blockIdx.x * W + wv;
+    const long site = wave_global * 64 + lane;
     const bool live = site < nsites;
     const size_t row = (size_t)S;
-    for (int i = lane; i < nnodes; i += 64) {
+    for (int i = threadIdx.x; i < nnodes; i += blockDim.x) {
         lops[i] = ops[i];
         lpar[i] = parent[i];
     }
-    for (int i = lane; i < nnodes * N; i += 64) {
+    for (int i = threadIdx.x; i < nnodes * N; i += blockDim.x) {
         lrb[i] = rowbits[i];
         lcb[i] = colbits[i];
     }
     if (PLDS)
-        for (int i = lane; i < nnodes * NN; i += 64) lP[i] = esd[i];
-    for (int v = 0; v < nnodes; ++v) lsets[v * 64 + lane] = sets[(size_t)v * S + site];
+        for (int i = threadIdx.x; i < nnodes * NN; i += blockDim.x) lP[i] = esd[i];
+    const bool idle = wave_global * 64 >= S;             // a wave past the padded batch
+    if (!idle)
+        for (int v = 0; v < nnodes; ++v) lsets[v * 64 + lane] = sets[(size_t)v * S + site];
     __syncthreads();
+    if (idle) return;
     RT_STAMP(1);
     // ---- backward / forward boolean passes on the LDS copy ----
     for (int v = nnodes - 1; v >= 1; --v) {
@@ -1084,7 +1093,7 @@ expect_lane_lds_kernel(int nnodes, long nsites, long S, int nslots, const int4 *
     RT_STAMP(3);
     // ---- downward pass (reverse order) + site sums ----
     const double wt = (live && weights) ? weights[site] : (live ? 1.0 : 0.0);
-    double *out = part + (size_t)blockIdx.x * nnodes * NN;
+    double *out = part + (size_t)wave_global * nnodes * NN;
     bool bad = false;
     {
         const int rs = (__builtin_amdgcn_readfirstlane(lops[nnodes - 1].z) >> 8) & 255;
@@ -1209,12 +1218,33 @@ int expectation_weights_lane(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t nsi
     size_t lds_bytes = 0;
     bool use_lds = !getenv("RAOTEH_EXPECT_GLOBAL") && build_lane_plan(nnodes, idx, ptr, parent, lp);
     bool p_in_lds = false;
+    int waves_per_group = 1;
     if (use_lds) {
-        const size_t fixed = (size_t)lp.nslots * n * 512 + (size_t)nnodes * (16 + 4 + 2 * n + 64);
+        // per wave: slots + state sets; per workgroup: topology (+ P when it fits).  As many
+        // waves per workgroup (<= 8) as make the most waves resident on a CU's 160 KB --
+        // RAOTEH_EXPECT_WAVES overrides
+        const size_t wave_bytes = (size_t)lp.nslots * n * 512 + (((size_t)nnodes * 64 + 15) & ~(size_t)15);
+        const size_t topo = (((size_t)nnodes * (16 + 4 + 2 * n)) + 15) & ~(size_t)15;
         const size_t pbytes = ((size_t)nnodes * nn + 1) / 2 * 2 * 8;
-        if (fixed > 65536) use_lds = false;
-        else if (fixed + pbytes <= 65536) { p_in_lds = true; lds_bytes = fixed + pbytes; }
-        else lds_bytes = fixed;
+        const size_t cap = 160 * 1024;
+        if (topo + wave_bytes > cap) use_lds = false;
+        else {
+            p_in_lds = topo + pbytes + wave_bytes <= cap && pbytes <= 64 * 1024;
+            const size_t shared = topo + (p_in_lds ? pbytes : 0);
+            int best = 1, best_resident = 0;
+            for (int w = 1; w <= 8; ++w) {
+                const size_t bytes = shared + w * wave_bytes;
+                if (bytes > cap) break;
+                const int resident = (int)(cap / bytes) * w;
+                if (resident > best_resident) { best_resident = resident; best = w; }
+            }
+            if (const char *v = getenv("RAOTEH_EXPECT_WAVES")) {
+                const int w = atoi(v);
+                if (w >= 1 && w <= 8 && shared + w * wave_bytes <= cap) best = w;
+            }
+            waves_per_group = best;
+            lds_bytes = shared + best * wave_bytes;
+        }
     }
     scratch_plan plan;
     const size_t o_ops = plan.take((size_t)nnodes * 16), o_trace = plan.take(64);
@@ -1273,16 +1303,22 @@ int expectation_weights_lane(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t nsi
             hipLaunchKernelGGL(sets_apply_obs_kernel, dim3(2048), dim3(256), 0, st, (int)n,
                                (long)nsites, S, (int)nobs, d_obsn, kind, d_data, d_sets);
     }
+#define RT_EXPECT_LDS_ONE(NV, PL)                                                            \
+    do {                                                                                      \
+        if (lds_bytes > 64 * 1024)                                                            \
+            RT_HIP(hipFuncSetAttribute((const void *)expect_lane_lds_kernel<NV, PL>,          \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,            \
+                                       (int)lds_bytes));                                      \
+        hipLaunchKernelGGL((expect_lane_lds_kernel<NV, PL>),                                  \
+                           dim3((unsigned)((G + waves_per_group - 1) / waves_per_group)),     \
+                           dim3(64 * waves_per_group), lds_bytes, st, (int)nnodes,            \
+                           (long)nsites, S, lp.nslots, d_ops, d_par, d_esd, d_rb, d_cb, d_root, \
+                           d_w, d_sets, d_L, d_part, d_st, d_trace);                          \
+    } while (0)
 #define RT_EXPECT_LDS(NV)                                                                    \
     do {                                                                                      \
-        if (p_in_lds)                                                                         \
-            hipLaunchKernelGGL((expect_lane_lds_kernel<NV, true>), dim3((unsigned)G), dim3(64), \
-                               lds_bytes, st, (int)nnodes, (long)nsites, S, lp.nslots, d_ops,  \
-                               d_par, d_esd, d_rb, d_cb, d_root, d_w, d_sets, d_L, d_part, d_st, d_trace); \
-        else                                                                                  \
-            hipLaunchKernelGGL((expect_lane_lds_kernel<NV, false>), dim3((unsigned)G), dim3(64), \
-                               lds_bytes, st, (int)nnodes, (long)nsites, S, lp.nslots, d_ops,  \
-                               d_par, d_esd, d_rb, d_cb, d_root, d_w, d_sets, d_L, d_part, d_st, d_trace); \
+        if (p_in_lds) RT_EXPECT_LDS_ONE(NV, true);                                            \
+        else RT_EXPECT_LDS_ONE(NV, false);                                                    \
     } while (0)
 #define RT_EXPECT_LANE(NV)                                                                   \
     if (use_lds) RT_EXPECT_LDS(NV);                                                          \
@@ -1301,6 +1337,7 @@ int expectation_weights_lane(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t nsi
     }
 #undef RT_EXPECT_LANE
 #undef RT_EXPECT_LDS
+#undef RT_EXPECT_LDS_ONE
     hipLaunchKernelGGL(sum_parts_wide_kernel, dim3((unsigned)((wcount + 3) / 4)), dim3(256), 0,
                        st, G, (long)wcount, d_part, d_out);
     RT_HIP(hipGetLastError());
@@ -1311,8 +1348,9 @@ int expectation_weights_lane(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t nsi
         unsigned long long t[6];
         RT_HIP(hipMemcpy(t, d_trace, sizeof t, hipMemcpyDeviceToHost));
         fprintf(stderr, "[raoteh_amd] expect trace (clocks): fill %llu, sets %llu, up %llu, root %llu, "
-                "down %llu; %d slots, %zu B of LDS\n", t[1] - t[0], t[2] - t[1], t[3] - t[2],
-                t[4] - t[3], t[5] - t[4], lp.nslots, lds_bytes);
+                "down %llu; %d slots, %d waves per workgroup, %zu B of LDS\n", t[1] - t[0],
+                t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], lp.nslots, waves_per_group,
+                lds_bytes);
     }
     return RT_OK;
 }
