@@ -277,3 +277,46 @@ class ShardedLikelihood(object):
             tot = reduce_totals(self.model.fetch_totals(self.batch), self.control)
         nzero = int(tot[1])
         return (-np.inf if nzero else float(tot[0])), nzero, int(tot[2])
+
+
+class ShardedHistoryBatch(object):
+    """Rao-Teh chains sharded over the ranks (raoteh_amd/_sampler.py).  Chains are
+    independent, so a sweep needs no collective at all; only the sample sums a caller
+    accumulates (dwell times per state, transition counts) cross the ranks, over the
+    control plane.  Every rank passes the FULL node_masks uint64[nchains, nnodes]; each
+    creates the batch of its block ``shard_range(nchains, rank, world)`` with a seed of
+    its own.  ``batch_cls`` defaults to the device-resident DeviceHistoryBatch."""
+
+    def __init__(self, T, root, Q, node_masks, control, root_distn=None,
+                 uniformization_factor=2, seed=0, ctx=None, batch_cls=None):
+        node_masks = np.asarray(node_masks)
+        self.control = control
+        self.nchains_total = int(node_masks.shape[0])
+        lo, hi = shard_range(self.nchains_total, control.rank, control.world)
+        self.range = (lo, hi)
+        if batch_cls is None:
+            from ._sampler import DeviceHistoryBatch as batch_cls
+        self.batch = None
+        if hi > lo:
+            self.batch = batch_cls(T, root, Q, node_masks=node_masks[lo:hi],
+                                   root_distn=root_distn,
+                                   uniformization_factor=uniformization_factor,
+                                   seed=int(seed) + (control.rank << 32), ctx=ctx)
+        self.nstates = int(np.asarray(Q).shape[0])
+
+    def sweep(self, nsweeps=1):
+        if self.batch is not None:
+            for _ in range(int(nsweeps)):
+                self.batch.sweep()
+        return self
+
+    def statistics_total(self):
+        """(dwell f64[n], transitions f64[n, n]) summed over ALL chains of all ranks."""
+        n = self.nstates
+        flat = np.zeros(n + n * n)
+        if self.batch is not None:
+            flat[:n] = self.batch.dwell_times().sum(axis=0)
+            flat[n:] = self.batch.transition_counts().sum(axis=0).ravel()
+        flat = self.control.allreduce(flat, np.sum)
+        return flat[:n], flat[n:].reshape(n, n)
+

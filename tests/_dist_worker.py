@@ -106,6 +106,37 @@ def main():
                              after_ok=after == world * (world + 1) / 2.0,
                              leaked=bool(stub.inited and not got and not stub.destroyed)))
     results['rccl'] = rccl
+    # chains of the Rao-Teh sampler sharded over the ranks: no collective in a sweep, the
+    # sample sums add over the control plane (a stand-in batch: no GPU here)
+    from raoteh_amd.dist import ShardedHistoryBatch
+
+    class StubBatch(object):
+        def __init__(self, T, root, Q, node_masks=None, root_distn=None,
+                     uniformization_factor=2, seed=0, ctx=None):
+            self.masks, self.n, self.sweeps, self.seed = node_masks, Q.shape[0], 0, seed
+
+        def sweep(self):
+            self.sweeps += 1
+
+        def dwell_times(self):
+            return (self.masks[:, :self.n] % 7).astype(float) + self.sweeps
+
+        def transition_counts(self):
+            c = (self.masks[:, 0] % 5).astype(np.int64)
+            return c[:, None, None] * np.ones((1, self.n, self.n), dtype=np.int64)
+
+    all_masks = (np.arange(11 * 6).reshape(11, 6) * 37 + 5).astype(np.uint64)
+    sh = ShardedHistoryBatch(None, None, np.zeros((4, 4)), all_masks, sc, seed=9,
+                             batch_cls=StubBatch)
+    sh.sweep(3)
+    d, t = sh.statistics_total()
+    results['chains'] = dict(dwell=d.tolist(), trans=t.tolist(), range=list(sh.range),
+                             seed=None if sh.batch is None else int(sh.batch.seed))
+    if rank == 0:
+        whole = StubBatch(None, None, np.zeros((4, 4)), node_masks=all_masks)
+        whole.sweeps = 3
+        results['chains_want'] = dict(dwell=whole.dwell_times().sum(axis=0).tolist(),
+                                      trans=whole.transition_counts().sum(axis=0).tolist())
     results['socket'] = reduce_totals(local, sc).tolist()
     results['max_rank'] = float(sc.allreduce([float(rank)], np.max)[0])
     sc.barrier()

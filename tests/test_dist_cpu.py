@@ -72,6 +72,11 @@ def test_sharded_reduce_matches_single_process(tmp_path, world):
     for row in res['rccl']:
         assert row['agree'] and row['after_ok'] and not row['leaked'], row
         assert row['got'] == (row['fail'] is None), row
+    # Rao-Teh chains sharded over the ranks: the sample sums of the shards add up to the
+    # unsharded batch's
+    np.testing.assert_allclose(res['chains']['dwell'], res['chains_want']['dwell'], rtol=1e-13)
+    np.testing.assert_array_equal(res['chains']['trans'], res['chains_want']['trans'])
+    assert res['chains']['range'][0] == 0 and res['chains']['seed'] == 9
     ranges = res['ranges']
     assert ranges[0][0] == 0 and ranges[-1][1] == 1003
     for a, b in zip(ranges, ranges[1:]):
