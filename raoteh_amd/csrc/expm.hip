@@ -500,9 +500,45 @@ __constant__ double c_inv_fact[16] = {
 // C = X * Y (+ cf0 I + cf1 P1 + cf2 P2 when cf != nullptr) on the matrix pipe.  All
 // matrices RN x RN (RN = 16 NT), leading dimension LD = RN + 1, zero outside n x n.
 // C may alias X and / or Y (results are held in registers across a barrier).
+// The elements of a matrix at the positions of this lane's accumulator tiles (the D
+// layout of v_mfma_f64_16x16x4: register r of tile (m, j) on lane l is row 16m + 4r + (l >> 4),
+// column 16j + (l & 15)).  The positions are the same for every product, so A and A^2 are
+// read into registers once and the addend of a Horner step is arithmetic only -- read from
+// LDS at every step it cost 4 000 of a product's 9 300 clocks (phase stamps,
+// RAOTEH_EXPM_TRACE).
+template <int NT>
+struct lane_tiles {
+    double v[(NT + 1) / 2][(NT + 1) / 2][4];
+};
+
+template <int NT>
+__device__ __forceinline__ void load_tiles(const double *M, lane_tiles<NT> &t)
+{
+    constexpr int RH = (NT + 1) / 2;
+    constexpr int LD = 16 * NT + 1;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int u = 0; u < RH; ++u)
+#pragma unroll
+        for (int v = 0; v < RH; ++v) {
+            const int m = wr * RH + u, j = wc * RH + v;
+            const bool ok = m < NT && j < NT;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                t.v[u][v][r] = ok ? M[(16 * m + 4 * r + lq) * LD + 16 * j + lr] : 0.0;
+        }
+}
+
 template <int NT>
 __device__ __forceinline__ void mm_blocked(const double *X, const double *Y, double *C,
-                                           const double *cf, const double *P1, const double *P2)
+                                           const double *cf, const double *P1, const double *P2,
+                                           const lane_tiles<NT> *R1 = nullptr,
+                                           const lane_tiles<NT> *R2 = nullptr,
+                                           lane_tiles<NT> *out = nullptr,
+                                           const double *top = nullptr, double *C2 = nullptr)
 {
     constexpr int RH = (NT + 1) / 2;
     constexpr int LD = 16 * NT + 1;
@@ -556,14 +592,23 @@ __device__ __forceinline__ void mm_blocked(const double *X, const double *Y, dou
                     for (int r = 0; r < 4; ++r) {
                         const int row = 16 * m + 4 * r + lq;
                         const int o = row * LD + col;
-                        double w = c1 * P1[o];
-                        if (P2) w += c2 * P2[o];
+                        double w = c1 * (R1 ? R1->v[u][v][r] : P1[o]);
+                        if (R2) w += c2 * R2->v[u][v][r];
+                        else if (P2) w += c2 * P2[o];
                         // the identity only inside n x n: P1 (= A) is zero outside, so
                         // the diagonal of the padding stays as cf[3] says (0 or c0)
                         if (row == col && (double)row < cf[3]) w += c0;
                         acc[u][v][r] += w;
                     }
                 }
+    }
+    if (out) {
+#pragma unroll
+        for (int u = 0; u < RH; ++u)
+#pragma unroll
+            for (int v = 0; v < RH; ++v)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out->v[u][v][r] = acc[u][v][r];
     }
     __syncthreads();
 #pragma unroll
@@ -574,12 +619,28 @@ __device__ __forceinline__ void mm_blocked(const double *X, const double *Y, dou
                 const int m = wr * RH + u, j = wc * RH + v;
                 const int col = 16 * j + lr;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) C[(16 * m + 4 * r + lq) * LD + col] = acc[u][v][r];
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * m + 4 * r + lq;
+                    C[row * LD + col] = acc[u][v][r];
+                    // the top block of the polynomial from the product just made (A^3) and
+                    // the register copies of A and A^2: top = {c0, c1, c2, c3, n}
+                    if (top)
+                        C2[row * LD + col] = top[1] * R1->v[u][v][r] + top[2] * R2->v[u][v][r] +
+                                             top[3] * acc[u][v][r] +
+                                             ((row == col && (double)row < top[4]) ? top[0] : 0.0);
+                }
             }
     __syncthreads();
 }
 
 // GLOBAL = false: the four matrices in LDS (n <= 64); true: in scratch[blockIdx] (n <= 128)
+// RAOTEH_EXPM_TRACE=1: workgroup 1 of the Taylor kernel stamps the shader clock at its
+// phase boundaries (printed by the launcher): diagnostics
+__device__ int rt_expm_trace_on = 0;
+__device__ unsigned long long rt_expm_trace[8];
+#define RT_EXPM_STAMP(k)                                                              \
+    if (trace_on && blockIdx.x == 1 && threadIdx.x == 0) rt_expm_trace[k] = __builtin_readcyclecounter()
+
 template <int NT, bool GLOBAL>
 __global__ void __launch_bounds__(TPB)
 expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ qidx,
@@ -596,8 +657,9 @@ expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ 
     constexpr int RN = 16 * NT;
     constexpr int LD = RN + 1;
     constexpr int MSZ = RN * LD;
-    __shared__ double cfs[4];
     __shared__ double colsum[RN];
+    const int trace_on = rt_expm_trace_on;
+    RT_EXPM_STAMP(0);
     double *B0 = GLOBAL ? scratch + (size_t)blockIdx.x * 4 * MSZ : (double *)smem;   // A
     double *B1 = B0 + MSZ;                     // A^2
     double *B2 = B1 + MSZ;                     // A^3
@@ -630,22 +692,24 @@ expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ 
     // dependent load -> store pairs costs one L2 round trip per iteration)
     {
         constexpr int PER = (MSZ + TPB - 1) / TPB;
-        for (int c0 = 0; c0 < PER; c0 += 8) {
-            double v[8];
+        constexpr int CH = PER <= 20 ? PER : 8;      // n <= 64: one round trip for all of Q
+        for (int c0 = 0; c0 < PER; c0 += CH) {
+            double v[CH];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < CH; ++u) {
                 const int e = (c0 + u) * TPB + tid;
                 const int i = e / LD, j = e - i * LD;
                 v[u] = (e < MSZ && i < n && j < n) ? Qb[i * n + j] * t : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < CH; ++u) {
                 const int e = (c0 + u) * TPB + tid;
                 if (e < MSZ) B0[e] = v[u];
             }
         }
     }
     __syncthreads();
+    RT_EXPM_STAMP(1);
     // ||A||_1 = max column sum
     for (int j = tid; j < RN; j += TPB) {
         double s = 0.0;
@@ -680,28 +744,38 @@ expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ 
         __syncthreads();
     }
     const int q = m / 3;
-    mm_blocked<NT>(B0, B0, B1, nullptr, nullptr, nullptr);     // A^2
-    mm_blocked<NT>(B0, B1, B2, nullptr, nullptr, nullptr);     // A^3
-    // T = B_(q-1) = c I + c A + c A^2 (the top block has no A^3 term: m = 3 q - ... see
-    // below: the degree-m polynomial is sum_{j<q} A^(3j) B_j plus c_m A^m, and c_m A^m =
-    // A^(3(q-1)) (c_m A^3), so the top block carries the A^3 term)
+    RT_EXPM_STAMP(2);
+    lane_tiles<NT> ra, ra2;
+    load_tiles<NT>(B0, ra);
+    mm_blocked<NT>(B0, B0, B1, nullptr, nullptr, nullptr, nullptr, nullptr, &ra2);     // A^2
+    // A^3, and with it T = B_(q-1) = c I + c A + c A^2 + c_m A^3 (the degree-m polynomial
+    // is sum_{j<q} A^(3j) B_j plus c_m A^m, and c_m A^m = A^(3(q-1)) (c_m A^3): the top
+    // block carries the A^3 term)
+    __shared__ double tops[5];
     {
         const int base = 3 * (q - 1);
-        const double c0 = c_inv_fact[base], c1 = c_inv_fact[base + 1],
-                     c2 = c_inv_fact[base + 2], c3 = c_inv_fact[m];
-        for (int e = tid; e < MSZ; e += TPB) {
-            const int i = e / LD, j = e - i * LD;
-            B3[e] = c1 * B0[e] + c2 * B1[e] + c3 * B2[e] + ((i == j && i < n) ? c0 : 0.0);
+        if (tid == 0) {
+            tops[0] = c_inv_fact[base];
+            tops[1] = c_inv_fact[base + 1];
+            tops[2] = c_inv_fact[base + 2];
+            tops[3] = c_inv_fact[m];
+            tops[4] = (double)n;
         }
         __syncthreads();
     }
-    for (int jj = q - 2; jj >= 0; --jj) {
-        if (tid < 3) cfs[tid] = c_inv_fact[3 * jj + tid];
-        if (tid == 3) cfs[3] = (double)n;
-        __syncthreads();
-        mm_blocked<NT>(B2, B3, B3, cfs, B0, B1);               // T = A^3 T + B_j
-    }
+    mm_blocked<NT>(B0, B1, B2, nullptr, nullptr, nullptr, &ra, &ra2, nullptr, tops, B3);
+    RT_EXPM_STAMP(3);
+    RT_EXPM_STAMP(4);
+    // the coefficients of every Horner step at once (one barrier, not one per step)
+    __shared__ double cfs_all[5][4];
+    if (tid < 20) cfs_all[tid >> 2][tid & 3] = (tid & 3) == 3 ? (double)n
+                                                             : c_inv_fact[3 * (tid >> 2) + (tid & 3)];
+    __syncthreads();
+    for (int jj = q - 2; jj >= 0; --jj)
+        mm_blocked<NT>(B2, B3, B3, cfs_all[jj], B0, B1, &ra, &ra2);    // T = A^3 T + B_j
+    RT_EXPM_STAMP(5);
     for (int r = 0; r < s; ++r) mm_blocked<NT>(B3, B3, B3, nullptr, nullptr, nullptr);
+    RT_EXPM_STAMP(6);
 
     const double *Xb = B3;
     for (int e = tid; e < nn; e += TPB) {
@@ -737,6 +811,7 @@ expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ 
             }
         }
     }
+    RT_EXPM_STAMP(7);
 }
 
 // ---------------------------------------------------------------------------
@@ -1150,6 +1225,21 @@ int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
         }
 #undef RT_TAYLOR
         RT_HIP(hipGetLastError());
+        if (getenv("RAOTEH_EXPM_TRACE")) {
+            static int armed = 0;
+            unsigned long long tr[8];
+            RT_HIP(hipStreamSynchronize(ctx->stream));
+            if (armed) {
+                RT_HIP(hipMemcpyFromSymbol(tr, HIP_SYMBOL(rt_expm_trace), sizeof tr));
+                fprintf(stderr, "[raoteh_amd] expm trace (clocks, workgroup 1): load %llu, norm %llu, "
+                        "A^2 A^3 %llu, block %llu, Horner %llu, squarings %llu, store %llu; total %llu\n",
+                        tr[1] - tr[0], tr[2] - tr[1], tr[3] - tr[2], tr[4] - tr[3], tr[5] - tr[4],
+                        tr[6] - tr[5], tr[7] - tr[6], tr[7] - tr[0]);
+            }
+            const int on = 1;
+            RT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(rt_expm_trace_on), &on, sizeof on));
+            armed = 1;
+        }
         rt_time_end(ctx, RT_K_EXPM, ev);
         return RT_OK;
     }
