@@ -561,24 +561,8 @@ __device__ __forceinline__ void mm_blocked(const double *X, const double *Y, dou
 #pragma unroll
         for (int v = 0; v < RH; ++v) acc[u][v] = (double4_t){0.0, 0.0, 0.0, 0.0};
     }
-    double a0[RH], b0[RH];
-#pragma unroll
-    for (int u = 0; u < RH; ++u) { a0[u] = ap[u][0]; b0[u] = bp[u][0]; }
-    for (int kk = 0; kk < KS; ++kk) {
-        // operands of the next k-step first (the last iteration re-reads its own)
-        const int kn = kk + 1 < KS ? kk + 1 : kk;
-        double a1[RH], b1[RH];
-#pragma unroll
-        for (int u = 0; u < RH; ++u) { a1[u] = ap[u][4 * kn]; b1[u] = bp[u][4 * kn * LD]; }
-#pragma unroll
-        for (int u = 0; u < RH; ++u)
-#pragma unroll
-            for (int v = 0; v < RH; ++v)
-                acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[v], acc[u][v], 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < RH; ++u) { a0[u] = a1[u]; b0[u] = b1[u]; }
-    }
-    // the addend of a Horner step, read before the barrier
+    // the addend of a Horner step seeds the accumulators (added after the k loop it waited
+    // for the matrix pipe to drain and stood between the last MFMA and the barrier)
     if (cf) {
         const double c0 = cf[0], c1 = cf[1], c2 = cf[2];
 #pragma unroll
@@ -598,9 +582,26 @@ __device__ __forceinline__ void mm_blocked(const double *X, const double *Y, dou
                         // the identity only inside n x n: P1 (= A) is zero outside, so
                         // the diagonal of the padding stays as cf[3] says (0 or c0)
                         if (row == col && (double)row < cf[3]) w += c0;
-                        acc[u][v][r] += w;
+                        acc[u][v][r] = w;
                     }
                 }
+    }
+    double a0[RH], b0[RH];
+#pragma unroll
+    for (int u = 0; u < RH; ++u) { a0[u] = ap[u][0]; b0[u] = bp[u][0]; }
+    for (int kk = 0; kk < KS; ++kk) {
+        // operands of the next k-step first (the last iteration re-reads its own)
+        const int kn = kk + 1 < KS ? kk + 1 : kk;
+        double a1[RH], b1[RH];
+#pragma unroll
+        for (int u = 0; u < RH; ++u) { a1[u] = ap[u][4 * kn]; b1[u] = bp[u][4 * kn * LD]; }
+#pragma unroll
+        for (int u = 0; u < RH; ++u)
+#pragma unroll
+            for (int v = 0; v < RH; ++v)
+                acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[v], acc[u][v], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < RH; ++u) { a0[u] = a1[u]; b0[u] = b1[u]; }
     }
     if (out) {
 #pragma unroll
@@ -688,37 +689,67 @@ expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ 
     }
     const double *Qb = Q + (long)qi * nn;
     const double t = tt[b];
-    // A = Q t, zero-padded; every thread's loads are in flight together (a loop of
-    // dependent load -> store pairs costs one L2 round trip per iteration)
-    {
-        constexpr int PER = (MSZ + TPB - 1) / TPB;
-        constexpr int CH = PER <= 20 ? PER : 8;      // n <= 64: one round trip for all of Q
-        for (int c0 = 0; c0 < PER; c0 += CH) {
-            double v[CH];
+    // A = Q t, zero-padded.  Thread = (column j, row group g): rows g, g + RP, ... of one
+    // column -- consecutive threads read consecutive addresses, no index division, all of a
+    // thread's loads in flight together (n <= 64: 16 of them), and the column's |.| sum
+    // falls out of the registers: ||A||_1 = max column sum without re-reading LDS.
+    double nrm = 0.0;
+    if (!GLOBAL) {
+        constexpr int RP = TPB / RN;                 // row groups (4 at RN = 64)
+        constexpr int PER = (RN + RP - 1) / RP;      // rows per thread
+        __shared__ double colpart[RP][RN];
+        const int jc = tid % RN, g = tid / RN;
+        const bool active = g < RP;
+        double v[PER];
+        double part = 0.0;
 #pragma unroll
-            for (int u = 0; u < CH; ++u) {
+        for (int u = 0; u < PER; ++u) {
+            const int i = g + u * RP;
+            v[u] = (active && i < n && jc < n) ? Qb[i * n + jc] * t : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i = g + u * RP;
+            if (active && i < RN) B0[i * LD + jc] = v[u];
+            part += fabs(v[u]);
+        }
+        if (active) colpart[g][jc] = part;
+        __syncthreads();
+        if (tid < RN) {
+            double sum = 0.0;
+#pragma unroll
+            for (int r = 0; r < RP; ++r) sum += colpart[r][tid];
+            colsum[tid] = sum;
+        }
+        __syncthreads();
+        for (int jj = 0; jj < RN; ++jj) nrm = fmax(nrm, colsum[jj]);
+    } else {
+        constexpr int PER = (MSZ + TPB - 1) / TPB;
+        for (int c0 = 0; c0 < PER; c0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
                 const int e = (c0 + u) * TPB + tid;
-                const int i = e / LD, j = e - i * LD;
-                v[u] = (e < MSZ && i < n && j < n) ? Qb[i * n + j] * t : 0.0;
+                const int i = e / LD, jx = e - i * LD;
+                v[u] = (e < MSZ && i < n && jx < n) ? Qb[i * n + jx] * t : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < CH; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int e = (c0 + u) * TPB + tid;
                 if (e < MSZ) B0[e] = v[u];
             }
         }
+        __syncthreads();
+        // ||A||_1 = max column sum
+        for (int jx = tid; jx < RN; jx += TPB) {
+            double sum = 0.0;
+            for (int i = 0; i < n; ++i) sum += fabs(B0[i * LD + jx]);
+            colsum[jx] = sum;
+        }
+        __syncthreads();
+        for (int jj = 0; jj < RN; ++jj) nrm = fmax(nrm, colsum[jj]);
     }
-    __syncthreads();
     RT_EXPM_STAMP(1);
-    // ||A||_1 = max column sum
-    for (int j = tid; j < RN; j += TPB) {
-        double s = 0.0;
-        for (int i = 0; i < n; ++i) s += fabs(B0[i * LD + j]);
-        colsum[j] = s;
-    }
-    __syncthreads();
-    double nrm = 0.0;
-    for (int j = 0; j < RN; ++j) nrm = fmax(nrm, colsum[j]);
     if (!(nrm < 1e300)) {                      // inf / NaN in Q * t (block-uniform)
         for (int e = tid; e < nn; e += TPB) Pb[e] = __builtin_nan("");
         if (info && tid == 0) { info[2 * b] = -1; info[2 * b + 1] = 0; }
@@ -778,9 +809,16 @@ expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ 
     RT_EXPM_STAMP(6);
 
     const double *Xb = B3;
-    for (int e = tid; e < nn; e += TPB) {
-        const int i = e / n, j = e - i * n;
-        Pb[e] = Xb[i * LD + j];
+    if (!GLOBAL) {               // thread = (column, row group) as in the load: no division
+        constexpr int RP = TPB / RN;
+        const int jc = tid % RN, g = tid / RN;
+        if (g < RP && jc < n)
+            for (int i = g; i < n; i += RP) Pb[i * n + jc] = Xb[i * LD + jc];
+    } else {
+        for (int e = tid; e < nn; e += TPB) {
+            const int i = e / n, j = e - i * n;
+            Pb[e] = Xb[i * LD + j];
+        }
     }
     if (step >= 0 && frag_kind == 0) {
         for (int e = tid; e < nn; e += TPB) {
@@ -792,11 +830,13 @@ expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ 
         // padding of Xb is zero, so no bounds check (KP pairs cover <= RN columns)
         const int KP = (KSn + 1) / 2;
         const int total = NTn * KP * 128;
-        for (int e = tid; e < total; e += TPB) {
+        // 128 entries per (row tile, k-pair): the block index is wave-uniform arithmetic
+        for (int blk = tid >> 7; blk < NTn * KP; blk += TPB >> 7) {
+            const int e = blk * 128 + (tid & 127);
             const int e2 = e & 1;
             const int ln = (e >> 1) & 63;
-            const int qq = (e >> 7) % KP;
-            const int mm = (e >> 7) / KP;
+            const int qq = blk % KP;
+            const int mm = blk / KP;
             const int row = 16 * mm + (ln & 15);
             const int col = 4 * (2 * qq + e2) + (ln >> 4);
             Pfrag[(long)step * total + e] = (col < RN) ? Xb[row * LD + col] : 0.0;
@@ -1231,7 +1271,7 @@ int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
             RT_HIP(hipStreamSynchronize(ctx->stream));
             if (armed) {
                 RT_HIP(hipMemcpyFromSymbol(tr, HIP_SYMBOL(rt_expm_trace), sizeof tr));
-                fprintf(stderr, "[raoteh_amd] expm trace (clocks, workgroup 1): load %llu, norm %llu, "
+                fprintf(stderr, "[raoteh_amd] expm trace (clocks, workgroup 1): load + norm %llu, order %llu, "
                         "A^2 A^3 %llu, block %llu, Horner %llu, squarings %llu, store %llu; total %llu\n",
                         tr[1] - tr[0], tr[2] - tr[1], tr[3] - tr[2], tr[4] - tr[3], tr[5] - tr[4],
                         tr[6] - tr[5], tr[7] - tr[6], tr[7] - tr[0]);
