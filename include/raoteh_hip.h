@@ -34,7 +34,7 @@ extern "C" {
 #define RT_ERR_UNSUPPORTED  -3   /* valid input outside implemented limits   */
 #define RT_ERR_NOMEM        -4   /* host or device allocation failed         */
 #define RT_ERR_RCCL         -5   /* RCCL missing or a collective failed      */
-#define RT_ERR_SINGULAR     -6   /* expm: Pade denominator singular          */
+#define RT_ERR_SINGULAR     -6   /* expm: non-finite Q t / singular Pade den. */
 #define RT_ERR_ZERO_PROB    -7   /* a chain's observations have likelihood 0 */
 
 #define RT_MAX_STATES       64   /* n <= 64 for the pruning kernels          */

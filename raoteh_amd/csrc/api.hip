@@ -258,7 +258,8 @@ extern "C" int rt_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *Q,
     if (info) memcpy(info, hinfo.data(), (size_t)count * 8);
     for (int64_t b = 0; b < count; ++b)
         if (hinfo[2 * b] < 0) {
-            rt_set_error("expm: singular Pade denominator for matrix %lld", (long long)b);
+            rt_set_error("expm: matrix %lld has a non-finite entry or norm (Taylor scheme), or its Pade "
+                         "denominator is singular (RAOTEH_EXPM=pade)", (long long)b);
             return RT_ERR_SINGULAR;
         }
     return RT_OK;
@@ -540,8 +541,9 @@ extern "C" int rt_model_get_expm_info(rt_model *m, int32_t *info)
     RT_HIP(hipMemcpy(info, m->d_info, (size_t)m->nnodes * 8, hipMemcpyDeviceToHost));
     for (int64_t v = 1; v < m->nnodes; ++v)
         if (info[2 * v] < 0) {
-            rt_set_error("expm: singular Pade denominator on the edge above node %lld",
-                         (long long)v);
+            rt_set_error("expm: the matrix of the edge above node %lld has a non-finite entry or "
+                         "norm (Taylor scheme), or its Pade denominator is singular "
+                         "(RAOTEH_EXPM=pade)", (long long)v);
             return RT_ERR_SINGULAR;
         }
     return RT_OK;
