@@ -394,6 +394,11 @@ int rt_chains_get_statistics(rt_chains *chains, double *dwell, int64_t *transiti
             int32_t *node_states);
 int rt_chains_get_rows(rt_chains *chains, int64_t capacity, int64_t *chain_offset,
             int32_t *edge, double *length, int32_t *state);
+/* Metropolis-Hastings on top of the sweeps (_sampler.py:393-551): rt_chains_snapshot keeps
+ * a copy of the current histories; after further sweeps rt_chains_restore gives the chains
+ * with reject[c] != 0 (uint8[nchains]) their snapshot back, the others keep what they have. */
+int rt_chains_snapshot(rt_chains *chains);
+int rt_chains_restore(rt_chains *chains, const uint8_t *reject);
 int rt_chains_destroy(rt_chains *chains);
 
 #ifdef __cplusplus

@@ -139,6 +139,8 @@ SIGNATURES = {
     'rt_chains_get_sizes': (c_int, [c_void_p, _p_i64, _p_i64, _p_i64]),
     'rt_chains_get_statistics': (c_int, [c_void_p, _p_f64, _p_i64, _p_i32]),
     'rt_chains_get_rows': (c_int, [c_void_p, c_int64, _p_i64, _p_i32, _p_f64, _p_i32]),
+    'rt_chains_snapshot': (c_int, [c_void_p]),
+    'rt_chains_restore': (c_int, [c_void_p, POINTER(c_ubyte)]),
     'rt_chains_destroy': (c_int, [c_void_p]),
 }
 

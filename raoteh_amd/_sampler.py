@@ -45,7 +45,8 @@ from ._tree import TreeArrays, check_square_dense
 from ._util import StructuralZeroProb
 from .device import get_context
 
-__all__ = ['HistoryBatch', 'DeviceHistoryBatch', 'gen_restricted_histories', 'gen_histories', 'get_total_rates',
+__all__ = ['HistoryBatch', 'DeviceHistoryBatch', 'gen_restricted_histories', 'gen_mh_histories',
+           'trajectory_log_likelihoods', 'gen_histories', 'get_total_rates',
            'poisson_split', 'chunk_forest', 'merge_segments']
 
 
@@ -57,6 +58,46 @@ def get_total_rates(Q):
     """Rate away from each state (_mjp_dense.get_total_rates: minus the diagonal)."""
     check_square_dense(Q)
     return -np.diag(Q).astype(np.float64)
+
+
+def trajectory_log_likelihoods(dwell, transitions, root_states, Q, root_distn=None):
+    """_mjp_dense.get_trajectory_log_likelihood (:188-240) for a batch of histories given
+    by their statistics: log prior of the root state - sum_a dwell[a] q_a + sum_{a != b}
+    transitions[a, b] log Q[a, b].  root_distn None: no root term."""
+    Q = np.asarray(Q, dtype=np.float64)
+    n = Q.shape[0]
+    rates = get_total_rates(Q)
+    off = ~np.eye(n, dtype=bool)
+    with np.errstate(divide='ignore'):
+        logq = np.where(off & (Q > 0), np.log(np.where(Q > 0, Q, 1.0)), -np.inf)
+    tr = np.asarray(transitions, dtype=np.float64)
+    trans_ll = np.where(tr[:, off] > 0, tr[:, off] * logq[off][None, :], 0.0).sum(axis=1)
+    ll = -np.asarray(dwell, dtype=np.float64).dot(rates) + trans_ll
+    if root_distn is not None:
+        with np.errstate(divide='ignore'):
+            ll = ll + np.log(np.asarray(root_distn, dtype=np.float64)[np.asarray(root_states)])
+    return ll
+
+
+def _mh_step(batch, target, rng, cache):
+    """One Metropolis-Hastings step of every chain (_sampler.py:470-520): a Rao-Teh sweep
+    under the batch's own process is the proposal; ``target(batch) -> f64[nchains]`` is the
+    log density it is corrected to.  Returns the bool[nchains] acceptance flags; rejected
+    chains are back at their previous history."""
+    if cache.get('biased') is None:
+        cache['biased'] = batch.trajectory_log_likelihoods()
+        cache['target'] = np.asarray(target(batch), dtype=np.float64)
+    batch.snapshot()
+    batch.sweep()
+    biased = batch.trajectory_log_likelihoods()
+    tgt = np.asarray(target(batch), dtype=np.float64)
+    log_ratio = tgt - cache['target'] - biased + cache['biased']
+    accept = (log_ratio > 0) | (rng.random(batch.nchains) < np.exp(np.minimum(log_ratio, 0.0)))
+    accept &= ~np.isnan(log_ratio)
+    batch.restore(~accept)
+    cache['biased'] = np.where(accept, biased, cache['biased'])
+    cache['target'] = np.where(accept, tgt, cache['target'])
+    return accept
 
 
 # ---------------------------------------------------------------------------
@@ -308,6 +349,37 @@ class HistoryBatch(object):
     def root_states(self):
         return self.node_states[:, 0].copy()
 
+    def trajectory_log_likelihoods(self):
+        """f64[nchains]: log density of each history under the batch's own process."""
+        return trajectory_log_likelihoods(self.dwell_times(), self.transition_counts(),
+                                          self.root_states(), self.Q, self.root_distn)
+
+    def snapshot(self):
+        self._snap = (self.chain.copy(), self.edge.copy(), self.length.copy(), self.state.copy(),
+                      self.node_states.copy())
+
+    def restore(self, reject):
+        """The chains flagged in ``reject`` (bool[nchains]) return to the snapshot."""
+        reject = np.asarray(reject, dtype=bool)
+        if not reject.any():
+            return
+        sc, se, sl, ss, sn = self._snap
+        keep = ~reject[self.chain]
+        back = reject[sc]
+        chain = np.concatenate([self.chain[keep], sc[back]])
+        order = np.argsort(chain, kind='stable')          # rows of a chain come from one side
+        self.chain = chain[order]
+        self.edge = np.concatenate([self.edge[keep], se[back]])[order]
+        self.length = np.concatenate([self.length[keep], sl[back]])[order]
+        self.state = np.concatenate([self.state[keep], ss[back]])[order]
+        self.node_states = np.where(reject[:, None], sn, self.node_states)
+
+    def mh_sweep(self, target, cache=None):
+        """Metropolis-Hastings step towards ``target(batch) -> log density per chain``."""
+        if cache is None:
+            cache = self.__dict__.setdefault('_mh_cache', {})
+        return _mh_step(self, target, self.rng, cache)
+
     def history(self, c=0):
         """Chain c as the reference yields it: an undirected nx tree whose edges carry
         'weight' and 'state'; the nodes of T keep their ids, event nodes are numbered from
@@ -411,6 +483,28 @@ class DeviceHistoryBatch(object):
     def root_states(self):
         return self.node_states[:, 0].copy()
 
+    def trajectory_log_likelihoods(self):
+        return trajectory_log_likelihoods(self.dwell_times(), self.transition_counts(),
+                                          self.root_states(), self.Q, self.root_distn)
+
+    def snapshot(self):
+        _lib.check(_lib.lib().rt_chains_snapshot(self._h))
+
+    def restore(self, reject):
+        """Undo the ONE sweep since the snapshot for the chains flagged in ``reject``."""
+        reject = np.ascontiguousarray(reject, dtype=np.uint8)
+        if reject.shape != (self.nchains,):
+            raise ValueError('one flag per chain expected')
+        _lib.check(_lib.lib().rt_chains_restore(self._h, _ptr(reject, ctypes.c_ubyte)))
+
+    def mh_sweep(self, target, cache=None):
+        """Metropolis-Hastings step towards ``target(batch) -> log density per chain``."""
+        if cache is None:
+            cache = self.__dict__.setdefault('_mh_cache', {})
+        if not hasattr(self, 'rng'):
+            self.rng = np.random.Generator(np.random.PCG64(self.seed))
+        return _mh_step(self, target, self.rng, cache)
+
     def rows(self):
         """(chain int64[S], edge int64[S], length f64[S], state int64[S]) of all histories."""
         total = self.sizes()[0]
@@ -501,3 +595,37 @@ def gen_histories(T, Q, node_to_state, root=None, root_distn=None, uniformizatio
                                       uniformization_factor=uniformization_factor,
                                       nhistories=nhistories, seed=seed, ctx=ctx):
         yield h
+
+
+def gen_mh_histories(T, Q, node_to_allowed_states, target_log_likelihood_callback, root,
+                     root_distn=None, uniformization_factor=2, nhistories=None, seed=0, ctx=None):
+    """raoteh.sampler._sampler.gen_mh_histories (:393-551): Rao-Teh proposals under ``Q``
+    corrected by Metropolis-Hastings to the density ``target_log_likelihood_callback(T_aug)``
+    gives for a history (an nx tree with 'weight' and 'state' on its edges).  Yields
+    (history, accepted): a rejected proposal yields the previous history again."""
+    bad = set(node_to_allowed_states) - set(T)
+    if bad:
+        raise ValueError('some of the nodes which have been annotated with state restrictions '
+                         'are not even in the tree: ' + str(sorted(bad)))
+    dense, allowed, rd, labels = _dense_problem(Q, node_to_allowed_states, root_distn)
+    batch = DeviceHistoryBatch(T, root, dense, node_to_allowed_states=allowed, nchains=1,
+                               root_distn=rd, uniformization_factor=uniformization_factor,
+                               seed=seed, ctx=ctx)
+
+    def labelled(b):
+        h = b.history(0)
+        if labels is not None:
+            for _, _, d in h.edges(data=True):
+                d['state'] = labels[d['state']]
+        return h
+
+    def target(b):
+        return np.array([target_log_likelihood_callback(labelled(b))], dtype=np.float64)
+
+    yield labelled(batch), True
+    count = 1
+    while nhistories is None or count < nhistories:
+        accepted = bool(batch.mh_sweep(target)[0])
+        yield labelled(batch), accepted
+        count += 1
+

@@ -781,6 +781,32 @@ sweep_stats_kernel(long nchains, int n, const long *__restrict__ start, const in
     }
 }
 
+// Metropolis-Hastings: the chains flagged in `reject` get the rows of the snapshot back.  A
+// chain's current run has room for them: the sweep since the snapshot only added rows
+// before the merge, and the run keeps the room of the split rows.
+__global__ void __launch_bounds__(64 * SWEEP_WAVES)
+sweep_restore_kernel(long nchains, int N, const unsigned char *__restrict__ reject,
+                     const long *__restrict__ start_k, const int *__restrict__ cnt_k,
+                     const int *__restrict__ edge_k, const double *__restrict__ len_k,
+                     const int *__restrict__ state_k, const int *__restrict__ node_state_k,
+                     const long *__restrict__ start, int *__restrict__ cnt,
+                     int *__restrict__ edge, double *__restrict__ len, int *__restrict__ state,
+                     int *__restrict__ node_state)
+{
+    const int lane = threadIdx.x & 63;
+    const long c = (long)blockIdx.x * SWEEP_WAVES + (threadIdx.x >> 6);
+    if (c >= nchains || !reject[c]) return;
+    const long src = start_k[c], dst = start[c];
+    const int m = cnt_k[c];
+    for (int i = lane; i < m; i += 64) {
+        edge[dst + i] = edge_k[src + i];
+        len[dst + i] = len_k[src + i];
+        state[dst + i] = state_k[src + i];
+    }
+    for (int v = lane; v < N; v += 64) node_state[c * N + v] = node_state_k[c * N + v];
+    if (lane == 0) cnt[c] = m;
+}
+
 }  // namespace
 
 struct rt_chains {
@@ -801,8 +827,18 @@ struct rt_chains {
     unsigned long long *d_cmask = nullptr;
     double *d_L = nullptr;
     int64_t last_rows = 0, last_chunks = 0;
+    // rt_chains_snapshot: the histories a Metropolis-Hastings step may return to
+    int64_t cap_backup = 0;
+    bool has_backup = false;
+    uint64_t backup_step = 0;              // nsweeps when the snapshot was taken
+    int *d_edge_k = nullptr, *d_state_k = nullptr, *d_cnt_k = nullptr, *d_node_state_k = nullptr;
+    double *d_len_k = nullptr;
+    long *d_start_k = nullptr;
+    unsigned char *d_reject = nullptr;
     ~rt_chains()
     {
+        hipFree(d_edge_k); hipFree(d_state_k); hipFree(d_cnt_k); hipFree(d_node_state_k);
+        hipFree(d_len_k); hipFree(d_start_k); hipFree(d_reject);
         hipFree(P.d_col); hipFree(P.d_val); hipFree(P.d_rowbits); hipFree(P.d_colbits);
         hipFree(P.d_dense);
         hipFree(d_parent); hipFree(d_branch); hipFree(d_rates); hipFree(d_root);
@@ -1108,6 +1144,62 @@ extern "C" int rt_chains_get_rows(rt_chains *h, int64_t capacity, int64_t *chain
             length[dst] = l[src];
             state[dst] = s[src];
         }
+    return RT_OK;
+}
+
+extern "C" int rt_chains_snapshot(rt_chains *h)
+{
+    RT_REQUIRE(h, "null pointer");
+    RT_HIP(hipSetDevice(h->ctx->device));
+    hipStream_t st = h->ctx->stream;
+    const int64_t C = h->nchains, N = h->N;
+    if (!h->d_start_k) {
+        RT_HIP(hipMalloc((void **)&h->d_start_k, C * sizeof(long)));
+        RT_HIP(hipMalloc((void **)&h->d_cnt_k, C * 4));
+        RT_HIP(hipMalloc((void **)&h->d_node_state_k, C * N * 4));
+        RT_HIP(hipMalloc((void **)&h->d_reject, C));
+    }
+    if (h->cap_backup < h->cap_rows) {
+        RT_HIP(hipStreamSynchronize(st));
+        hipFree(h->d_edge_k); hipFree(h->d_state_k); hipFree(h->d_len_k);
+        h->d_edge_k = h->d_state_k = nullptr;
+        h->d_len_k = nullptr;
+        RT_HIP(hipMalloc((void **)&h->d_edge_k, h->cap_rows * 4));
+        RT_HIP(hipMalloc((void **)&h->d_state_k, h->cap_rows * 4));
+        RT_HIP(hipMalloc((void **)&h->d_len_k, h->cap_rows * 8));
+        h->cap_backup = h->cap_rows;
+    }
+    const int64_t span = h->cap_rows;
+    RT_HIP(hipMemcpyAsync(h->d_edge_k, h->d_edge_a, span * 4, hipMemcpyDeviceToDevice, st));
+    RT_HIP(hipMemcpyAsync(h->d_state_k, h->d_state_a, span * 4, hipMemcpyDeviceToDevice, st));
+    RT_HIP(hipMemcpyAsync(h->d_len_k, h->d_len_a, span * 8, hipMemcpyDeviceToDevice, st));
+    RT_HIP(hipMemcpyAsync(h->d_start_k, h->d_start, C * sizeof(long), hipMemcpyDeviceToDevice, st));
+    RT_HIP(hipMemcpyAsync(h->d_cnt_k, h->d_cnt, C * 4, hipMemcpyDeviceToDevice, st));
+    RT_HIP(hipMemcpyAsync(h->d_node_state_k, h->d_node_state, C * N * 4, hipMemcpyDeviceToDevice, st));
+    h->has_backup = true;
+    h->backup_step = h->nsweeps;
+    return RT_OK;
+}
+
+extern "C" int rt_chains_restore(rt_chains *h, const uint8_t *reject)
+{
+    RT_REQUIRE(h && reject, "null pointer");
+    RT_REQUIRE(h->has_backup, "no snapshot to return to");
+    // a chain's run has room for its snapshot only right after the sweep that followed it
+    // (the run keeps the room of that sweep's split rows, which include every snapshot row)
+    RT_REQUIRE(h->nsweeps == h->backup_step + 1,
+               "rt_chains_restore undoes exactly one sweep (%llu since the snapshot)",
+               (unsigned long long)(h->nsweeps - h->backup_step));
+    RT_HIP(hipSetDevice(h->ctx->device));
+    hipStream_t st = h->ctx->stream;
+    const int64_t C = h->nchains;
+    RT_HIP(hipMemcpyAsync(h->d_reject, reject, C, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(sweep_restore_kernel, dim3(sweep_grid(C)), dim3(64 * SWEEP_WAVES), 0, st,
+                       (long)C, (int)h->N, h->d_reject, h->d_start_k, h->d_cnt_k, h->d_edge_k,
+                       h->d_len_k, h->d_state_k, h->d_node_state_k, h->d_start, h->d_cnt,
+                       h->d_edge_a, h->d_len_a, h->d_state_a, h->d_node_state);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipStreamSynchronize(st));           // `reject` is the caller's buffer
     return RT_OK;
 }
 

@@ -1905,3 +1905,78 @@ def test_device_resident_histories_are_consistent_and_reproducible(ra):
     bad[5, cols[0]] = 0
     with pytest.raises(ra.pkg.StructuralZeroProb):
         _sampler.DeviceHistoryBatch(T, root, Q, node_masks=bad, ctx=ra.ctx)
+
+
+@pytest.mark.parametrize('where', ['device', 'host'])
+def test_metropolis_hastings_corrects_rao_teh_to_another_process(ra, where):
+    """_sampler.gen_mh_histories (:393-551) on a batch: proposals are Rao-Teh sweeps under
+    Q, the target density is the trajectory log-likelihood under ANOTHER rate matrix and
+    root distribution; the corrected chains must reproduce the expected history
+    statistics of that other process (expectation path, pinned to the oracle).  With the
+    target equal to the proposal process every proposal is accepted."""
+    from raoteh_amd import _mjp_dense, _sampler
+    cfg = ra.synth.make_config('c1', nsites=2)
+    T, root, n = cfg['T'], cfg['root'], cfg['nstates']
+    Q = cfg['Q_default']
+    rng = np.random.RandomState(12)
+    Q2 = Q * rng.uniform(0.4, 2.5, size=Q.shape)
+    np.fill_diagonal(Q2, 0.0)
+    Q2 -= np.diag(Q2.sum(axis=1))
+    rd2 = rng.dirichlet(np.ones(n) * 3)
+    allowed = dict((v, set(range(n))) for v in T)
+    for leaf, s in zip(cfg['leaves'], cfg['leaf_states'][0]):
+        allowed[leaf] = {int(s)}
+    want_dwell, want_root, _ = _mjp_dense.get_expected_history_statistics(
+        T, allowed, root, n, root_distn=rd2, Q_default=Q2)
+    B = 3000
+    cls = _sampler.DeviceHistoryBatch if where == 'device' else _sampler.HistoryBatch
+    batch = cls(T, root, Q, node_to_allowed_states=allowed, nchains=B,
+                root_distn=cfg['root_distn'], seed=31, ctx=ra.ctx)
+
+    def same(b):
+        return b.trajectory_log_likelihoods()
+
+    def other(b):
+        return _sampler.trajectory_log_likelihoods(b.dwell_times(), b.transition_counts(),
+                                                   b.root_states(), Q2, rd2)
+
+    assert batch.mh_sweep(same, cache={}).all()
+    cache = {}
+    dwell = np.zeros((B, n))
+    roots = np.zeros((B, n))
+    rate = 0.0
+    burn, keep = 25, 40
+    for it in range(burn + keep):
+        accepted = batch.mh_sweep(other, cache=cache)
+        if it >= burn:
+            dwell += batch.dwell_times()
+            roots[np.arange(B), batch.root_states()] += 1
+            rate += accepted.mean()
+    dwell /= keep
+    roots /= keep
+    assert 0.1 < rate / keep < 0.999                       # some proposals are rejected
+    for s in range(n):
+        for sample, expected in ((dwell[:, s], want_dwell[s]), (roots[:, s], want_root[s])):
+            se = sample.std(ddof=1) / np.sqrt(B)
+            assert abs(sample.mean() - expected) <= 5 * se + 1e-3 * max(abs(expected), 1e-2)
+    # the proposal process alone does NOT give these numbers (the test has power)
+    _, plain_root, _ = _mjp_dense.get_expected_history_statistics(
+        T, allowed, root, n, root_distn=cfg['root_distn'], Q_default=Q)
+    assert np.abs(np.asarray(plain_root) - np.asarray(want_root)).max() > 0.02
+    if where == 'device':
+        # a snapshot goes back exactly one sweep
+        batch.snapshot()
+        batch.sweep(2)
+        with pytest.raises(ValueError):
+            batch.restore(np.ones(B, dtype=bool))
+        # the reference's generator: (history, accepted) pairs
+        count = 0
+        total = sum(d['weight'] for _, _, d in T.edges(data=True))
+        for h, ok in _sampler.gen_mh_histories(
+                T, Q, allowed, lambda tree: -0.5 * sum(d['weight'] for _, _, d in tree.edges(data=True)
+                                                       if d['state'] == 0),
+                root, root_distn=cfg['root_distn'], nhistories=6, seed=2, ctx=ra.ctx):
+            count += 1
+            assert isinstance(ok, bool)
+            assert sum(d['weight'] for _, _, d in h.edges(data=True)) == pytest.approx(total, rel=1e-12)
+        assert count == 6
