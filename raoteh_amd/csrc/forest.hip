@@ -28,6 +28,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <hipcub/hipcub.hpp>
 
 namespace {
 
@@ -248,6 +249,256 @@ forest_sample_kernel(int n, long ntrees, const long *__restrict__ off,
     if (lane == 0) status[tree] = st;
 }
 
+// ---- small state spaces: several trees per wave ----------------------------------------------
+// With a wave per tree and a lane per state, a 4-state model uses 4 of 64 lanes and the three
+// passes are chains of per-node round trips (LDS, shuffles) whose latency is the same whatever
+// the width.  For n <= 16 a wave takes G = 64 / NP consecutive trees (NP = 4, 8 or 16 lanes
+// each): lane = (group, state), ballots are cut into the group's bits, prefix sums run inside
+// the group, and the trees' nodes -- consecutive in the forest -- share the wave's LDS image.
+// Same arithmetic per tree as the kernels above (same draws: the counter is the node index).
+template <int NP>
+struct group_geom {
+    static constexpr int G = 64 / NP;
+    static constexpr unsigned long long mask = NP == 64 ? ~0ull : (1ull << NP) - 1ull;
+};
+
+template <int NP>
+__global__ void __launch_bounds__(64 * FOREST_WAVES)
+forest_sets_grouped_kernel(int n, long ntrees, const long *__restrict__ off,
+                           const int *__restrict__ parent,
+                           const unsigned long long *__restrict__ rowbits,
+                           const unsigned long long *__restrict__ colbits,
+                           unsigned long long *__restrict__ allowed, int forward)
+{
+    constexpr int G = group_geom<NP>::G;
+    __shared__ unsigned long long lset[FOREST_WAVES][FOREST_CAP];
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int g = lane / NP, s = lane % NP;
+    const long t0 = ((long)blockIdx.x * FOREST_WAVES + w) * G;
+    if (t0 >= ntrees) return;
+    const long tree = t0 + g;
+    const bool active = tree < ntrees;
+    const long lo = active ? off[tree] : 0, hi = active ? off[tree + 1] : 0;
+    const long wlo = off[t0], whi = off[t0 + G < ntrees ? t0 + G : ntrees];
+    const bool fits = whi - wlo <= FOREST_CAP;
+    const unsigned long long rb = s < n ? rowbits[s] : 0ull;
+    const unsigned long long cb = s < n ? colbits[s] : 0ull;
+    const int shift = g * NP;
+    if (fits) {
+        for (long i = lane; i < whi - wlo; i += 64) lset[w][i] = allowed[wlo + i];
+        wave_lds_order();
+    }
+    for (long step = 0;; ++step) {
+        const long v = hi - 1 - step;
+        const bool valid = active && v > lo;
+        if (!__any(valid)) break;
+        const unsigned long long cset =
+            !valid ? 0ull : fits ? lset[w][v - wlo] : coherent_load(&allowed[v]);
+        const unsigned long long keep =
+            (__ballot(valid && (rb & cset) != 0ull) >> shift) & group_geom<NP>::mask;
+        if (valid && s == 0) {
+            const long p = lo + parent[v];
+            if (fits) lset[w][p - wlo] &= keep;
+            else coherent_store(&allowed[p], coherent_load(&allowed[p]) & keep);
+        }
+        wave_lds_order();
+    }
+    for (long step = 0; forward; ++step) {
+        const long v = lo + 1 + step;
+        const bool valid = active && v < hi;
+        if (!__any(valid)) break;
+        const long p = valid ? lo + parent[v] : 0;
+        const unsigned long long pset =
+            !valid ? 0ull : fits ? lset[w][p - wlo] : coherent_load(&allowed[p]);
+        const unsigned long long reach =
+            (__ballot(valid && (cb & pset) != 0ull) >> shift) & group_geom<NP>::mask;
+        if (valid && s == 0) {
+            if (fits) lset[w][v - wlo] &= reach;
+            else coherent_store(&allowed[v], coherent_load(&allowed[v]) & reach);
+        }
+        wave_lds_order();
+    }
+    if (fits)
+        for (long i = lane; i < whi - wlo; i += 64) allowed[wlo + i] = lset[w][i];
+}
+
+template <int NP>
+__global__ void __launch_bounds__(64 * FOREST_WAVES)
+forest_pmap_grouped_kernel(int n, long ntrees, const long *__restrict__ off,
+                           const int *__restrict__ parent, int width,
+                           const int *__restrict__ ecol, const double *__restrict__ eval,
+                           const unsigned long long *__restrict__ allowed, double *__restrict__ L)
+{
+    constexpr int G = group_geom<NP>::G;
+    __shared__ double vec[FOREST_WAVES][64];
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int g = lane / NP, s = lane % NP;
+    const long t0 = ((long)blockIdx.x * FOREST_WAVES + w) * G;
+    if (t0 >= ntrees) return;
+    const long tree = t0 + g;
+    const bool active = tree < ntrees;
+    const long lo = active ? off[tree] : 0, hi = active ? off[tree + 1] : 0;
+    const bool live = active && s < n;
+    for (long v = lo; v < hi; ++v)
+        if (live) L[v * n + s] = (allowed[v] >> s) & 1ull ? 1.0 : 0.0;
+    for (long step = 0;; ++step) {
+        const long v = hi - 1 - step;
+        const bool valid = active && v > lo;
+        if (!__any(valid)) break;
+        vec[w][lane] = (valid && live) ? L[v * n + s] : 0.0;
+        wave_lds_order();
+        double msg = 0.0;
+        if (s < n)
+            for (int k = 0; k < width; ++k)
+                msg = fma(eval[k * 64 + s], vec[w][g * NP + ecol[k * 64 + s]], msg);
+        if (valid && live) L[(lo + parent[v]) * n + s] *= msg;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int NP>
+__global__ void __launch_bounds__(64 * FOREST_WAVES)
+forest_sample_grouped_kernel(int n, long ntrees, const long *__restrict__ off,
+                             const int *__restrict__ parent, const double *__restrict__ P,
+                             const double *__restrict__ root_distn, const double *__restrict__ L,
+                             unsigned long long seed, unsigned long long sweep,
+                             int *__restrict__ states, int *__restrict__ status)
+{
+    constexpr int G = group_geom<NP>::G;
+    __shared__ int lstate[FOREST_WAVES][FOREST_CAP];
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int g = lane / NP, s = lane % NP;
+    const long t0 = ((long)blockIdx.x * FOREST_WAVES + w) * G;
+    if (t0 >= ntrees) return;
+    const long tree = t0 + g;
+    const bool active = tree < ntrees;
+    const long lo = active ? off[tree] : 0, hi = active ? off[tree + 1] : 0;
+    const long wlo = off[t0], whi = off[t0 + G < ntrees ? t0 + G : ntrees];
+    const bool fits = whi - wlo <= FOREST_CAP;
+    const bool live = active && s < n;
+    const int shift = g * NP;
+    int st = 0;
+    for (long step = 0;; ++step) {
+        const long v = lo + step;
+        const bool valid = active && v < hi;
+        if (!__any(valid)) break;
+        double prior = 0.0;
+        if (valid && live) {
+            if (v == lo) prior = root_distn ? root_distn[s] : 1.0;
+            else {
+                const long p = lo + parent[v];
+                const int ps = fits ? lstate[w][p - wlo]
+                                    : __hip_atomic_load(&states[p], __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT);
+                prior = ps >= 0 ? P[(long)ps * n + s] : 0.0;
+            }
+        }
+        const double wgt = (valid && live) ? fmax(prior * L[v * n + s], 0.0) : 0.0;
+        double cdf = wgt;                         // inclusive prefix sum inside the group
+#pragma unroll
+        for (int d = 1; d < NP; d <<= 1) {
+            const double y = __shfl_up(cdf, d, 64);
+            if (s >= d) cdf += y;
+        }
+        const double total = __shfl(cdf, shift + NP - 1, 64);
+        const bool ok = total > 0.0 && total < 1e308 * 10.0;
+        const double target = (valid && ok) ? philox_uniform(seed, sweep, (unsigned long long)v) * total
+                                            : 0.0;
+        const unsigned long long hit =
+            (__ballot(valid && ok && wgt > 0.0 && cdf > target) >> shift) & group_geom<NP>::mask;
+        const unsigned long long pos =
+            (__ballot(valid && wgt > 0.0) >> shift) & group_geom<NP>::mask;
+        int pick = -1;
+        if (valid) {
+            if (ok) pick = hit ? __ffsll((long long)hit) - 1 : 63 - __clzll((long long)pos);
+            else if (st == 0) st = v == lo ? 1 : 2;
+            if (s == 0) {
+                if (fits) {
+                    lstate[w][v - wlo] = pick;
+                    states[v] = pick;
+                } else {
+                    __hip_atomic_store(&states[v], pick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        wave_lds_order();
+    }
+    if (active && s == 0) status[tree] = st;
+}
+
+// the three passes, by state count
+unsigned forest_grid_grouped(int64_t ntrees, int G)
+{
+    const int64_t waves = (ntrees + G - 1) / G;
+    return (unsigned)((waves + FOREST_WAVES - 1) / FOREST_WAVES);
+}
+
+void launch_forest_sets(int n, long ntrees, const long *off, const int *parent,
+                        const unsigned long long *rowbits, const unsigned long long *colbits,
+                        unsigned long long *allowed, int forward, hipStream_t st)
+{
+    const dim3 block(64 * FOREST_WAVES);
+    const bool wide = getenv("RAOTEH_FOREST_WAVE_PER_TREE") != nullptr;
+    if (n <= 4 && !wide)
+        hipLaunchKernelGGL(forest_sets_grouped_kernel<4>, dim3(forest_grid_grouped(ntrees, 16)), block,
+                           0, st, n, ntrees, off, parent, rowbits, colbits, allowed, forward);
+    else if (n <= 8 && !wide)
+        hipLaunchKernelGGL(forest_sets_grouped_kernel<8>, dim3(forest_grid_grouped(ntrees, 8)), block,
+                           0, st, n, ntrees, off, parent, rowbits, colbits, allowed, forward);
+    else if (n <= 16 && !wide)
+        hipLaunchKernelGGL(forest_sets_grouped_kernel<16>, dim3(forest_grid_grouped(ntrees, 4)), block,
+                           0, st, n, ntrees, off, parent, rowbits, colbits, allowed, forward);
+    else
+        hipLaunchKernelGGL(forest_sets_kernel, dim3(forest_grid_grouped(ntrees, 1)), block, 0, st, n,
+                           ntrees, off, parent, rowbits, colbits, allowed, forward);
+}
+
+void launch_forest_pmap(int n, long ntrees, const long *off, const int *parent, int width,
+                        const int *ecol, const double *eval, const unsigned long long *allowed,
+                        double *L, hipStream_t st)
+{
+    const dim3 block(64 * FOREST_WAVES);
+    const bool wide = getenv("RAOTEH_FOREST_WAVE_PER_TREE") != nullptr;
+    if (n <= 4 && !wide)
+        hipLaunchKernelGGL(forest_pmap_grouped_kernel<4>, dim3(forest_grid_grouped(ntrees, 16)), block,
+                           0, st, n, ntrees, off, parent, width, ecol, eval, allowed, L);
+    else if (n <= 8 && !wide)
+        hipLaunchKernelGGL(forest_pmap_grouped_kernel<8>, dim3(forest_grid_grouped(ntrees, 8)), block,
+                           0, st, n, ntrees, off, parent, width, ecol, eval, allowed, L);
+    else if (n <= 16 && !wide)
+        hipLaunchKernelGGL(forest_pmap_grouped_kernel<16>, dim3(forest_grid_grouped(ntrees, 4)), block,
+                           0, st, n, ntrees, off, parent, width, ecol, eval, allowed, L);
+    else
+        hipLaunchKernelGGL(forest_pmap_kernel, dim3(forest_grid_grouped(ntrees, 1)), block, 0, st, n,
+                           ntrees, off, parent, width, ecol, eval, allowed, L);
+}
+
+void launch_forest_sample(int n, long ntrees, const long *off, const int *parent, const double *P,
+                          const double *root_distn, const double *L, unsigned long long seed,
+                          unsigned long long sweep, int *states, int *status, hipStream_t st)
+{
+    const dim3 block(64 * FOREST_WAVES);
+    const bool wide = getenv("RAOTEH_FOREST_WAVE_PER_TREE") != nullptr;
+    if (n <= 4 && !wide)
+        hipLaunchKernelGGL(forest_sample_grouped_kernel<4>, dim3(forest_grid_grouped(ntrees, 16)),
+                           block, 0, st, n, ntrees, off, parent, P, root_distn, L, seed, sweep, states,
+                           status);
+    else if (n <= 8 && !wide)
+        hipLaunchKernelGGL(forest_sample_grouped_kernel<8>, dim3(forest_grid_grouped(ntrees, 8)),
+                           block, 0, st, n, ntrees, off, parent, P, root_distn, L, seed, sweep, states,
+                           status);
+    else if (n <= 16 && !wide)
+        hipLaunchKernelGGL(forest_sample_grouped_kernel<16>, dim3(forest_grid_grouped(ntrees, 4)),
+                           block, 0, st, n, ntrees, off, parent, P, root_distn, L, seed, sweep, states,
+                           status);
+    else
+        hipLaunchKernelGGL(forest_sample_kernel, dim3(forest_grid_grouped(ntrees, 1)), block, 0, st, n,
+                           ntrees, off, parent, P, root_distn, L, seed, sweep, states, status);
+}
+
 // ---- host side -------------------------------------------------------------------------------
 
 struct forest_dev {
@@ -397,15 +648,13 @@ extern "C" int rt_forest_passes(rt_ctx *ctx, int64_t n, int64_t ntrees,
     hipStream_t st = ctx->stream;
     RT_HIP(hipMalloc((void **)&f.d_allowed, total * 8));
     RT_HIP(hipMemcpyAsync(f.d_allowed, allowed_sets, total * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(forest_sets_kernel, dim3(forest_grid(ntrees)), dim3(64 * FOREST_WAVES), 0, st,
-                       (int)n, (long)ntrees, f.d_off, f.d_parent, f.P.d_rowbits, f.P.d_colbits,
-                       (unsigned long long *)f.d_allowed, 1);
+    launch_forest_sets((int)n, (long)ntrees, f.d_off, f.d_parent, f.P.d_rowbits, f.P.d_colbits,
+                       (unsigned long long *)f.d_allowed, 1, st);
     RT_HIP(hipGetLastError());
     if (subtree_probability) {
         RT_HIP(hipMalloc((void **)&f.d_L, total * n * 8));
-        hipLaunchKernelGGL(forest_pmap_kernel, dim3(forest_grid(ntrees)), dim3(64 * FOREST_WAVES), 0,
-                           st, (int)n, (long)ntrees, f.d_off, f.d_parent, f.P.width, f.P.d_col,
-                           f.P.d_val, (const unsigned long long *)f.d_allowed, f.d_L);
+        launch_forest_pmap((int)n, (long)ntrees, f.d_off, f.d_parent, f.P.width, f.P.d_col, f.P.d_val,
+                           (const unsigned long long *)f.d_allowed, f.d_L, st);
         RT_HIP(hipGetLastError());
         RT_HIP(hipMemcpyAsync(subtree_probability, f.d_L, total * n * 8, hipMemcpyDeviceToHost, st));
     }
@@ -436,16 +685,14 @@ static int forest_resample_impl(rt_ctx *ctx, int64_t n, int64_t ntrees,
         RT_HIP(hipMemcpyAsync(f.d_root, root_distn, n * 8, hipMemcpyHostToDevice, st));
     }
     RT_HIP(hipMemcpyAsync(f.d_allowed, allowed_sets, total * 8, hipMemcpyHostToDevice, st));
-    const dim3 grid(forest_grid(ntrees)), block(64 * FOREST_WAVES);
     // one sweep's worth of passes back to back on the stream: sets, pmap, sampling
-    hipLaunchKernelGGL(forest_sets_kernel, grid, block, 0, st, (int)n, (long)ntrees, f.d_off,
-                       f.d_parent, f.P.d_rowbits, f.P.d_colbits, (unsigned long long *)f.d_allowed, 1);
-    hipLaunchKernelGGL(forest_pmap_kernel, grid, block, 0, st, (int)n, (long)ntrees, f.d_off,
-                       f.d_parent, f.P.width, f.P.d_col, f.P.d_val,
-                       (const unsigned long long *)f.d_allowed, f.d_L);
-    hipLaunchKernelGGL(forest_sample_kernel, grid, block, 0, st, (int)n, (long)ntrees, f.d_off,
-                       f.d_parent, f.P.d_dense, f.d_root, f.d_L, (unsigned long long)seed,
-                       (unsigned long long)sweep, f.d_states, f.d_status);
+    launch_forest_sets((int)n, (long)ntrees, f.d_off, f.d_parent, f.P.d_rowbits, f.P.d_colbits,
+                       (unsigned long long *)f.d_allowed, 1, st);
+    launch_forest_pmap((int)n, (long)ntrees, f.d_off, f.d_parent, f.P.width, f.P.d_col, f.P.d_val,
+                       (const unsigned long long *)f.d_allowed, f.d_L, st);
+    launch_forest_sample((int)n, (long)ntrees, f.d_off, f.d_parent, f.P.d_dense, f.d_root, f.d_L,
+                         (unsigned long long)seed, (unsigned long long)sweep, f.d_states, f.d_status,
+                         st);
     RT_HIP(hipGetLastError());
     RT_HIP(hipMemcpyAsync(states, f.d_states, total * 4, hipMemcpyDeviceToHost, st));
     RT_HIP(hipMemcpyAsync(status, f.d_status, ntrees * 4, hipMemcpyDeviceToHost, st));
@@ -494,7 +741,7 @@ extern "C" int rt_forest_resample_states_parents(rt_ctx *ctx, int64_t n, int64_t
 //           omega - q(state) until they pass the row's end, _sample_mjp_dense.py:47-61; Philox
 //           counter = (chain, row, gap), so the second pass regenerates the same gaps)
 //   scan    exclusive prefix sum of the new row counts over the chains (= where each chain's
-//           rows and, shifted, its chunks start)
+//           rows and, shifted, its chunks start; rocPRIM's device scan)
 //   split   one wave per chain: write the new rows, count the events per edge (LDS), number the
 //           chunks -- the first piece of an edge lies in the chunk of its upper node, the last in
 //           the chunk of its lower node, pieces in between are chunks of their own
@@ -578,32 +825,6 @@ sweep_count_kernel(long nchains, const long *__restrict__ start, const int *__re
     if (lane == 0) newcnt[c] = total;
 }
 
-// exclusive prefix sum of count[0 .. n) -> out[0 .. n], one workgroup
-__global__ void __launch_bounds__(1024)
-sweep_scan_kernel(long n, const long *__restrict__ count, long *__restrict__ out)
-{
-    __shared__ long part[1024];
-    const int t = threadIdx.x;
-    const long per = (n + 1023) / 1024;
-    const long lo = t * per < n ? t * per : n, hi = lo + per < n ? lo + per : n;
-    long s = 0;
-    for (long i = lo; i < hi; ++i) s += count[i];
-    part[t] = s;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const long y = t >= d ? part[t - d] : 0;
-        __syncthreads();
-        part[t] += y;
-        __syncthreads();
-    }
-    long run = part[t] - s;
-    for (long i = lo; i < hi; ++i) {
-        out[i] = run;
-        run += count[i];
-    }
-    if (t == 1023) out[n] = part[1023];
-}
-
 __global__ void __launch_bounds__(64 * SWEEP_WAVES)
 sweep_split_kernel(long nchains, int N, int nbits, const int *__restrict__ parent,
                    const long *__restrict__ start, const int *__restrict__ cnt,
@@ -674,14 +895,38 @@ sweep_split_kernel(long nchains, int N, int nbits, const int *__restrict__ paren
     // (bottom-up): chains of dependent LDS accesses, done by the whole wave in step
     for (int v = lane; v < N; v += 64) acc[v] = node_masks[c * N + v] & full;
     wave_lds_order();
-    if (lane == 0) {
-        node[0] = 0;
-        for (int v = 1; v < N; ++v) {
-            const int m = rows[v] - 1;                       // events on the edge above v
-            node[v] = m > 0 ? first[v] - v + 2 + m - 1 : node[parent[v]];
+    // the chunk of a base node is the chunk of its nearest ancestor-or-self whose edge carries
+    // events (or the root): pointer jumping, ceil(log2 N) rounds of two LDS reads per node (a
+    // walk by one lane was 2 N dependent LDS round trips: 1.06 ms of a 2.4 ms sweep of 100 000
+    // chains); a jump may read an already updated entry -- still an ancestor on the path
+    for (int v = lane; v < N; v += 64) node[v] = (v == 0 || rows[v] > 1) ? v : parent[v];
+    wave_lds_order();
+    for (int span = 1; span < N; span <<= 1) {
+        for (int v = lane; v < N; v += 64) node[v] = node[node[v]];
+        wave_lds_order();
+    }
+    // allowed sets of the event-free region below each such node, ANDed into it
+    for (int v = lane; v < N; v += 64) {
+        const int top = node[v];
+        if (top != v) atomicAnd(&acc[top], acc[v]);
+    }
+    wave_lds_order();
+    {
+        int cid[(SWEEP_MAX_NODES + 63) / 64];
+#pragma unroll
+        for (int q = 0; q < (SWEEP_MAX_NODES + 63) / 64; ++q) {
+            const int v = q * 64 + lane;
+            if (v < N) {
+                const int top = node[v];
+                cid[q] = top == 0 ? 0 : first[top] - top + 2 + (rows[top] - 1) - 1;
+            }
         }
-        for (int v = N - 1; v >= 1; --v)
-            if (rows[v] == 1) acc[parent[v]] &= acc[v];
+        wave_lds_order();
+#pragma unroll
+        for (int q = 0; q < (SWEEP_MAX_NODES + 63) / 64; ++q) {
+            const int v = q * 64 + lane;
+            if (v < N) node[v] = cid[q];
+        }
     }
     wave_lds_order();
     for (int v = lane; v < N; v += 64) node_chunk[c * N + v] = node[v];
@@ -835,10 +1080,12 @@ struct rt_chains {
     double *d_len_k = nullptr;
     long *d_start_k = nullptr;
     unsigned char *d_reject = nullptr;
+    void *d_scan_tmp = nullptr;
+    size_t scan_tmp_bytes = 0;
     ~rt_chains()
     {
         hipFree(d_edge_k); hipFree(d_state_k); hipFree(d_cnt_k); hipFree(d_node_state_k);
-        hipFree(d_len_k); hipFree(d_start_k); hipFree(d_reject);
+        hipFree(d_len_k); hipFree(d_start_k); hipFree(d_reject); hipFree(d_scan_tmp);
         hipFree(P.d_col); hipFree(P.d_val); hipFree(P.d_rowbits); hipFree(P.d_colbits);
         hipFree(P.d_dense);
         hipFree(d_parent); hipFree(d_branch); hipFree(d_rates); hipFree(d_root);
@@ -879,8 +1126,14 @@ int chains_step(rt_chains *h, int per, int *flag_out)
     hipLaunchKernelGGL(sweep_count_kernel, grid, block, 0, st, (long)C, h->d_start, h->d_cnt,
                        h->d_len_a, h->d_state_a, h->d_rates, per, (unsigned long long)h->seed,
                        stream_events, h->d_newcnt);
-    hipLaunchKernelGGL(sweep_scan_kernel, dim3(1), dim3(1024), 0, st, (long)C, h->d_newcnt,
-                       h->d_newstart);
+    // where each chain's new rows start: exclusive prefix sum over C + 1 counts (the last is 0,
+    // so the last output is the total); rocPRIM's scan (a single-workgroup scan took 186 us at
+    // 100 000 chains)
+    {
+        size_t bytes = h->scan_tmp_bytes;
+        RT_HIP(hipcub::DeviceScan::ExclusiveSum(h->d_scan_tmp, bytes, h->d_newcnt, h->d_newstart,
+                                                (int)(C + 1), st));
+    }
     RT_HIP(hipGetLastError());
     long total_rows = 0;
     RT_HIP(hipMemcpyAsync(&total_rows, h->d_newstart + C, sizeof(long), hipMemcpyDeviceToHost, st));
@@ -911,14 +1164,13 @@ int chains_step(rt_chains *h, int per, int *flag_out)
                        h->d_rates, per, (unsigned long long)h->seed, stream_events, h->d_node_masks,
                        h->d_newstart, h->d_edge_b, h->d_len_b, h->d_row_chunk, h->d_choff,
                        h->d_cparent, h->d_cmask, h->d_node_chunk);
-    const dim3 fgrid(forest_grid(C)), fblock(64 * FOREST_WAVES);
-    hipLaunchKernelGGL(forest_sets_kernel, fgrid, fblock, 0, st, (int)h->n, (long)C, h->d_choff,
-                       h->d_cparent, h->P.d_rowbits, h->P.d_colbits, h->d_cmask, 1);
-    hipLaunchKernelGGL(forest_pmap_kernel, fgrid, fblock, 0, st, (int)h->n, (long)C, h->d_choff,
-                       h->d_cparent, h->P.width, h->P.d_col, h->P.d_val, h->d_cmask, h->d_L);
-    hipLaunchKernelGGL(forest_sample_kernel, fgrid, fblock, 0, st, (int)h->n, (long)C, h->d_choff,
-                       h->d_cparent, h->P.d_dense, h->d_root, h->d_L, (unsigned long long)h->seed,
-                       stream_states, h->d_cstate, h->d_status);
+    launch_forest_sets((int)h->n, (long)C, h->d_choff, h->d_cparent, h->P.d_rowbits, h->P.d_colbits,
+                       h->d_cmask, 1, st);
+    launch_forest_pmap((int)h->n, (long)C, h->d_choff, h->d_cparent, h->P.width, h->P.d_col,
+                       h->P.d_val, h->d_cmask, h->d_L, st);
+    launch_forest_sample((int)h->n, (long)C, h->d_choff, h->d_cparent, h->P.d_dense, h->d_root,
+                         h->d_L, (unsigned long long)h->seed, stream_states, h->d_cstate,
+                         h->d_status, st);
     RT_HIP(hipMemsetAsync(h->d_flag, 0, sizeof(int), st));
     hipLaunchKernelGGL(sweep_flag_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st,
                        (long)C, h->d_status, h->d_flag);
@@ -981,7 +1233,14 @@ extern "C" int rt_chains_create(rt_ctx *ctx, int64_t nnodes, const int32_t *pare
     RT_CH(hipMalloc((void **)&h->d_rates, n * 8));
     RT_CH(hipMalloc((void **)&h->d_node_masks, C * N * 8));
     RT_CH(hipMalloc((void **)&h->d_start, C * sizeof(long)));
-    RT_CH(hipMalloc((void **)&h->d_newcnt, C * sizeof(long)));
+    RT_CH(hipMalloc((void **)&h->d_newcnt, (C + 1) * sizeof(long)));
+    RT_CH(hipMemsetAsync(h->d_newcnt, 0, (C + 1) * sizeof(long), st));
+    {
+        size_t bytes = 0;
+        RT_CH(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, h->d_newcnt, h->d_newcnt, (int)(C + 1), st));
+        RT_CH(hipMalloc(&h->d_scan_tmp, std::max<size_t>(bytes, 16)));
+        h->scan_tmp_bytes = bytes;
+    }
     RT_CH(hipMalloc((void **)&h->d_newstart, (C + 1) * sizeof(long)));
     RT_CH(hipMalloc((void **)&h->d_choff, (C + 1) * sizeof(long)));
     RT_CH(hipMalloc((void **)&h->d_cnt, C * 4));
