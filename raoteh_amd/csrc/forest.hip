@@ -807,7 +807,8 @@ __global__ void __launch_bounds__(64 * SWEEP_WAVES)
 sweep_count_kernel(long nchains, const long *__restrict__ start, const int *__restrict__ cnt,
                    const double *__restrict__ len, const int *__restrict__ state,
                    const double *__restrict__ rates, int per, unsigned long long seed,
-                   unsigned long long stream, long *__restrict__ newcnt)
+                   unsigned long long stream, long *__restrict__ newcnt,
+                   unsigned char *__restrict__ row_k)
 {
     const int lane = threadIdx.x & 63;
     const long c = (long)blockIdx.x * SWEEP_WAVES + (threadIdx.x >> 6);
@@ -818,6 +819,7 @@ sweep_count_kernel(long nchains, const long *__restrict__ start, const int *__re
         const int k = row_events(rates[state[lo + i]], len[lo + i], seed, stream,
                                  (unsigned long long)c, (unsigned long long)i, per,
                                  [](int, double) {});
+        row_k[lo + i] = (unsigned char)k;        // <= SWEEP_MAX_GAPS: the split pass reads it back
         total += k + 1;
     }
 #pragma unroll
@@ -831,6 +833,7 @@ sweep_split_kernel(long nchains, int N, int nbits, const int *__restrict__ paren
                    const int *__restrict__ edge, const double *__restrict__ len,
                    const int *__restrict__ state, const double *__restrict__ rates, int per,
                    unsigned long long seed, unsigned long long stream,
+                   const unsigned char *__restrict__ row_k,
                    const unsigned long long *__restrict__ node_masks,
                    const long *__restrict__ newstart, int *__restrict__ edge_out,
                    double *__restrict__ len_out, int *__restrict__ row_chunk,
@@ -864,10 +867,7 @@ sweep_split_kernel(long nchains, int N, int nbits, const int *__restrict__ paren
         const int e = valid ? edge[lo + i] : 0;
         const double l = valid ? len[lo + i] : 0.0;
         const double r = valid ? rates[state[lo + i]] : 0.0;
-        int k = -1;
-        if (valid)
-            k = row_events(r, l, seed, stream, (unsigned long long)c, (unsigned long long)i, per,
-                           [](int, double) {});
+        const int k = valid ? (int)row_k[lo + i] : -1;      // counted by sweep_count_kernel
         const int incl = wave_inclusive_sum_int(k + 1, lane);
         const long dst = out + running + incl - (k + 1);
         if (valid) {
@@ -1065,6 +1065,7 @@ struct rt_chains {
     // rows: buffer A holds the current histories, B the freshly split ones
     int64_t cap_rows = 0, cap_chunks = 0;
     int *d_edge_a = nullptr, *d_state_a = nullptr, *d_edge_b = nullptr, *d_row_chunk = nullptr;
+    unsigned char *d_row_k = nullptr;      // events of each current row (count -> split)
     double *d_len_a = nullptr, *d_len_b = nullptr;
     long *d_start = nullptr, *d_newcnt = nullptr, *d_newstart = nullptr, *d_choff = nullptr;
     int *d_cnt = nullptr, *d_node_chunk = nullptr, *d_node_state = nullptr;
@@ -1090,7 +1091,7 @@ struct rt_chains {
         hipFree(P.d_dense);
         hipFree(d_parent); hipFree(d_branch); hipFree(d_rates); hipFree(d_root);
         hipFree(d_node_masks); hipFree(d_edge_a); hipFree(d_state_a); hipFree(d_edge_b);
-        hipFree(d_row_chunk); hipFree(d_len_a); hipFree(d_len_b); hipFree(d_start);
+        hipFree(d_row_chunk); hipFree(d_row_k); hipFree(d_len_a); hipFree(d_len_b); hipFree(d_start);
         hipFree(d_newcnt); hipFree(d_newstart); hipFree(d_choff); hipFree(d_cnt);
         hipFree(d_node_chunk); hipFree(d_node_state); hipFree(d_cparent); hipFree(d_cstate);
         hipFree(d_status); hipFree(d_flag); hipFree(d_cmask); hipFree(d_L);
@@ -1125,7 +1126,7 @@ int chains_step(rt_chains *h, int per, int *flag_out)
     const unsigned long long stream_events = 2 * h->nsweeps + 1, stream_states = 2 * h->nsweeps;
     hipLaunchKernelGGL(sweep_count_kernel, grid, block, 0, st, (long)C, h->d_start, h->d_cnt,
                        h->d_len_a, h->d_state_a, h->d_rates, per, (unsigned long long)h->seed,
-                       stream_events, h->d_newcnt);
+                       stream_events, h->d_newcnt, h->d_row_k);
     // where each chain's new rows start: exclusive prefix sum over C + 1 counts (the last is 0,
     // so the last output is the total); rocPRIM's scan (a single-workgroup scan took 186 us at
     // 100 000 chains)
@@ -1145,6 +1146,7 @@ int chains_step(rt_chains *h, int per, int *flag_out)
         RT_TRY(grow(h->d_edge_a, cap, h->cap_rows, st));
         RT_TRY(grow(h->d_len_a, cap, h->cap_rows, st));
         RT_TRY(grow(h->d_state_a, cap, h->cap_rows, st));
+        RT_TRY(grow(h->d_row_k, cap, h->cap_rows, st));
         RT_TRY(grow(h->d_edge_b, cap, 0, st));
         RT_TRY(grow(h->d_len_b, cap, 0, st));
         RT_TRY(grow(h->d_row_chunk, cap, 0, st));
@@ -1161,7 +1163,8 @@ int chains_step(rt_chains *h, int per, int *flag_out)
     const size_t lds = (size_t)SWEEP_WAVES * N * 24;      // acc (8 B) + three int tables
     hipLaunchKernelGGL(sweep_split_kernel, grid, block, lds, st, (long)C, (int)N, (int)h->n,
                        h->d_parent, h->d_start, h->d_cnt, h->d_edge_a, h->d_len_a, h->d_state_a,
-                       h->d_rates, per, (unsigned long long)h->seed, stream_events, h->d_node_masks,
+                       h->d_rates, per, (unsigned long long)h->seed, stream_events, h->d_row_k,
+                       h->d_node_masks,
                        h->d_newstart, h->d_edge_b, h->d_len_b, h->d_row_chunk, h->d_choff,
                        h->d_cparent, h->d_cmask, h->d_node_chunk);
     launch_forest_sets((int)h->n, (long)C, h->d_choff, h->d_cparent, h->P.d_rowbits, h->P.d_colbits,
@@ -1275,6 +1278,7 @@ extern "C" int rt_chains_create(rt_ctx *ctx, int64_t nnodes, const int32_t *pare
         RT_CH(hipMalloc((void **)&h->d_edge_b, h->cap_rows * 4));
         RT_CH(hipMalloc((void **)&h->d_len_b, h->cap_rows * 8));
         RT_CH(hipMalloc((void **)&h->d_row_chunk, h->cap_rows * 4));
+        RT_CH(hipMalloc((void **)&h->d_row_k, h->cap_rows));
         RT_CH(hipMemcpyAsync(h->d_edge_a, edge.data(), edge.size() * 4, hipMemcpyHostToDevice, st));
         RT_CH(hipMemcpyAsync(h->d_state_a, state.data(), state.size() * 4, hipMemcpyHostToDevice, st));
         RT_CH(hipMemcpyAsync(h->d_len_a, len.data(), len.size() * 8, hipMemcpyHostToDevice, st));
