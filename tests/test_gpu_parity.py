@@ -1980,3 +1980,52 @@ def test_metropolis_hastings_corrects_rao_teh_to_another_process(ra, where):
             assert isinstance(ok, bool)
             assert sum(d['weight'] for _, _, d in h.edges(data=True)) == pytest.approx(total, rel=1e-12)
         assert count == 6
+
+
+def test_device_chains_at_the_limits(ra):
+    """rt_chains_* at the edges of what it accepts: a two-node tree, one chain, 64 states
+    (every lane a state, full 64-bit masks), and a base tree of 1 024 nodes (98 KB of LDS
+    tables in the split kernel); one node more is an error, not a fault."""
+    from raoteh_amd import _sampler
+    rng = np.random.RandomState(3)
+    # 64 states on an edge
+    n = 64
+    Q = rng.exponential(size=(n, n)) * (rng.uniform(size=(n, n)) < 0.2)
+    for i in range(n):
+        Q[i, (i + 1) % n] += 0.5
+    np.fill_diagonal(Q, 0.0)
+    Q -= np.diag(Q.sum(axis=1))
+    T = nx.Graph()
+    T.add_edge(7, 3, weight=0.8)
+    b = _sampler.DeviceHistoryBatch(T, 7, Q, node_to_allowed_states={7: {63}, 3: {0, 5, 63}},
+                                    nchains=1, seed=1, ctx=ra.ctx)
+    b.sweep(5)
+    chain, edge, length, state = b.rows()
+    assert (chain == 0).all() and (edge == 1).all() and length.sum() == pytest.approx(0.8, rel=1e-12)
+    assert state[0] == 63 and state[-1] in (0, 5, 63)
+    assert (Q[state[:-1], state[1:]] > 0).all()
+    # 1 024 base nodes: a caterpillar with random leaf states, 4 states
+    n = 4
+    Q4, pi = ra.synth.hky85()
+    N = 1024
+    big = nx.Graph()
+    for v in range(1, N):
+        big.add_edge(v - 1 if v % 2 else v - 2, v,          # spine 0, 2, 4, ...; a leaf on each
+                     weight=0.02 + 0.05 * rng.uniform())
+    assert nx.is_tree(big) and big.number_of_nodes() == N
+    leaves = [v for v in big if big.degree(v) == 1 and v != 0]
+    allowed = dict((v, {int(rng.randint(n))}) for v in leaves[::3])
+    c = _sampler.DeviceHistoryBatch(big, 0, Q4, node_to_allowed_states=allowed, nchains=40,
+                                    root_distn=pi, seed=2, ctx=ra.ctx)
+    c.sweep(3)
+    chain, edge, length, state = c.rows()
+    per_edge = np.bincount(chain * N + edge, weights=length, minlength=40 * N).reshape(40, N)
+    np.testing.assert_allclose(per_edge[:, 1:], np.broadcast_to(c.branch[1:], (40, N - 1)), rtol=1e-11)
+    ns = c.node_states
+    for v, ss in allowed.items():
+        assert set(np.unique(ns[:, c.tree.node_to_index[v]]).tolist()) <= ss
+    big.add_edge(0, N, weight=0.1)
+    with pytest.raises(ValueError):
+        _sampler.DeviceHistoryBatch(big, 0, Q4, nchains=2, ctx=ra.ctx)
+    with pytest.raises(ValueError):
+        _sampler.DeviceHistoryBatch(T, 7, np.zeros((3, 3)), nchains=1, ctx=ra.ctx)
