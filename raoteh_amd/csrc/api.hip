@@ -567,7 +567,6 @@ extern "C" int rt_model_schedule_depth(const rt_model *m)
 
 // ---- sites ------------------------------------------------------------------------------------
 
-static const int RT_FAST_MAX_DEPTH = 16;   // LDS accumulator stack of the fast kernels
 // Process-wide defaults (rt_set_option); a context's own value (rt_ctx_set_option)
 // takes precedence.  Atomics: two threads with a context each may create batches
 // while a third changes a default.
@@ -1133,6 +1132,14 @@ static int sites_create_impl(rt_model *m, int64_t nsites, int kind, int64_t nobs
     }
     *out = s;
     return RT_OK;
+}
+
+int rt_sites_create_interpreter(rt_model *m, int64_t nsites, int kind, int64_t nobs,
+                                const int64_t *obs_nodes, const void *data, rt_sites **out)
+{
+    jit_override interp;
+    interp.mode = 1;
+    return sites_create_impl(m, nsites, kind, nobs, obs_nodes, data, &interp, out);
 }
 
 extern "C" int rt_sites_create(rt_model *m, int64_t nsites, int kind, int64_t nobs,

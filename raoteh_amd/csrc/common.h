@@ -100,6 +100,8 @@ static const int RT_OPT_UNSET = -2;
 // post-order.  For a non-root node v the step forms L_v (pop its accumulator if
 // internal, multiply its observation in), t = P_v * L_v and folds t into its
 // parent's accumulator slot; the final step (dst = -1) is the root reduction.
+static const int RT_FAST_MAX_DEPTH = 16;   // LDS accumulator stack of the fast kernels
+
 struct rt_op {
     int32_t node;      // preorder index of v (also the P slot of edge parent->v)
     int32_t obs;       // position of v in the observation stream, or -1
@@ -177,6 +179,9 @@ struct rt_sites {
     int jit_waves = 1;              // waves per workgroup of the tree-specialised kernel
     int jit_tiles = 1;              // MFMA family: site tiles per wave of that kernel
     bool jit_quad = false;          // ... built on v_mfma_f64_4x4x4_4b (reads d_Pquad)
+    // not owned: where the split-M interpreter kernel leaves L_v and M_v of every step
+    // (expect_mfma.hip sets them around its own launch)
+    double *d_Lout = nullptr, *d_Mout = nullptr;
     int compact_states = 0;         // lane family + specialised kernel: the batch stays resident
                                     // as one byte per leaf: 1 = uint8 states, 2 = allowed-set masks
     double *d_scratch = nullptr;    // generic kernel message stack
@@ -239,6 +244,15 @@ void rt_jit_set_verified(const rt_ctx *ctx, void *fn, bool ok);
 void rt_jit_release(const rt_ctx *ctx);
 int rt_jit_read_global(const rt_ctx *ctx, void *fn, const char *name, void *dst, size_t bytes);
 int rt_launch_prune_jit(rt_model *m, rt_sites *s);
+// a batch that runs the interpreter kernels only (no tree-specialised kernel is compiled)
+int rt_sites_create_interpreter(rt_model *m, int64_t nsites, int kind, int64_t nobs,
+                                const int64_t *obs_nodes, const void *data, rt_sites **out);
+// expectation path on the matrix pipe (expect_mfma.hip); RT_ERR_UNSUPPORTED = not this case
+int rt_expectation_weights_mfma(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t nsites,
+                                const int64_t *idx, const int64_t *ptr, const double *esd,
+                                const double *root_distn, int64_t nobs, const int64_t *obs_nodes,
+                                int kind, const void *data, const double *site_weights,
+                                double *edge_weights, int32_t *status);
 int rt_sites_pack(rt_sites *s, int kind, const int64_t *obs_order,
                   const void *data);
 

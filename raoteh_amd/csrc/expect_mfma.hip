@@ -1,0 +1,366 @@
+// Expected history statistics at codon scale on the matrix pipe (32 < n <= 64).
+//
+// rt_mjp_esd_expectation_weights_obs needs, per edge e = (p -> v) and summed over the sites,
+//     W_e[a][b] = sum_s w_s u_s[a] L_v,s[b],   u = D_p / M_v,   D_v = (P_v^T u) * L_v,
+// with L the subtree likelihoods, M_v = P_v L_v the message to the parent and D the posterior
+// node marginals (raoteh/sampler/_mjp_dense.py:458-533 after the passes of _mcy_dense.py:57-230).
+// The reference-format kernels of passes.hip do that one site per wave: 80 ms for 10 000 sites
+// of the 61-state model, next to 0.24 ms for the likelihood of the same batch.  The work is two
+// pruning-sized passes and one GEMM over the sites per edge, so it runs here as
+//
+//   up     the split-M interpreter pruning kernel (prune.hip) with its own rows of L_v and M_v
+//          of every step written out, [step][tile][m][r][lane] (the D layout of
+//          v_mfma_f64_16x16x4: register r of row tile m on lane l = state 16m + 4r + (l >> 4) of
+//          site l & 15 of the 16-site tile);
+//   down   the same tile-per-workgroup shape over the steps in reverse: u = D_p / M_v in
+//          registers, exchanged through LDS as B operands, P_v^T as A fragments, D_v = (.) * L_v;
+//          u is kept for the site sums; leaves skip the product (nobody reads their D);
+//   wsum   per edge and chunk of site tiles: W += U^T-tile x L-tile with K = sites (4 sites per
+//          MFMA), accumulators in registers over the chunk, one partial per chunk;
+//   finish the chunks summed in order, masked by P != 0, written in the reference's
+//          [node][a][b] order; the root's posterior sums.
+//
+// Everything is summed in a fixed order.  The boolean passes are not run: with the upward pass
+// carrying exact zeros they change no number here (an infeasible site has likelihood 0 and
+// contributes nothing, as before).
+#include "common.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int EX_CHUNKS = 8;              // site-tile chunks per edge in the site sums
+
+// A fragments of P^T in step order: T[step][m][q][lane][e2] = P_v[4(2q+e2) + (lane>>4)][16m + (lane&15)]
+__global__ void __launch_bounds__(256)
+pack_pt_kernel(int n, int NT, int KP, int nops, const int *__restrict__ step_node,
+               const double *__restrict__ P, double *__restrict__ out)
+{
+    const long total = (long)nops * NT * KP * 128;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int e2 = (int)(e & 1);
+        const int ln = (int)((e >> 1) & 63);
+        long rest = e >> 7;
+        const int q = (int)(rest % KP);
+        rest /= KP;
+        const int m = (int)(rest % NT);
+        const int step = (int)(rest / NT);
+        const int b = 16 * m + (ln & 15);                 // output state (row of P^T)
+        const int a = 4 * (2 * q + e2) + (ln >> 4);       // input state (k)
+        const int v = step_node[step];
+        out[e] = (a < n && b < n) ? P[((long)v * n + a) * n + b] : 0.0;
+    }
+}
+
+template <int NT, int KS>
+__global__ void __launch_bounds__(64 * NT)
+expect_down_kernel(const double *__restrict__ PfragT, int nops, const int *__restrict__ parent_step,
+                   const unsigned char *__restrict__ internal, const double *__restrict__ Larr,
+                   const double *__restrict__ Marr, double *__restrict__ Darr,
+                   double *__restrict__ Uarr, const double *__restrict__ root_w, int n,
+                   int *__restrict__ status, long nsites, long nblocks)
+{
+    constexpr int KP = (KS + 1) / 2;
+    __shared__ double xb[NT * 4 * 64];
+    __shared__ double red[NT][16];
+    const int lane = threadIdx.x & 63;
+    const int m = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long blk = blockIdx.x;
+    const size_t tile_stride = (size_t)NT * 256;
+    auto at = [&](int step) { return ((size_t)step * nblocks + blk) * tile_stride + (m * 4) * 64 + lane; };
+    bool bad = false;
+    // root: D = w L / sum_states(w L)  (_mc0_dense.py:400-489 with the prior weights)
+    {
+        const int i = nops - 1;
+        const size_t o = at(i);
+        double wl[4], s = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * m + 4 * r + (lane >> 4);
+            const double w = row < n ? (root_w ? root_w[row] : 1.0) : 0.0;
+            wl[r] = w * Larr[o + r * 64];
+            s += wl[r];
+        }
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (lane < 16) red[m][lane] = s;
+        __syncthreads();
+        double tot = 0.0;
+#pragma unroll
+        for (int mm = 0; mm < NT; ++mm) tot += red[mm][lane & 15];
+        if (!(tot > 0.0)) bad = true;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Darr[o + r * 64] = tot > 0.0 ? wl[r] / tot : 0.0;
+    }
+    const double *ag = PfragT + ((size_t)m * KP * 64 + lane) * 2;
+    constexpr size_t ASTRIDE = (size_t)NT * KP * 128;
+    for (int i = nops - 2; i >= 0; --i) {
+        const size_t o = at(i), po = at(parent_step[i]);
+        double u[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double dp = Darr[po + r * 64];
+            const double den = Marr[o + r * 64];
+            u[r] = 0.0;
+            if (dp != 0.0) {
+                if (den > 0.0) u[r] = dp / den;
+                else bad = true;
+            }
+            Uarr[o + r * 64] = u[r];
+        }
+        if (!internal[i]) continue;              // a leaf: nobody reads its D (uniform)
+        __syncthreads();                         // the previous step's operands are read
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xb[(4 * m + r) * 64 + lane] = u[r];
+        double a[2 * KP];
+#pragma unroll
+        for (int q = 0; q < KP; ++q) {
+            const double2 v = *(const double2 *)(ag + (size_t)i * ASTRIDE + q * 128);
+            a[2 * q] = v.x;
+            a[2 * q + 1] = v.y;
+        }
+        __syncthreads();
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], xb[kk * 64 + lane], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Darr[o + r * 64] = acc[r] * Larr[o + r * 64];
+    }
+    const long site = blk * 16 + (lane & 15);
+    if (bad && site < nsites) atomicOr(&status[site], 2);
+}
+
+// W partial of one edge (= step) and one chunk of site tiles: wave ma holds row tile ma of W
+template <int NT>
+__global__ void __launch_bounds__(64 * NT)
+expect_wsum_kernel(int nops, const double *__restrict__ Uarr, const double *__restrict__ Larr,
+                   const double *__restrict__ weights, long nsites, long nblocks,
+                   double *__restrict__ partial)
+{
+    const int lane = threadIdx.x & 63;
+    const int ma = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int step = blockIdx.x, chunk = blockIdx.y;
+    const long per = (nblocks + EX_CHUNKS - 1) / EX_CHUNKS;
+    const long t0 = chunk * per, t1 = t0 + per < nblocks ? t0 + per : nblocks;
+    const size_t tile_stride = (size_t)NT * 256;
+    const int lo = lane & 15, hi = lane >> 4;
+    // element (state 16 M + x, site t) of a tile sits at (M * 4 + x / 4) * 64 + 16 (x % 4) + t
+    const int row_off = (lo >> 2) * 64 + 16 * (lo & 3);
+    double4_t acc[NT];
+#pragma unroll
+    for (int mb = 0; mb < NT; ++mb) acc[mb] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (long tile = t0; tile < t1; ++tile) {
+        const double *Ut = Uarr + ((size_t)step * nblocks + tile) * tile_stride;
+        const double *Lt = Larr + ((size_t)step * nblocks + tile) * tile_stride;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const long site = tile * 16 + 4 * ks + hi;
+            const double w = site < nsites ? (weights ? weights[site] : 1.0) : 0.0;
+            const double av = Ut[ma * 256 + row_off + 4 * ks + hi] * w;     // U[16 ma + lo][site]
+#pragma unroll
+            for (int mb = 0; mb < NT; ++mb) {
+                const double bv = Lt[mb * 256 + row_off + 4 * ks + hi];     // L[16 mb + lo][site]
+                acc[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[mb], 0, 0, 0);
+            }
+        }
+    }
+    double *out = partial + (((size_t)step * EX_CHUNKS + chunk) * NT + ma) * NT * 256;
+#pragma unroll
+    for (int mb = 0; mb < NT; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(mb * 4 + r) * 64 + lane] = acc[mb][r];
+}
+
+// chunks summed in order, structural zeros of P masked, reference order [node][a][b]
+__global__ void __launch_bounds__(256)
+expect_finish_kernel(int n, int NT, int nops, const int *__restrict__ step_node,
+                     const double *__restrict__ esd, const double *__restrict__ partial,
+                     double *__restrict__ W)
+{
+    const int step = blockIdx.x;                 // edges: steps 0 .. nops - 2
+    const int v = step_node[step];
+    for (int e = threadIdx.x; e < n * n; e += 256) {
+        const int a = e / n, b = e - a * n;
+        const int ma = a >> 4, r = (a & 15) >> 2, hi = a & 3;
+        const int mb = b >> 4, lo = b & 15;
+        double sum = 0.0;
+        for (int c = 0; c < EX_CHUNKS; ++c)
+            sum += partial[((((size_t)step * EX_CHUNKS + c) * NT + ma) * NT + mb) * 256 + r * 64 +
+                           hi * 16 + lo];
+        W[((size_t)v * n + a) * n + b] = esd[((size_t)v * n + a) * n + b] != 0.0 ? sum : 0.0;
+    }
+}
+
+// slot 0, column 0: the weighted sum of the root posteriors (one workgroup, fixed order)
+__global__ void __launch_bounds__(256)
+expect_root_kernel(int n, int NT, int root_step, const double *__restrict__ Darr,
+                   const double *__restrict__ weights, long nsites, long nblocks,
+                   double *__restrict__ W)
+{
+    for (int e = threadIdx.x; e < n * n; e += 256) W[e] = 0.0;
+    __syncthreads();
+    for (int a = threadIdx.x; a < n; a += 256) {
+        const int ma = a >> 4, r = (a & 15) >> 2, hi = a & 3;
+        double sum = 0.0;
+        for (long tile = 0; tile < nblocks; ++tile) {
+            const double *Dt = Darr + ((size_t)root_step * nblocks + tile) * ((size_t)NT * 256) +
+                               (ma * 4 + r) * 64 + hi * 16;
+            for (int t = 0; t < 16; ++t) {
+                const long site = tile * 16 + t;
+                if (site < nsites) sum += (weights ? weights[site] : 1.0) * Dt[t];
+            }
+        }
+        W[(size_t)a * n] = sum;
+    }
+}
+
+struct dev_free {
+    std::vector<void *> ptrs;
+    ~dev_free() { for (void *p : ptrs) hipFree(p); }
+    template <class T> int alloc(T *&p, size_t count)
+    {
+        p = nullptr;
+        RT_HIP(hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T)));
+        ptrs.push_back(p);
+        return RT_OK;
+    }
+};
+
+template <int NT, int KS>
+int run_chunk(rt_ctx *ctx, rt_model *model, int64_t n, int64_t nsites, int64_t nobs,
+              const int64_t *obs_nodes, int kind, const void *data, const double *esd_dev,
+              const double *d_root_w, const double *site_weights, const std::vector<int> &step_node,
+              const std::vector<int> &parent_step, const std::vector<unsigned char> &internal,
+              double *d_W, int *d_status, double *d_PT, const int *d_step_node,
+              const int *d_parent_step, const unsigned char *d_internal)
+{
+    (void)step_node; (void)parent_step; (void)internal;
+    hipStream_t st = ctx->stream;
+    rt_sites *s = nullptr;
+    RT_TRY(rt_sites_create_interpreter(model, nsites, kind, nobs, obs_nodes, data, &s));
+    struct guard { rt_sites *s; ~guard() { rt_sites_destroy(s); } } g{s};
+    RT_REQUIRE(s->layout == RT_LAYOUT_MFMA && !s->mfma_solo && !s->jit_fn,
+               "unexpected batch layout for the matrix-pipe expectation path");
+    const int nops = (int)s->ops.size();
+    const long nblocks = (long)s->nblocks;
+    const size_t arr = (size_t)nops * nblocks * NT * 256;
+    dev_free mem;
+    double *d_L, *d_M, *d_D, *d_U, *d_part, *d_w = nullptr;
+    RT_TRY(mem.alloc(d_L, arr));
+    RT_TRY(mem.alloc(d_M, arr));
+    RT_TRY(mem.alloc(d_D, arr));
+    RT_TRY(mem.alloc(d_U, arr));
+    RT_TRY(mem.alloc(d_part, (size_t)nops * EX_CHUNKS * NT * NT * 256));
+    if (site_weights) {
+        RT_TRY(mem.alloc(d_w, (size_t)nsites));
+        RT_HIP(hipMemcpyAsync(d_w, site_weights, (size_t)nsites * 8, hipMemcpyHostToDevice, st));
+    }
+    // M of the root step is never written by the upward pass (no product there)
+    s->d_Lout = d_L;
+    s->d_Mout = d_M;
+    const int rc = rt_launch_prune(model, s, false);
+    s->d_Lout = s->d_Mout = nullptr;
+    RT_TRY(rc);
+    RT_HIP(hipMemsetAsync(d_status, 0, (size_t)nsites * 4, st));
+    hipLaunchKernelGGL((expect_down_kernel<NT, KS>), dim3((unsigned)nblocks), dim3(64 * NT), 0, st,
+                       d_PT, nops, d_parent_step, d_internal, d_L, d_M, d_D, d_U, d_root_w, (int)n,
+                       d_status, (long)nsites, nblocks);
+    hipLaunchKernelGGL((expect_wsum_kernel<NT>), dim3((unsigned)(nops - 1), EX_CHUNKS), dim3(64 * NT),
+                       0, st, nops, d_U, d_L, d_w, (long)nsites, nblocks, d_part);
+    hipLaunchKernelGGL(expect_finish_kernel, dim3((unsigned)(nops - 1)), dim3(256), 0, st, (int)n, NT,
+                       nops, d_step_node, esd_dev, d_part, d_W);
+    hipLaunchKernelGGL(expect_root_kernel, dim3(1), dim3(256), 0, st, (int)n, NT, nops - 1, d_D, d_w,
+                       (long)nsites, nblocks, d_W);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipStreamSynchronize(st));
+    return RT_OK;
+}
+
+}  // namespace
+
+int rt_expectation_weights_mfma(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t nsites,
+                                const int64_t *idx, const int64_t *ptr, const double *esd,
+                                const double *root_distn, int64_t nobs, const int64_t *obs_nodes,
+                                int kind, const void *data, const double *site_weights,
+                                double *edge_weights, int32_t *status)
+{
+    if (n <= 32 || n > 64 || nnodes < 2 || getenv("RAOTEH_EXPECT_LEGACY")) return RT_ERR_UNSUPPORTED;
+    rt_model *model = nullptr;
+    RT_TRY(rt_model_create(ctx, nnodes, n, idx, ptr, &model));
+    struct mguard { rt_model *m; ~mguard() { rt_model_destroy(m); } } mg{model};
+    if (model->max_depth > RT_FAST_MAX_DEPTH) return RT_ERR_UNSUPPORTED;     // generic kernel only
+    RT_TRY(rt_model_set_transitions(model, esd));
+    std::vector<double> ones;
+    if (!root_distn) {                       // weights of one (_mjp_dense.py:389-393)
+        ones.assign((size_t)n, 1.0);
+        root_distn = ones.data();
+    }
+    RT_TRY(rt_model_set_root_distn(model, root_distn));
+    // the schedule: step -> node, its parent's step, whether it has children
+    const int nops = (int)model->ops.size();
+    std::vector<int> parent((size_t)nnodes, -1), step_of((size_t)nnodes, -1);
+    for (int64_t v = 0; v < nnodes; ++v)
+        for (int64_t e = ptr[v]; e < ptr[v + 1]; ++e) parent[(size_t)idx[e]] = (int)v;
+    std::vector<int> step_node((size_t)nops), parent_step((size_t)nops, 0);
+    std::vector<unsigned char> internal((size_t)nops, 0);
+    for (int i = 0; i < nops; ++i) {
+        step_node[(size_t)i] = model->ops[(size_t)i].node;
+        step_of[(size_t)model->ops[(size_t)i].node] = i;
+        internal[(size_t)i] = model->ops[(size_t)i].pop >= 0;
+    }
+    RT_REQUIRE(nops == nnodes && model->ops[(size_t)nops - 1].dst < 0, "unexpected schedule");
+    for (int i = 0; i + 1 < nops; ++i) parent_step[(size_t)i] = step_of[(size_t)parent[(size_t)step_node[(size_t)i]]];
+    const int NT = (int)((n + 15) / 16), KS = (int)((n + 3) / 4), KP = (KS + 1) / 2;
+    hipStream_t st = ctx->stream;
+    dev_free mem;
+    double *d_W, *d_PT;
+    int *d_status, *d_step_node, *d_parent_step;
+    unsigned char *d_internal;
+    const int64_t CS = 32768;                 // sites per pass: 4 arrays of nops x tiles x 8 KB
+    RT_TRY(mem.alloc(d_W, (size_t)nnodes * n * n));
+    RT_TRY(mem.alloc(d_PT, (size_t)nops * NT * KP * 128));
+    RT_TRY(mem.alloc(d_status, (size_t)std::min<int64_t>(nsites, CS)));
+    RT_TRY(mem.alloc(d_step_node, (size_t)nops));
+    RT_TRY(mem.alloc(d_parent_step, (size_t)nops));
+    RT_TRY(mem.alloc(d_internal, (size_t)nops));
+    RT_HIP(hipMemcpyAsync(d_step_node, step_node.data(), (size_t)nops * 4, hipMemcpyHostToDevice, st));
+    RT_HIP(hipMemcpyAsync(d_parent_step, parent_step.data(), (size_t)nops * 4, hipMemcpyHostToDevice, st));
+    RT_HIP(hipMemcpyAsync(d_internal, internal.data(), (size_t)nops, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(pack_pt_kernel, dim3(512), dim3(256), 0, st, (int)n, NT, KP, nops, d_step_node,
+                       model->d_P, d_PT);
+    RT_HIP(hipGetLastError());
+    const size_t wcount = (size_t)nnodes * n * n;
+    std::vector<double> acc(wcount, 0.0), part(wcount);
+    const size_t item = kind == RT_OBS_STATE ? 1 : 8;
+    for (int64_t lo = 0; lo < nsites; lo += CS) {
+        const int64_t cnt = std::min<int64_t>(CS, nsites - lo);
+        const void *chunk_data = (const unsigned char *)data + (size_t)lo * (size_t)nobs * item;
+        const double *chunk_w = site_weights ? site_weights + lo : nullptr;
+        int rc = RT_ERR_UNSUPPORTED;
+#define RT_EX(NTV, KSV)                                                                           \
+        rc = run_chunk<NTV, KSV>(ctx, model, n, cnt, nobs, obs_nodes, kind, chunk_data, model->d_P, \
+                                 model->d_root, chunk_w, step_node, parent_step, internal, d_W,     \
+                                 d_status, d_PT, d_step_node, d_parent_step, d_internal)
+        switch (KS) {
+        case 9: RT_EX(3, 9); break;
+        case 10: RT_EX(3, 10); break;
+        case 11: RT_EX(3, 11); break;
+        case 12: RT_EX(3, 12); break;
+        case 13: RT_EX(4, 13); break;
+        case 14: RT_EX(4, 14); break;
+        case 15: RT_EX(4, 15); break;
+        default: RT_EX(4, 16); break;
+        }
+#undef RT_EX
+        RT_TRY(rc);
+        RT_HIP(hipMemcpy(part.data(), d_W, wcount * 8, hipMemcpyDeviceToHost));
+        for (size_t e = 0; e < wcount; ++e) acc[e] += part[e];
+        if (status) RT_HIP(hipMemcpy(status + lo, d_status, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+    }
+    memcpy(edge_weights, acc.data(), wcount * 8);
+    return RT_OK;
+}

@@ -1383,6 +1383,14 @@ int expectation_weights_impl(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t nsi
         memset(edge_weights, 0, wcount * 8);
         return RT_OK;
     }
+    // 32 < n <= 64, compact observations: two pruning-shaped passes and the site sums on the
+    // matrix pipe (expect_mfma.hip); RT_ERR_UNSUPPORTED = not its case, go on below
+    if (!state_mask) {
+        const int rc = rt_expectation_weights_mfma(ctx, nnodes, n, nsites, idx, ptr, esd, root_distn,
+                                                   nobs, obs_nodes, kind, data, site_weights,
+                                                   edge_weights, status);
+        if (rc != RT_ERR_UNSUPPORTED) return rc;
+    }
     // n <= 8: the fused lane-per-site kernel on the resident layout
     // (RAOTEH_EXPECT_LEGACY=1: the per-pass kernels below, for A/B runs)
     if (n <= 8 && !getenv("RAOTEH_EXPECT_LEGACY"))

@@ -601,8 +601,12 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
                   const double *__restrict__ obs, int K,  // [blk16][K][KP][64][2]
                   const double *__restrict__ root_w, int n, int lds_slots,
                   double *__restrict__ loglik, int *__restrict__ status,
-                  double *__restrict__ partial, long nsites, long nblocks16)
+                  double *__restrict__ partial, long nsites, long nblocks16,
+                  double *__restrict__ Lout, double *__restrict__ Mout)
 {
+    // Lout / Mout (optional): own rows of L_v and of the message M_v = P_v L_v of every step,
+    // [step][tile][m][r][lane] -- what the downward pass and the site sums of the expectation
+    // path read back (csrc/expect_mfma.hip)
     constexpr int WAVES = (NT == 3) ? 3 : 4;
     constexpr int TILES = WAVES / NT;
     constexpr int KP = (KS + 1) / 2;           // k-step pairs
@@ -679,6 +683,11 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
             for (int r = 0; r < 4; ++r) x[r] = (flags & LOP_OBS) ? on[r] : 1.0;
         }
         if (flags & LOP_OBS) knext += 1;
+        if (Lout && live) {
+            double *lo = Lout + ((size_t)i * nblocks16 + gt) * (NT * 256) + (m * 4) * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lo[r * 64] = x[r];
+        }
         if (flags & LOP_ROOT) {
             double s = 0.0;
 #pragma unroll
@@ -737,6 +746,11 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
         for (int kk = 0; kk < KS; ++kk) {
             const double b = xb[kk * 64 + lane];
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], b, acc, 0, 0, 0);
+        }
+        if (Mout && live) {
+            double *mo = Mout + ((size_t)i * nblocks16 + gt) * (NT * 256) + (m * 4) * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mo[r * 64] = acc[r];
         }
 
         if (flags & LOP_FIRST) {
@@ -1417,7 +1431,7 @@ static int launch_mfma_inst(rt_model *m, rt_sites *s)
                        m->d_Pfrag, (const int4_t *)s->d_lane_ops, (int)s->ops.size(),
                        s->d_obs, (int)s->nobs, m->d_root, (int)m->n, lds_slots,
                        s->d_loglik, s->d_status, s->d_partial, (long)s->nsites,
-                       (long)s->nblocks);
+                       (long)s->nblocks, s->d_Lout, s->d_Mout);
     return RT_OK;
 }
 

@@ -2029,3 +2029,56 @@ def test_device_chains_at_the_limits(ra):
         _sampler.DeviceHistoryBatch(big, 0, Q4, nchains=2, ctx=ra.ctx)
     with pytest.raises(ValueError):
         _sampler.DeviceHistoryBatch(T, 7, np.zeros((3, 3)), nchains=1, ctx=ra.ctx)
+
+
+def test_codon_scale_expectation_weights_on_the_matrix_pipe(ra, monkeypatch):
+    """rt_mjp_esd_expectation_weights_obs for 32 < n <= 64 (csrc/expect_mfma.hip: upward pass
+    with L and M kept, downward pass with P^T fragments, site sums as GEMMs over the sites)
+    against the reference-format per-pass kernels on the same input: 61-state codon model
+    and a 40-state random model (three row tiles), site weights, ambiguous and impossible
+    observations, a batch that is not a multiple of 16 sites; and the per-pass form is the
+    one the oracle tests pin."""
+    from raoteh_amd import _mjp_dense
+    from raoteh_amd._tree import TreeArrays
+    rng = np.random.RandomState(21)
+    cfg = ra.synth.make_config('c3', nsites=203)
+    cases = [(cfg['T'], cfg['root'], cfg['nstates'], cfg['leaves'], cfg['Q_default'],
+              cfg['root_distn'], cfg['leaf_states'])]
+    n2 = 40
+    T2, root2, leaves2 = ra.synth.balanced_tree(8, seed=5)
+    R = rng.exponential(size=(n2, n2)) * (rng.uniform(size=(n2, n2)) < 0.5)
+    np.fill_diagonal(R, 0.0)
+    Q2 = R - np.diag(R.sum(axis=1))
+    cases.append((T2, root2, n2, leaves2, Q2, None, rng.randint(n2, size=(77, len(leaves2)))))
+    for T, root, n, leaves, Q, rd, states in cases:
+        nb = states.shape[0]
+        T_aug = _mjp_dense.get_expm_augmented_tree(T, root, Q_default=Q)
+        ta = TreeArrays(T_aug, root)
+        esd = ta.esd_transitions(n)
+        cols = [ta.node_to_index[v] for v in leaves]
+        masks = (np.uint64(1) << states.astype(np.uint64))
+        masks[::7, 1] |= np.uint64(1) << np.uint64((states[::7, 1] + 1) % n)      # ambiguous
+        masks[5, 0] = 0                                                           # impossible
+        w = rng.uniform(0.5, 2.0, size=nb)
+        got = ra.ctx.expectation_weights_obs(ta.indices, ta.indptr, esd, rd, cols, masks, 'mask',
+                                             site_weights=w)
+        monkeypatch.setenv('RAOTEH_EXPECT_LEGACY', '1')
+        want = ra.ctx.expectation_weights_obs(ta.indices, ta.indptr, esd, rd, cols, masks, 'mask',
+                                              site_weights=w)
+        monkeypatch.delenv('RAOTEH_EXPECT_LEGACY')
+        W, rp, st = got
+        W0, rp0, st0 = want
+        np.testing.assert_array_equal(st, st0)
+        assert st[5] == 2 and (st != 0).sum() == 1
+        scale = np.abs(W0).max()
+        np.testing.assert_allclose(W, W0, rtol=1e-10, atol=1e-13 * scale)
+        np.testing.assert_allclose(rp, rp0, rtol=1e-12)
+        assert not W[0].any()
+        # uint8 states: the same numbers as the one-hot masks
+        ok = np.ones(nb, dtype=bool)
+        ok[5] = False
+        a = ra.ctx.expectation_weights_obs(ta.indices, ta.indptr, esd, rd, cols,
+                                           states[ok][:, :].astype(np.uint8), 'state')
+        b = ra.ctx.expectation_weights_obs(ta.indices, ta.indptr, esd, rd, cols,
+                                           np.uint64(1) << states[ok].astype(np.uint64), 'mask')
+        np.testing.assert_array_equal(a[0], b[0])
