@@ -247,6 +247,8 @@ int rt_launch_prune_jit(rt_model *m, rt_sites *s);
 // a batch that runs the interpreter kernels only (no tree-specialised kernel is compiled)
 int rt_sites_create_interpreter(rt_model *m, int64_t nsites, int kind, int64_t nobs,
                                 const int64_t *obs_nodes, const void *data, rt_sites **out);
+// the context's grow-only device scratch (ctx->d_scratch) holds at least `bytes` afterwards
+int rt_scratch_reserve(rt_ctx *ctx, size_t bytes);
 // expectation path on the matrix pipe (expect_mfma.hip); RT_ERR_UNSUPPORTED = not this case
 int rt_expectation_weights_mfma(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t nsites,
                                 const int64_t *idx, const int64_t *ptr, const double *esd,

@@ -195,18 +195,22 @@ expect_finish_kernel(int n, int NT, int nops, const int *__restrict__ step_node,
     }
 }
 
-// slot 0, column 0: the weighted sum of the root posteriors (one workgroup, fixed order)
-__global__ void __launch_bounds__(256)
+// slot 0, column 0: the weighted sum of the root posteriors -- per chunk of tiles here, the
+// chunks are added in order by expect_root_finish_kernel
+constexpr int EX_ROOT_CHUNKS = 64;
+
+__global__ void __launch_bounds__(64)
 expect_root_kernel(int n, int NT, int root_step, const double *__restrict__ Darr,
                    const double *__restrict__ weights, long nsites, long nblocks,
-                   double *__restrict__ W)
+                   double *__restrict__ rootpart)
 {
-    for (int e = threadIdx.x; e < n * n; e += 256) W[e] = 0.0;
-    __syncthreads();
-    for (int a = threadIdx.x; a < n; a += 256) {
+    const int a = threadIdx.x;                   // state (n <= 64)
+    const long per = (nblocks + EX_ROOT_CHUNKS - 1) / EX_ROOT_CHUNKS;
+    const long t0 = blockIdx.x * per, t1 = t0 + per < nblocks ? t0 + per : nblocks;
+    double sum = 0.0;
+    if (a < n) {
         const int ma = a >> 4, r = (a & 15) >> 2, hi = a & 3;
-        double sum = 0.0;
-        for (long tile = 0; tile < nblocks; ++tile) {
+        for (long tile = t0; tile < t1; ++tile) {
             const double *Dt = Darr + ((size_t)root_step * nblocks + tile) * ((size_t)NT * 256) +
                                (ma * 4 + r) * 64 + hi * 16;
             for (int t = 0; t < 16; ++t) {
@@ -214,7 +218,19 @@ expect_root_kernel(int n, int NT, int root_step, const double *__restrict__ Darr
                 if (site < nsites) sum += (weights ? weights[site] : 1.0) * Dt[t];
             }
         }
-        W[(size_t)a * n] = sum;
+    }
+    rootpart[blockIdx.x * 64 + a] = sum;
+}
+
+__global__ void __launch_bounds__(256)
+expect_root_finish_kernel(int n, const double *__restrict__ rootpart, double *__restrict__ W)
+{
+    for (int e = threadIdx.x; e < n * n; e += 256) {
+        const int a = e / n, b = e - a * n;
+        double sum = 0.0;
+        if (b == 0)
+            for (int c = 0; c < EX_ROOT_CHUNKS; ++c) sum += rootpart[c * 64 + a];
+        W[e] = sum;
     }
 }
 
@@ -249,12 +265,18 @@ int run_chunk(rt_ctx *ctx, rt_model *model, int64_t n, int64_t nsites, int64_t n
     const long nblocks = (long)s->nblocks;
     const size_t arr = (size_t)nops * nblocks * NT * 256;
     dev_free mem;
-    double *d_L, *d_M, *d_D, *d_U, *d_part, *d_w = nullptr;
-    RT_TRY(mem.alloc(d_L, arr));
-    RT_TRY(mem.alloc(d_M, arr));
-    RT_TRY(mem.alloc(d_D, arr));
-    RT_TRY(mem.alloc(d_U, arr));
-    RT_TRY(mem.alloc(d_part, (size_t)nops * EX_CHUNKS * NT * NT * 256));
+    double *d_L, *d_M, *d_D, *d_U, *d_part, *d_rootpart, *d_w = nullptr;
+    RT_TRY(mem.alloc(d_rootpart, (size_t)EX_ROOT_CHUNKS * 64));
+    // the four per-step arrays and the chunk partials live in the context's grow-only scratch
+    // (2.6 GB at 10 000 sites of the codon model: a hipMalloc / hipFree pair per call costs more
+    // than the kernels)
+    const size_t npart = (size_t)nops * EX_CHUNKS * NT * NT * 256;
+    RT_TRY(rt_scratch_reserve(ctx, (4 * arr + npart) * 8));
+    d_L = (double *)ctx->d_scratch;
+    d_M = d_L + arr;
+    d_D = d_M + arr;
+    d_U = d_D + arr;
+    d_part = d_U + arr;
     if (site_weights) {
         RT_TRY(mem.alloc(d_w, (size_t)nsites));
         RT_HIP(hipMemcpyAsync(d_w, site_weights, (size_t)nsites * 8, hipMemcpyHostToDevice, st));
@@ -273,8 +295,9 @@ int run_chunk(rt_ctx *ctx, rt_model *model, int64_t n, int64_t nsites, int64_t n
                        0, st, nops, d_U, d_L, d_w, (long)nsites, nblocks, d_part);
     hipLaunchKernelGGL(expect_finish_kernel, dim3((unsigned)(nops - 1)), dim3(256), 0, st, (int)n, NT,
                        nops, d_step_node, esd_dev, d_part, d_W);
-    hipLaunchKernelGGL(expect_root_kernel, dim3(1), dim3(256), 0, st, (int)n, NT, nops - 1, d_D, d_w,
-                       (long)nsites, nblocks, d_W);
+    hipLaunchKernelGGL(expect_root_kernel, dim3(EX_ROOT_CHUNKS), dim3(64), 0, st, (int)n, NT, nops - 1,
+                       d_D, d_w, (long)nsites, nblocks, d_rootpart);
+    hipLaunchKernelGGL(expect_root_finish_kernel, dim3(1), dim3(256), 0, st, (int)n, d_rootpart, d_W);
     RT_HIP(hipGetLastError());
     RT_HIP(hipStreamSynchronize(st));
     return RT_OK;

@@ -225,6 +225,8 @@ int scratch_reserve(rt_ctx *ctx, size_t bytes)
 
 }  // namespace
 
+int rt_scratch_reserve(rt_ctx *ctx, size_t bytes) { return scratch_reserve(ctx, bytes); }
+
 // The pass sequence of _mcy_dense.py:261-291 / _mcz.py:128-163 in ONE call: the tree,
 // the transition matrices and the masks go to the device once, the three kernels
 // run back to back, masks and pmaps come back once.  (Through the three separate
