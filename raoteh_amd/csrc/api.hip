@@ -830,6 +830,7 @@ struct jit_override {
     int mode = 0;             // 0 automatic, 1 interpreter only, 2 exactly these parameters
     int T = 1, S = 64, WG = 1, D = 1, LA = 1, compact = 0;
     bool quad = false;
+    bool no_solo = false;     // n <= 32: the split-M interpreter kernel, not the one-wave one
 };
 
 static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov)
@@ -1103,6 +1104,7 @@ static int sites_create_impl(rt_model *m, int64_t nsites, int kind, int64_t nobs
         s->lane_dma = ptab + 4 * (3 * 64 * np * 8 + stack) <= 80 * 1024;
     }
     s->mfma_solo = s->layout == RT_LAYOUT_MFMA && m->n <= 32 && !getenv("RAOTEH_MFMA_NO_SOLO");
+    if (ov && ov->no_solo) s->mfma_solo = false;
     if (const char *v = getenv("RAOTEH_LANE_VARIANT")) s->lane_dma = strcmp(v, "dma") == 0;
     if (const char *r = getenv("RAOTEH_LANE_RING")) s->lane_ring = atoi(r);
     else s->lane_ring = s->lane_dma ? 0 : 8;      // 0: rt_launch_prune picks what fits
@@ -1139,6 +1141,7 @@ int rt_sites_create_interpreter(rt_model *m, int64_t nsites, int kind, int64_t n
 {
     jit_override interp;
     interp.mode = 1;
+    interp.no_solo = true;        // the kernel that can leave L and M of every step behind
     return sites_create_impl(m, nsites, kind, nobs, obs_nodes, data, &interp, out);
 }
 

@@ -1,4 +1,4 @@
-// Expected history statistics at codon scale on the matrix pipe (32 < n <= 64).
+// Expected history statistics on the matrix pipe (8 < n <= 64: the codon and compound models).
 //
 // rt_mjp_esd_expectation_weights_obs needs, per edge e = (p -> v) and summed over the sites,
 //     W_e[a][b] = sum_s w_s u_s[a] L_v,s[b],   u = D_p / M_v,   D_v = (P_v^T u) * L_v,
@@ -311,7 +311,7 @@ int rt_expectation_weights_mfma(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t 
                                 int kind, const void *data, const double *site_weights,
                                 double *edge_weights, int32_t *status)
 {
-    if (n <= 32 || n > 64 || nnodes < 2 || getenv("RAOTEH_EXPECT_LEGACY")) return RT_ERR_UNSUPPORTED;
+    if (n <= 8 || n > 64 || nnodes < 2 || getenv("RAOTEH_EXPECT_LEGACY")) return RT_ERR_UNSUPPORTED;
     rt_model *model = nullptr;
     RT_TRY(rt_model_create(ctx, nnodes, n, idx, ptr, &model));
     struct mguard { rt_model *m; ~mguard() { rt_model_destroy(m); } } mg{model};
@@ -369,6 +369,12 @@ int rt_expectation_weights_mfma(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t 
                                  model->d_root, chunk_w, step_node, parent_step, internal, d_W,     \
                                  d_status, d_PT, d_step_node, d_parent_step, d_internal)
         switch (KS) {
+        case 3: RT_EX(1, 3); break;
+        case 4: RT_EX(1, 4); break;
+        case 5: RT_EX(2, 5); break;
+        case 6: RT_EX(2, 6); break;
+        case 7: RT_EX(2, 7); break;
+        case 8: RT_EX(2, 8); break;
         case 9: RT_EX(3, 9); break;
         case 10: RT_EX(3, 10); break;
         case 11: RT_EX(3, 11); break;

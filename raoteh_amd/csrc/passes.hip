@@ -1385,7 +1385,7 @@ int expectation_weights_impl(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t nsi
         memset(edge_weights, 0, wcount * 8);
         return RT_OK;
     }
-    // 32 < n <= 64, compact observations: two pruning-shaped passes and the site sums on the
+    // 8 < n <= 64, compact observations: two pruning-shaped passes and the site sums on the
     // matrix pipe (expect_mfma.hip); RT_ERR_UNSUPPORTED = not its case, go on below
     if (!state_mask) {
         const int rc = rt_expectation_weights_mfma(ctx, nnodes, n, nsites, idx, ptr, esd, root_distn,

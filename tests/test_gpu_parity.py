@@ -956,8 +956,12 @@ def test_expected_history_statistics_batch(ra):
         assert not st.any()
         W2, rp2, st2 = ra.ctx.expectation_weights_obs(
             ta.indices, ta.indptr, esd, big['root_distn'], cols, bmask, 'mask', site_weights=bw)
-        np.testing.assert_array_equal(W2, W)
-        np.testing.assert_array_equal(rp2, rp)
+        if bn <= 8:          # both forms go through the same fused kernel
+            np.testing.assert_array_equal(W2, W)
+            np.testing.assert_array_equal(rp2, rp)
+        else:                # compact observations: the matrix-pipe passes; full masks: per-pass
+            np.testing.assert_allclose(W2, W, rtol=1e-11, atol=1e-14 * np.abs(W).max())
+            np.testing.assert_allclose(rp2, rp, rtol=1e-12)
         pm = np.empty(m3.shape)
         ra.ctx.passes(ta.indices, ta.indptr, esd, m3.copy(), pm)
         dn, _ = ra.ctx.node_to_distn(ta.indices, ta.indptr, esd, big['root_distn'], pm)
@@ -2032,7 +2036,7 @@ def test_device_chains_at_the_limits(ra):
 
 
 def test_codon_scale_expectation_weights_on_the_matrix_pipe(ra, monkeypatch):
-    """rt_mjp_esd_expectation_weights_obs for 32 < n <= 64 (csrc/expect_mfma.hip: upward pass
+    """rt_mjp_esd_expectation_weights_obs for 8 < n <= 64 (csrc/expect_mfma.hip: upward pass
     with L and M kept, downward pass with P^T fragments, site sums as GEMMs over the sites)
     against the reference-format per-pass kernels on the same input: 61-state codon model
     and a 40-state random model (three row tiles), site weights, ambiguous and impossible
@@ -2050,6 +2054,11 @@ def test_codon_scale_expectation_weights_on_the_matrix_pipe(ra, monkeypatch):
     np.fill_diagonal(R, 0.0)
     Q2 = R - np.diag(R.sum(axis=1))
     cases.append((T2, root2, n2, leaves2, Q2, None, rng.randint(n2, size=(77, len(leaves2)))))
+    for n3 in (9, 20, 31):                                   # one and two row tiles
+        R = rng.exponential(size=(n3, n3))
+        np.fill_diagonal(R, 0.0)
+        cases.append((T2, root2, n3, leaves2, R - np.diag(R.sum(axis=1)), rng.dirichlet(np.ones(n3)),
+                      rng.randint(n3, size=(130, len(leaves2)))))
     for T, root, n, leaves, Q, rd, states in cases:
         nb = states.shape[0]
         T_aug = _mjp_dense.get_expm_augmented_tree(T, root, Q_default=Q)
