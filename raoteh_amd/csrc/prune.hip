@@ -594,7 +594,7 @@ prune_lanedma_kernel(const double *__restrict__ Pord,   // [nrec][N][N]
 // the pending accumulators (LDS stack, 2 KB per slot per wave).  A workgroup is
 // 4 waves (3 when NT = 3) = 4/NT site tiles; nothing but x crosses waves.
 
-template <int NT, int KS>
+template <int NT, int KS, bool STORE>
 __global__ void __launch_bounds__((NT == 3 ? 3 : 4) * 64)
 prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
                   const int4_t *__restrict__ prog, int nops,   // LOP_* program
@@ -683,7 +683,7 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
             for (int r = 0; r < 4; ++r) x[r] = (flags & LOP_OBS) ? on[r] : 1.0;
         }
         if (flags & LOP_OBS) knext += 1;
-        if (Lout && live) {
+        if (STORE && live) {
             double *lo = Lout + ((size_t)i * nblocks16 + gt) * (NT * 256) + (m * 4) * 64 + lane;
 #pragma unroll
             for (int r = 0; r < 4; ++r) lo[r * 64] = x[r];
@@ -747,7 +747,7 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
             const double b = xb[kk * 64 + lane];
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], b, acc, 0, 0, 0);
         }
-        if (Mout && live) {
+        if (STORE && live) {
             double *mo = Mout + ((size_t)i * nblocks16 + gt) * (NT * 256) + (m * 4) * 64 + lane;
 #pragma unroll
             for (int r = 0; r < 4; ++r) mo[r * 64] = acc[r];
@@ -1424,7 +1424,8 @@ static int launch_mfma_inst(rt_model *m, rt_sites *s)
     constexpr int TILES = WAVES / NT;
     const int lds = (TILES * NT * 4 * 64 + TILES * NT * 16) * 8 + WAVES * lds_slots * 2048;
     const unsigned grid = (unsigned)((s->nblocks + TILES - 1) / TILES);
-    auto kern = prune_mfma_kernel<NT, KS>;
+    // the instance with the two stores only when somebody asked for L and M (expect_mfma.hip)
+    auto kern = s->d_Lout ? prune_mfma_kernel<NT, KS, true> : prune_mfma_kernel<NT, KS, false>;
     RT_HIP(hipFuncSetAttribute((const void *)kern,
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     RT_LAUNCH_TIMED(m->ctx, kern, dim3(grid), dim3(WAVES * 64), lds,
