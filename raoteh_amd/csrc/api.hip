@@ -230,16 +230,19 @@ extern "C" int rt_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *Q,
         qi[(size_t)b] = (int32_t)v;
     }
     RT_HIP(hipSetDevice(ctx->device));
-    double *dQ = nullptr, *dt = nullptr, *dP = nullptr;
-    int32_t *dqi = nullptr, *dinfo = nullptr;
+    // operands in the context's grow-only scratch: five hipMalloc / hipFree pairs per call cost
+    // far more than the kernel (the call is synchronous, nothing else uses the scratch meanwhile)
     const size_t nn = (size_t)n * n;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_Q = 0, o_t = o_Q + up(nq * nn * 8), o_P = o_t + up(count * 8),
+                 o_qi = o_P + up(count * nn * 8), o_info = o_qi + up(count * 4),
+                 total = o_info + up(count * 8);
+    RT_TRY(rt_scratch_reserve(ctx, total));
+    unsigned char *base = ctx->d_scratch;
+    double *dQ = (double *)(base + o_Q), *dt = (double *)(base + o_t), *dP = (double *)(base + o_P);
+    int32_t *dqi = (int32_t *)(base + o_qi), *dinfo = (int32_t *)(base + o_info);
     int rc = RT_OK;
-    hipError_t e = hipMalloc((void **)&dQ, nq * nn * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&dt, count * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&dP, count * nn * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&dqi, count * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&dinfo, count * 8);
-    if (e == hipSuccess) e = hipMemcpyAsync(dQ, Q, nq * nn * 8, hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e = hipMemcpyAsync(dQ, Q, nq * nn * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(dt, t, count * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(dqi, qi.data(), count * 4, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) rc = rt_launch_expm(ctx, n, count, dQ, dqi, dt, dP, dinfo, nullptr, 0, nullptr);
@@ -249,7 +252,6 @@ extern "C" int rt_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *Q,
     if (e == hipSuccess && rc == RT_OK)
         e = hipMemcpyAsync(hinfo.data(), dinfo, count * 8, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && rc == RT_OK) e = hipStreamSynchronize(ctx->stream);
-    hipFree(dQ); hipFree(dt); hipFree(dP); hipFree(dqi); hipFree(dinfo);
     if (rc != RT_OK) return rc;
     if (e != hipSuccess) {
         rt_set_error("rt_expm: %s", hipGetErrorString(e));
