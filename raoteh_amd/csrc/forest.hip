@@ -1352,6 +1352,11 @@ extern "C" int rt_chains_get_statistics(rt_chains *h, double *dwell, int64_t *tr
     const int64_t C = h->nchains, n = h->n, N = h->N;
     double *d_dwell = nullptr;
     long long *d_trans = nullptr;
+    struct release {                      // also on the error returns below
+        double *&a;
+        long long *&b;
+        ~release() { hipFree(a); hipFree(b); }
+    } guard{d_dwell, d_trans};
     if (dwell) RT_HIP(hipMalloc((void **)&d_dwell, C * n * 8));
     if (transitions) {
         RT_HIP(hipMalloc((void **)&d_trans, C * n * n * 8));
@@ -1369,8 +1374,6 @@ extern "C" int rt_chains_get_statistics(rt_chains *h, double *dwell, int64_t *tr
     if (node_states)
         RT_HIP(hipMemcpyAsync(node_states, h->d_node_state, C * N * 4, hipMemcpyDeviceToHost, st));
     RT_HIP(hipStreamSynchronize(st));
-    hipFree(d_dwell);
-    hipFree(d_trans);
     return RT_OK;
 }
 
