@@ -117,6 +117,7 @@ extern "C" int rt_ctx_destroy(rt_ctx *ctx)
     hipSetDevice(ctx->device);
     ctx->pending_reduce = nullptr;       // its batch may be gone already
     hipStreamSynchronize(ctx->stream);
+    rt_expect_cache_release(ctx);
     rt_comm_destroy(ctx);
     rt_jit_release(ctx);
     for (auto &s : ctx->slots) {

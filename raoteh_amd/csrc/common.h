@@ -92,6 +92,7 @@ struct rt_ctx {
     size_t expm_attr_lds = 0;      // dynamic-LDS attribute already granted to expm_kernel
     size_t expm_ts_attr_lds[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ... to the Taylor kernels (per NT)
     double *d_expm_scratch = nullptr;   // matrices of the order > 64 Taylor kernel (grow-only)
+    void *expect_cache = nullptr;       // expect_mfma.hip: model + packed batch of the last call
     size_t expm_scratch_bytes = 0;
 };
 static const int RT_OPT_UNSET = -2;
@@ -247,6 +248,8 @@ int rt_launch_prune_jit(rt_model *m, rt_sites *s);
 // a batch that runs the interpreter kernels only (no tree-specialised kernel is compiled)
 int rt_sites_create_interpreter(rt_model *m, int64_t nsites, int kind, int64_t nobs,
                                 const int64_t *obs_nodes, const void *data, rt_sites **out);
+// drops what rt_expectation_weights_mfma keeps between calls (rt_ctx_destroy)
+void rt_expect_cache_release(rt_ctx *ctx);
 // the context's grow-only device scratch (ctx->d_scratch) holds at least `bytes` afterwards
 int rt_scratch_reserve(rt_ctx *ctx, size_t bytes);
 // expectation path on the matrix pipe (expect_mfma.hip); RT_ERR_UNSUPPORTED = not this case

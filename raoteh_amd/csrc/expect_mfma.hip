@@ -26,6 +26,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 namespace {
@@ -246,19 +247,65 @@ struct dev_free {
     }
 };
 
+// An EM loop calls with the same tree and the same observations again and again, only the
+// transition matrices change: the model (schedule, device tree) and the packed batch of the
+// last call stay with the context (one entry; 2.5 of a call's 6 ms at 10 000 codon sites were
+// creating and destroying them).  Keys: sizes + FNV-1a of the tree arrays / of the observations.
+struct expect_cache_t {
+    uint64_t tree_key = 0, data_key = 0;
+    int64_t nnodes = 0, n = 0, nsites = 0, nobs = 0, chunk_lo = -1;
+    int kind = -1;
+    rt_model *model = nullptr;
+    rt_sites *sites = nullptr;
+    ~expect_cache_t()
+    {
+        if (sites) rt_sites_destroy(sites);
+        if (model) rt_model_destroy(model);
+    }
+};
+
+uint64_t fnv1a(const void *p, size_t bytes, uint64_t h = 1469598103934665603ull)
+{
+    // eight bytes a round (the observations of a batch are megabytes), the tail bytewise
+    const unsigned char *b = (const unsigned char *)p;
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) {
+        uint64_t w;
+        memcpy(&w, b + i, 8);
+        h = (h ^ w) * 1099511628211ull;
+        h ^= h >> 29;
+    }
+    for (; i < bytes; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    return h;
+}
+
 template <int NT, int KS>
 int run_chunk(rt_ctx *ctx, rt_model *model, int64_t n, int64_t nsites, int64_t nobs,
               const int64_t *obs_nodes, int kind, const void *data, const double *esd_dev,
               const double *d_root_w, const double *site_weights, const std::vector<int> &step_node,
               const std::vector<int> &parent_step, const std::vector<unsigned char> &internal,
               double *d_W, int *d_status, double *d_PT, const int *d_step_node,
-              const int *d_parent_step, const unsigned char *d_internal)
+              const int *d_parent_step, const unsigned char *d_internal, rt_sites *cached_sites,
+              rt_sites **keep_sites)
 {
     (void)step_node; (void)parent_step; (void)internal;
     hipStream_t st = ctx->stream;
-    rt_sites *s = nullptr;
-    RT_TRY(rt_sites_create_interpreter(model, nsites, kind, nobs, obs_nodes, data, &s));
-    struct guard { rt_sites *s; ~guard() { rt_sites_destroy(s); } } g{s};
+    // RAOTEH_EXPECT_TRACE=1: host wall clock of the stages (each ends with a stream sync)
+    const bool trace = getenv("RAOTEH_EXPECT_TRACE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t0 = now();
+    rt_sites *s = cached_sites;
+    struct guard { rt_sites *s; ~guard() { if (s) rt_sites_destroy(s); } } g{nullptr};
+    if (!s) {
+        RT_TRY(rt_sites_create_interpreter(model, nsites, kind, nobs, obs_nodes, data, &s));
+        if (keep_sites) *keep_sites = s;      // the caller's cache owns it now
+        else g.s = s;
+    }
+    if (trace) hipStreamSynchronize(st);
+    const auto t1 = now();
     RT_REQUIRE(s->layout == RT_LAYOUT_MFMA && !s->mfma_solo && !s->jit_fn,
                "unexpected batch layout for the matrix-pipe expectation path");
     const int nops = (int)s->ops.size();
@@ -287,6 +334,8 @@ int run_chunk(rt_ctx *ctx, rt_model *model, int64_t n, int64_t nsites, int64_t n
     const int rc = rt_launch_prune(model, s, false);
     s->d_Lout = s->d_Mout = nullptr;
     RT_TRY(rc);
+    if (trace) hipStreamSynchronize(st);
+    const auto t2 = now();
     RT_HIP(hipMemsetAsync(d_status, 0, (size_t)nsites * 4, st));
     hipLaunchKernelGGL((expect_down_kernel<NT, KS>), dim3((unsigned)nblocks), dim3(64 * NT), 0, st,
                        d_PT, nops, d_parent_step, d_internal, d_L, d_M, d_D, d_U, d_root_w, (int)n,
@@ -300,6 +349,10 @@ int run_chunk(rt_ctx *ctx, rt_model *model, int64_t n, int64_t nsites, int64_t n
     hipLaunchKernelGGL(expect_root_finish_kernel, dim3(1), dim3(256), 0, st, (int)n, d_rootpart, d_W);
     RT_HIP(hipGetLastError());
     RT_HIP(hipStreamSynchronize(st));
+    if (trace)
+        fprintf(stderr, "[raoteh_amd] expectation pass of %lld sites: batch + packing %.2f ms, scratch "
+                "+ upward pass %.2f ms, downward pass + site sums %.2f ms\n", (long long)nsites,
+                ms(t0, t1), ms(t1, t2), ms(t2, now()));
     return RT_OK;
 }
 
@@ -312,9 +365,34 @@ int rt_expectation_weights_mfma(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t 
                                 double *edge_weights, int32_t *status)
 {
     if (n <= 8 || n > 64 || nnodes < 2 || getenv("RAOTEH_EXPECT_LEGACY")) return RT_ERR_UNSUPPORTED;
-    rt_model *model = nullptr;
-    RT_TRY(rt_model_create(ctx, nnodes, n, idx, ptr, &model));
-    struct mguard { rt_model *m; ~mguard() { rt_model_destroy(m); } } mg{model};
+    const auto call_start = std::chrono::steady_clock::now();
+    const size_t item = kind == RT_OBS_STATE ? 1 : 8;
+    uint64_t tree_key = fnv1a(ptr, (size_t)(nnodes + 1) * 8);
+    tree_key = fnv1a(idx, (size_t)(nnodes - 1) * 8, tree_key);
+    tree_key = fnv1a(obs_nodes, (size_t)nobs * 8, tree_key);
+    expect_cache_t *cache = (expect_cache_t *)ctx->expect_cache;
+    if (cache && !(cache->tree_key == tree_key && cache->nnodes == nnodes && cache->n == n &&
+                   cache->nobs == nobs && cache->kind == kind)) {
+        delete cache;
+        cache = nullptr;
+        ctx->expect_cache = nullptr;
+    }
+    if (!cache) {
+        cache = new (std::nothrow) expect_cache_t();
+        if (!cache) return RT_ERR_NOMEM;
+        ctx->expect_cache = cache;
+        cache->tree_key = tree_key;
+        cache->nnodes = nnodes;
+        cache->n = n;
+        cache->nobs = nobs;
+        cache->kind = kind;
+        const int rc = rt_model_create(ctx, nnodes, n, idx, ptr, &cache->model);
+        if (rc != RT_OK) {
+            rt_expect_cache_release(ctx);
+            return rc;
+        }
+    }
+    rt_model *model = cache->model;
     if (model->max_depth > RT_FAST_MAX_DEPTH) return RT_ERR_UNSUPPORTED;     // generic kernel only
     RT_TRY(rt_model_set_transitions(model, esd));
     std::vector<double> ones;
@@ -358,16 +436,31 @@ int rt_expectation_weights_mfma(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t 
     RT_HIP(hipGetLastError());
     const size_t wcount = (size_t)nnodes * n * n;
     std::vector<double> acc(wcount, 0.0), part(wcount);
-    const size_t item = kind == RT_OBS_STATE ? 1 : 8;
+    // the packed batch is kept when the whole call is one pass (its observations hashed)
+    const bool one_pass = nsites <= CS;
+    uint64_t data_key = 0;
+    if (one_pass) {
+        data_key = fnv1a(data, (size_t)nsites * (size_t)nobs * item);
+        if (cache->sites && !(cache->data_key == data_key && cache->nsites == nsites)) {
+            rt_sites_destroy(cache->sites);
+            cache->sites = nullptr;
+        }
+    } else if (cache->sites) {
+        rt_sites_destroy(cache->sites);
+        cache->sites = nullptr;
+    }
     for (int64_t lo = 0; lo < nsites; lo += CS) {
         const int64_t cnt = std::min<int64_t>(CS, nsites - lo);
         const void *chunk_data = (const unsigned char *)data + (size_t)lo * (size_t)nobs * item;
         const double *chunk_w = site_weights ? site_weights + lo : nullptr;
+        rt_sites *cached = one_pass ? cache->sites : nullptr;
+        rt_sites *made = nullptr;
+        rt_sites **keep = one_pass && !cached ? &made : nullptr;
         int rc = RT_ERR_UNSUPPORTED;
 #define RT_EX(NTV, KSV)                                                                           \
         rc = run_chunk<NTV, KSV>(ctx, model, n, cnt, nobs, obs_nodes, kind, chunk_data, model->d_P, \
                                  model->d_root, chunk_w, step_node, parent_step, internal, d_W,     \
-                                 d_status, d_PT, d_step_node, d_parent_step, d_internal)
+                                 d_status, d_PT, d_step_node, d_parent_step, d_internal, cached, keep)
         switch (KS) {
         case 3: RT_EX(1, 3); break;
         case 4: RT_EX(1, 4); break;
@@ -385,11 +478,28 @@ int rt_expectation_weights_mfma(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t 
         default: RT_EX(4, 16); break;
         }
 #undef RT_EX
+        if (made) {
+            cache->sites = made;
+            cache->data_key = data_key;
+            cache->nsites = nsites;
+        }
         RT_TRY(rc);
         RT_HIP(hipMemcpy(part.data(), d_W, wcount * 8, hipMemcpyDeviceToHost));
         for (size_t e = 0; e < wcount; ++e) acc[e] += part[e];
         if (status) RT_HIP(hipMemcpy(status + lo, d_status, (size_t)cnt * 4, hipMemcpyDeviceToHost));
     }
     memcpy(edge_weights, acc.data(), wcount * 8);
+    if (getenv("RAOTEH_EXPECT_TRACE"))
+        fprintf(stderr, "[raoteh_amd] expectation call: %.2f ms in all\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() -
+                                                          call_start).count());
     return RT_OK;
 }
+
+void rt_expect_cache_release(rt_ctx *ctx)
+{
+    if (!ctx || !ctx->expect_cache) return;
+    delete (expect_cache_t *)ctx->expect_cache;
+    ctx->expect_cache = nullptr;
+}
+
