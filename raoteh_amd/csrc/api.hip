@@ -125,6 +125,9 @@ extern "C" int rt_ctx_destroy(rt_ctx *ctx)
         for (auto ev : s.pool) hipEventDestroy(ev);
     }
     hipStreamDestroy(ctx->stream);
+    if (ctx->stream2) hipStreamDestroy(ctx->stream2);
+    if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     hipFree(ctx->d_totals_arena);
     hipFree(ctx->d_scratch);
     hipFree(ctx->d_expm_scratch);
@@ -635,6 +638,7 @@ extern "C" int rt_sites_destroy(rt_sites *s)
     hipStreamSynchronize(s->model->ctx->stream);
     // an all-reduce of this batch's totals may still be in flight on the comm stream
     rt_jit_ref(s->model->ctx, s->jit_fn, -1);
+    if (s->jit_fn2) rt_jit_ref(s->model->ctx, s->jit_fn2, -1);
     hipFree(s->d_ops); hipFree(s->d_lane_ops); hipFree(s->d_obs); hipFree(s->d_loglik); hipFree(s->d_status);
     if (s->model->ctx->comm_stream) hipStreamSynchronize(s->model->ctx->comm_stream);
     hipFree(s->d_partial); hipFree(s->d_scratch);
@@ -938,6 +942,45 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
         bool quad = s->model->d_Pquad != nullptr && KS * KS * 16.5 <= 0.8 * NT * KS * 67.0;
         if (const char *v = getenv("RAOTEH_JIT_QUAD")) quad = s->model->d_Pquad && atoi(v) != 0;
         int rc = RT_ERR_UNSUPPORTED;
+        // A batch a little over a whole number q of tiles per SIMD (C5: 3 125 tiles on 1 024
+        // SIMDs = 3.05) leaves, with q + 1 tiles per wave, a quarter of the SIMDs without a wave
+        // and the others with a tile too many.  Then: q tiles per wave on every SIMD and the few
+        // tiles over as one-tile waves of a second kernel on a side stream, next to them.
+        // MEASURED, AND NOT THE DEFAULT (RAOTEH_JIT_SPLIT2=1 turns it on): the two kernels do
+        // run side by side (rocprofv3: main 0..64 us, tail 7..65 us, against 67 us for the
+        // single T = 4 kernel), but the one-tile waves crawl next to the three-tile ones (58 us
+        // instead of 26 alone), the main kernel slows from 57 to 64 us, and the fork / join
+        // events between the streams cost more than the 2 us gained: the step goes from 80 to
+        // 95 us.  Only without an explicit RAOTEH_JIT_TILES.
+        {
+            const int64_t nsimd = 4 * (int64_t)s->model->ctx->num_cus;
+            const int64_t q = nsimd > 0 ? ntiles / nsimd : 0, r = nsimd > 0 ? ntiles - q * nsimd : 0;
+            const char *sp = getenv("RAOTEH_JIT_SPLIT2");
+            if (!getenv("RAOTEH_JIT_TILES") && sp && atoi(sp) != 0 && q >= 1 && q <= 3 && r > 0 &&
+                r <= nsimd / 4 && T == (int)q + 1) {
+                void *fn_main = nullptr, *fn_tail = nullptr;
+                double cs1 = 0.0, cs2 = 0.0;
+                const std::string src_main =
+                    rt_jit_mfma_source(s->ops, (int)s->model->n, (int)s->nobs, (int)q, D, LA, quad);
+                int rc2 = rt_jit_get(s->model->ctx, src_main, &fn_main, true, &cs1);
+                if (rc2 == RT_OK) {
+                    const std::string src_tail =
+                        rt_jit_mfma_source(s->ops, (int)s->model->n, (int)s->nobs, 1, D, LA, quad);
+                    rc2 = rt_jit_get(s->model->ctx, src_tail, &fn_tail, true, &cs2);
+                    if (rc2 != RT_OK) rt_jit_ref(s->model->ctx, fn_main, -1);
+                }
+                if (rc2 == RT_OK) {
+                    s->jit_fn = fn_main;
+                    s->jit_fn2 = fn_tail;
+                    s->jit_tiles = (int)q;
+                    s->jit_tiles2 = 1;
+                    s->jit_split_tiles = q * nsimd;
+                    s->jit_compile_s = cs1 + cs2;
+                    s->jit_quad = quad;
+                    return RT_OK;
+                }
+            }
+        }
         for (; T >= 1 && rc == RT_ERR_UNSUPPORTED; --T) {         // fewer tiles if it spills
             const std::string src =
                 rt_jit_mfma_source(s->ops, (int)s->model->n, (int)s->nobs, T, D, LA, quad);
@@ -1115,7 +1158,33 @@ static int sites_create_impl(rt_model *m, int64_t nsites, int kind, int64_t nobs
     // a freshly compiled kernel is checked against the interpreter kernel on a probe batch
     // before any user batch may launch it; if it fails this batch runs the interpreter
     // (RAOTEH_JIT_NO_VERIFY: diagnostics only, tests/soak/spill_probe.py)
-    if (rc == RT_OK && s->jit_fn && !ov && !rt_jit_verified(m->ctx, s->jit_fn) &&
+    if (rc == RT_OK && s->jit_fn2 && !ov && !getenv("RAOTEH_JIT_NO_VERIFY")) {
+        // two-kernel batch: each kernel is checked as the single kernel of a probe batch
+        void *fn_main = s->jit_fn, *fn_tail = s->jit_fn2;
+        const int t_main = s->jit_tiles;
+        bool good = true;
+        for (int which = 0; which < 2 && good; ++which) {
+            s->jit_fn = which ? fn_tail : fn_main;
+            s->jit_tiles = which ? s->jit_tiles2 : t_main;
+            s->jit_fn2 = nullptr;
+            if (!rt_jit_verified(m->ctx, s->jit_fn)) {
+                const int vrc = verify_jit_kernel(s, kind);
+                rt_jit_set_verified(m->ctx, s->jit_fn, vrc == RT_OK);
+                good = vrc == RT_OK;
+            }
+        }
+        s->jit_fn = fn_main;
+        s->jit_fn2 = fn_tail;
+        s->jit_tiles = t_main;
+        if (!good) {
+            rt_jit_ref(m->ctx, fn_main, -1);
+            rt_jit_ref(m->ctx, fn_tail, -1);
+            s->jit_fn = s->jit_fn2 = nullptr;
+            s->jit_split_tiles = 0;
+            s->jit_tiles = 1;
+            s->jit_quad = false;
+        }
+    } else if (rc == RT_OK && s->jit_fn && !ov && !rt_jit_verified(m->ctx, s->jit_fn) &&
         !getenv("RAOTEH_JIT_NO_VERIFY")) {
         const int vrc = verify_jit_kernel(s, kind);
         rt_jit_set_verified(m->ctx, s->jit_fn, vrc == RT_OK);
@@ -1282,6 +1351,10 @@ extern "C" int rt_sites_clone(rt_sites *src, rt_sites **out)
     s->lane_ring = src->lane_ring;
     s->jit_fn = src->jit_fn;
     rt_jit_ref(src->model->ctx, s->jit_fn, +1);
+    s->jit_fn2 = src->jit_fn2;
+    if (s->jit_fn2) rt_jit_ref(src->model->ctx, s->jit_fn2, +1);
+    s->jit_tiles2 = src->jit_tiles2;
+    s->jit_split_tiles = src->jit_split_tiles;
     s->jit_prefetch = src->jit_prefetch;
     s->jit_lookahead = src->jit_lookahead;
     s->block_sites = src->block_sites;

@@ -93,6 +93,8 @@ struct rt_ctx {
     size_t expm_ts_attr_lds[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ... to the Taylor kernels (per NT)
     double *d_expm_scratch = nullptr;   // matrices of the order > 64 Taylor kernel (grow-only)
     void *expect_cache = nullptr;       // expect_mfma.hip: model + packed batch of the last call
+    hipStream_t stream2 = nullptr;      // side stream of two-kernel pruning launches (lazy)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     size_t expm_scratch_bytes = 0;
 };
 static const int RT_OPT_UNSET = -2;
@@ -179,6 +181,12 @@ struct rt_sites {
     int block_sites = 64;           // lane family: sites per block (< 64 only with jit_fn)
     int jit_waves = 1;              // waves per workgroup of the tree-specialised kernel
     int jit_tiles = 1;              // MFMA family: site tiles per wave of that kernel
+    // one-wave MFMA family, batches a little over a whole number of tiles per SIMD: the
+    // first jit_split_tiles tiles go to jit_fn (one wave per SIMD), the rest to jit_fn2
+    // (jit_tiles2 = 1 tile per wave) on the context's second stream, side by side
+    void *jit_fn2 = nullptr;
+    int jit_tiles2 = 1;
+    int64_t jit_split_tiles = 0;
     bool jit_quad = false;          // ... built on v_mfma_f64_4x4x4_4b (reads d_Pquad)
     // not owned: where the split-M interpreter kernel leaves L_v and M_v of every step
     // (expect_mfma.hip sets them around its own launch)

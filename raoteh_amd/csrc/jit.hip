@@ -455,12 +455,13 @@ static std::string rt_jit_mfma_quad_pp_source(const std::vector<rt_op> &ops, int
          "rt_jit_prune(const double *__restrict__ Pfrag, const rt_d2 *__restrict__ obs,\n"
          "             const double *__restrict__ root_w, double *__restrict__ loglik,\n"
          "             int *__restrict__ status, double *__restrict__ partial,\n"
-         "             long nsites, long nblocks)\n{\n";
+         "             long nsites, long nblocks, long first_tile, long stride)\n{\n"
+         "    if (blockIdx.x % stride) return;      // a sparse launch: every stride-th workgroup works\n";
     o << "    const int lane = threadIdx.x;\n";
     if (trace)      // the constant 100 MHz clock next to the shader clock: the core frequency
         o << "    if (blockIdx.x == " << trace_wg << " && lane == 0) rt_trace[" << nrec * 3 + 1
           << "] = __builtin_amdgcn_s_memrealtime();\n";
-    o << "    const long tbase = (long)blockIdx.x * " << T << ";\n";
+    o << "    const long tbase = first_tile + (long)(blockIdx.x / stride) * " << T << ";\n";
     o << "    typedef const __attribute__((address_space(1))) rt_d2 *rt_glb2;\n";
     o << "    __shared__ __attribute__((aligned(16))) double qa0[" << QS << "];\n";
     o << "    __shared__ __attribute__((aligned(16))) double qa1[" << QS << "];\n";
@@ -696,12 +697,13 @@ std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int 
          "rt_jit_prune(const double *__restrict__ Pfrag, const rt_d2 *__restrict__ obs,\n"
          "             const double *__restrict__ root_w, double *__restrict__ loglik,\n"
          "             int *__restrict__ status, double *__restrict__ partial,\n"
-         "             long nsites, long nblocks)\n{\n";
+         "             long nsites, long nblocks, long first_tile, long stride)\n{\n"
+         "    if (blockIdx.x % stride) return;      // a sparse launch: every stride-th workgroup works\n";
     o << "    const int lane = threadIdx.x;\n";
     if (trace)      // the constant 100 MHz clock next to the shader clock: the core frequency
         o << "    if (blockIdx.x == " << trace_wg << " && lane == 0) rt_trace[" << nrec * 3 + 1
           << "] = __builtin_amdgcn_s_memrealtime();\n";
-    o << "    const long tbase = (long)blockIdx.x * " << T << ";\n";
+    o << "    const long tbase = first_tile + (long)(blockIdx.x / stride) * " << T << ";\n";
     o << "    typedef const __attribute__((address_space(1))) rt_d2 *rt_glb2;\n";
     const int QS = ((KS * KS * 16 + 127) / 128) * 128;    // rt_quad_stride(n)
     const int QL = QS / 128;                              // 1 KiB wave loads per step
@@ -1737,7 +1739,41 @@ int rt_launch_prune_jit(rt_model *m, rt_sites *s)
     double *partial = s->d_partial;
     long nsites = (long)s->nsites;
     long nblocks = (long)s->nblocks;
-    void *args[] = {&Pord, &obs, &root_w, &loglik, &status, &partial, &nsites, &nblocks};
+    long tile0 = 0, stride1 = 1;     // declared by the one-wave MFMA family only
+    void *args[] = {&Pord, &obs, &root_w, &loglik, &status, &partial, &nsites, &nblocks, &tile0,
+                    &stride1};
+    if (s->jit_fn2) {
+        // main kernel: jit_split_tiles tiles, jit_tiles per wave (one wave per SIMD); the rest
+        // one tile per wave on the side stream, at the same time.  The timing events, when
+        // this launch is sampled, stand around both.
+        rt_ctx *ctx = m->ctx;
+        if (!ctx->stream2) {
+            RT_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+            RT_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+            RT_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        }
+        if (ctx->ev_start) RT_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
+        RT_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+        RT_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        const unsigned main_groups = (unsigned)(s->jit_split_tiles / s->jit_tiles);
+        RT_HIP(hipModuleLaunchKernel((hipFunction_t)s->jit_fn, main_groups, 1, 1, 64, 1, 1, 0,
+                                     ctx->stream, args, nullptr));
+        // the few tail waves as every stride-th workgroup of a launch as wide as the main one:
+        // launched dense, the dispatcher put all of them on the first free slots it found -- a
+        // handful of CUs -- and those SIMDs carried six tiles (87 us instead of 67)
+        long tail0 = (long)s->jit_split_tiles;
+        const long tail_waves = (s->nblocks - s->jit_split_tiles + s->jit_tiles2 - 1) / s->jit_tiles2;
+        long stride = std::max<long>(1, (long)main_groups / tail_waves);
+        if (const char *v = getenv("RAOTEH_JIT_TAIL_STRIDE")) stride = std::max(1, atoi(v));
+        void *args2[] = {&Pord, &obs, &root_w, &loglik, &status, &partial, &nsites, &nblocks, &tail0,
+                         &stride};
+        RT_HIP(hipModuleLaunchKernel((hipFunction_t)s->jit_fn2, (unsigned)(tail_waves * stride), 1, 1,
+                                     64, 1, 1, 0, ctx->stream2, args2, nullptr));
+        RT_HIP(hipEventRecord(ctx->ev_join, ctx->stream2));
+        RT_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        if (ctx->ev_stop) RT_HIP(hipEventRecord(ctx->ev_stop, ctx->stream));
+        return RT_OK;
+    }
     // lane family: jit_waves waves of one site block each per workgroup; MFMA family,
     // n <= 32: one wave of jit_tiles site tiles per workgroup; n > 32: jit_waves = NT
     // waves share jit_tiles tiles

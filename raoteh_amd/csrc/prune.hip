@@ -1548,6 +1548,10 @@ int rt_launch_prune(rt_model *m, rt_sites *s, bool defer_reduce)
                      s->jit_prefetch, s->compact_states == 1 ? ",states"
                                       : s->compact_states == 2 ? ",masks" : "");
         else
+            if (s->jit_fn2)
+                snprintf(jit_name, sizeof(s->kernel_name), "prune_tree_jit_mfma%s<%d,T%d+T%d>",
+                         s->jit_quad ? "4x4" : "", (int)m->n, s->jit_tiles, s->jit_tiles2);
+            else
             snprintf(jit_name, sizeof(s->kernel_name), "prune_tree_jit_mfma%s<%d,T%d>",
                      s->jit_quad ? "4x4" : "", (int)m->n, s->jit_tiles);
         name = jit_name;
