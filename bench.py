@@ -412,6 +412,51 @@ def run_workload(name, ctx, ctl, rank, world, reduce_kind, steps, warmup, args,
     return out
 
 
+def measure_next_rows(ctx):
+    """The paths either side of the hot path, one short measurement each,
+    carried next to the headline; not part of any timed region above and never fatal."""
+    import time
+    out = {}
+    try:
+        from raoteh_amd import _mjp_dense, _sampler, synth
+        for name, nsites in (('c3', 10000), ('c2', 100000)):
+            cfg = synth.make_config(name, nsites=nsites)
+            kw = dict(root_distn=cfg['root_distn'], Q_default=cfg['Q_default'],
+                      obs_nodes=cfg['leaves'], data=cfg['leaf_states'], kind='state')
+            _mjp_dense.get_expected_history_statistics_batch(cfg['T'], cfg['root'], cfg['nstates'], **kw)
+            best = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                _mjp_dense.get_expected_history_statistics_batch(cfg['T'], cfg['root'],
+                                                                 cfg['nstates'], **kw)
+                best = min(best, time.perf_counter() - t0)
+            out['expected_history_statistics_%s' % name] = dict(
+                sites=nsites, seconds_per_call=best, sites_per_s=nsites / best,
+                what='dwell times, root posteriors and transition counts summed over the batch, '
+                     'one host call (expm, passes, site sums, Frechet block exponentials)')
+        cfg = synth.make_config('c2', nsites=100000)
+        T, root, n = cfg['T'], cfg['root'], cfg['nstates']
+        index = _sampler.TreeArrays(T, root).node_to_index
+        masks = np.full((100000, len(index)), (1 << n) - 1, dtype=np.uint64)
+        masks[:, [index[v] for v in cfg['leaves']]] = \
+            np.uint64(1) << cfg['leaf_states'].astype(np.uint64)
+        batch = _sampler.DeviceHistoryBatch(T, root, cfg['Q_default'], node_masks=masks,
+                                            root_distn=cfg['root_distn'], seed=1, ctx=ctx)
+        batch.sweep(5)
+        ctx.sync()
+        t0 = time.perf_counter()
+        batch.sweep(20)
+        rows = batch.sizes()[0]
+        dt = (time.perf_counter() - t0) / 20
+        out['rao_teh_sweep_c2'] = dict(
+            chains=100000, ms_per_sweep=dt * 1e3, chain_sweeps_per_s=100000 / dt,
+            segments_per_chain=rows / 100000.0,
+            what='one Rao-Teh sweep of every chain, histories resident on the device')
+    except Exception as exc:                      # noqa: BLE001 -- a side measurement
+        out['error'] = repr(exc)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -489,6 +534,7 @@ def main():
                                 min(cpu_s, 8.0))
     if rank != 0:
         return
+    next_rows = measure_next_rows(ctx) if (world == 1 and also and not args.no_cpu_baseline) else None
 
     out = {
         'metric': 'site log-likelihoods/sec (batched tree pruning)',
@@ -513,6 +559,8 @@ def main():
     if head.get('speedup_vs_reference_faithful_cpu') is not None:
         out['speedup_vs_reference_faithful_cpu'] = head['speedup_vs_reference_faithful_cpu']
     out['workloads'] = extra
+    if next_rows is not None:
+        out['next_rows'] = next_rows
     print(json.dumps(out))
 
 
