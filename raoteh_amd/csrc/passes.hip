@@ -122,83 +122,6 @@ pmap_kernel(int nnodes, int n, long nsites, const long *__restrict__ idx,
     }
 }
 
-struct dev_tree {
-    long *idx = nullptr, *ptr = nullptr;
-    double *esd = nullptr;
-    ~dev_tree() { hipFree(idx); hipFree(ptr); hipFree(esd); }
-};
-
-int check_tree(int64_t nnodes, int64_t n, int64_t nsites, const int64_t *idx,
-               const int64_t *ptr, const double *esd)
-{
-    RT_REQUIRE(nnodes >= 1 && n >= 1 && nsites >= 0, "bad sizes");
-    RT_REQUIRE(n <= RT_MAX_STATES, "n=%lld > %d", (long long)n, RT_MAX_STATES);
-    RT_REQUIRE(ptr && esd && (idx || nnodes == 1), "null array");
-    RT_REQUIRE(ptr[0] == 0 && ptr[nnodes] == nnodes - 1,
-               "tree_csr_indptr does not describe a tree");
-    for (int64_t v = 0; v < nnodes; ++v) {
-        RT_REQUIRE(ptr[v + 1] >= ptr[v], "tree_csr_indptr not monotone");
-        for (int64_t e = ptr[v]; e < ptr[v + 1]; ++e)
-            RT_REQUIRE(idx[e] > v && idx[e] < nnodes,
-                       "child index %lld of node %lld is not in preorder",
-                       (long long)idx[e], (long long)v);
-    }
-    return RT_OK;
-}
-
-int upload_tree(rt_ctx *ctx, dev_tree &d, int64_t nnodes, int64_t n,
-                const int64_t *idx, const int64_t *ptr, const double *esd)
-{
-    const size_t ni = (size_t)(nnodes > 1 ? nnodes - 1 : 1);
-    RT_HIP(hipMalloc((void **)&d.idx, ni * 8));
-    RT_HIP(hipMalloc((void **)&d.ptr, (size_t)(nnodes + 1) * 8));
-    RT_HIP(hipMalloc((void **)&d.esd, (size_t)nnodes * n * n * 8));
-    if (nnodes > 1)
-        RT_HIP(hipMemcpyAsync(d.idx, idx, (size_t)(nnodes - 1) * 8,
-                              hipMemcpyHostToDevice, ctx->stream));
-    RT_HIP(hipMemcpyAsync(d.ptr, ptr, (size_t)(nnodes + 1) * 8, hipMemcpyHostToDevice,
-                          ctx->stream));
-    RT_HIP(hipMemcpyAsync(d.esd, esd, (size_t)nnodes * n * n * 8,
-                          hipMemcpyHostToDevice, ctx->stream));
-    return RT_OK;
-}
-
-int mask_pass(rt_ctx *ctx, bool forward, int64_t nnodes, int64_t n, int64_t nsites,
-              const int64_t *idx, const int64_t *ptr, const double *esd,
-              int64_t *state_mask)
-{
-    RT_REQUIRE(ctx, "null context");
-    RT_TRY(check_tree(nnodes, n, nsites, idx, ptr, esd));
-    RT_REQUIRE(state_mask || nsites == 0, "null state_mask");
-    if (nsites == 0) return RT_OK;
-    RT_HIP(hipSetDevice(ctx->device));
-    dev_tree d;
-    RT_TRY(upload_tree(ctx, d, nnodes, n, idx, ptr, esd));
-    const size_t bytes = (size_t)nsites * nnodes * n * 8;
-    long *dm = nullptr;
-    RT_HIP(hipMalloc((void **)&dm, bytes));
-    hipError_t e = hipMemcpyAsync(dm, state_mask, bytes, hipMemcpyHostToDevice,
-                                  ctx->stream);
-    if (e == hipSuccess) {
-        if (forward)
-            hipLaunchKernelGGL(set_kernel, dim3(pass_grid(nsites, n)), dim3(64), 0, ctx->stream, (int)nnodes, (int)n,
-                       (long)nsites, d.idx, d.ptr, d.esd, dm);
-        else
-            hipLaunchKernelGGL(pset_kernel, dim3(pass_grid(nsites, n)), dim3(64), 0, ctx->stream, (int)nnodes, (int)n,
-                       (long)nsites, d.idx, d.ptr, d.esd, dm);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(state_mask, dm, bytes, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    hipFree(dm);
-    if (e != hipSuccess) {
-        rt_set_error("mask pass failed: %s", hipGetErrorString(e));
-        return RT_ERR_HIP;
-    }
-    return RT_OK;
-}
-
 // bump allocation out of the context's grow-only scratch (valid until the next call)
 struct scratch_plan {
     size_t total = 0;
@@ -220,6 +143,89 @@ int scratch_reserve(rt_ctx *ctx, size_t bytes)
     const size_t want = std::max(bytes + bytes / 2, (size_t)1 << 20);
     RT_HIP(hipMalloc((void **)&ctx->d_scratch, want));
     ctx->scratch_bytes = want;
+    return RT_OK;
+}
+
+
+// the tree of a reference-format call, in the context's scratch (nothing to free: a
+// hipMalloc / hipFree pair per array was most of the 0.8-3.5 ms of a single-site call)
+struct dev_tree {
+    long *idx = nullptr, *ptr = nullptr;
+    double *esd = nullptr;
+    unsigned char *rest = nullptr;         // scratch behind the tree, `extra` bytes of it
+};
+
+int check_tree(int64_t nnodes, int64_t n, int64_t nsites, const int64_t *idx,
+               const int64_t *ptr, const double *esd)
+{
+    RT_REQUIRE(nnodes >= 1 && n >= 1 && nsites >= 0, "bad sizes");
+    RT_REQUIRE(n <= RT_MAX_STATES, "n=%lld > %d", (long long)n, RT_MAX_STATES);
+    RT_REQUIRE(ptr && esd && (idx || nnodes == 1), "null array");
+    RT_REQUIRE(ptr[0] == 0 && ptr[nnodes] == nnodes - 1,
+               "tree_csr_indptr does not describe a tree");
+    for (int64_t v = 0; v < nnodes; ++v) {
+        RT_REQUIRE(ptr[v + 1] >= ptr[v], "tree_csr_indptr not monotone");
+        for (int64_t e = ptr[v]; e < ptr[v + 1]; ++e)
+            RT_REQUIRE(idx[e] > v && idx[e] < nnodes,
+                       "child index %lld of node %lld is not in preorder",
+                       (long long)idx[e], (long long)v);
+    }
+    return RT_OK;
+}
+
+int upload_tree(rt_ctx *ctx, dev_tree &d, int64_t nnodes, int64_t n,
+                const int64_t *idx, const int64_t *ptr, const double *esd, size_t extra = 0)
+{
+    const size_t ni = (size_t)(nnodes > 1 ? nnodes - 1 : 1);
+    scratch_plan plan;
+    const size_t o_idx = plan.take(ni * 8), o_ptr = plan.take((size_t)(nnodes + 1) * 8);
+    const size_t o_esd = plan.take((size_t)nnodes * n * n * 8), o_rest = plan.take(extra);
+    RT_TRY(scratch_reserve(ctx, plan.total));
+    d.idx = (long *)(ctx->d_scratch + o_idx);
+    d.ptr = (long *)(ctx->d_scratch + o_ptr);
+    d.esd = (double *)(ctx->d_scratch + o_esd);
+    d.rest = ctx->d_scratch + o_rest;
+    if (nnodes > 1)
+        RT_HIP(hipMemcpyAsync(d.idx, idx, (size_t)(nnodes - 1) * 8,
+                              hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(hipMemcpyAsync(d.ptr, ptr, (size_t)(nnodes + 1) * 8, hipMemcpyHostToDevice,
+                          ctx->stream));
+    RT_HIP(hipMemcpyAsync(d.esd, esd, (size_t)nnodes * n * n * 8,
+                          hipMemcpyHostToDevice, ctx->stream));
+    return RT_OK;
+}
+
+int mask_pass(rt_ctx *ctx, bool forward, int64_t nnodes, int64_t n, int64_t nsites,
+              const int64_t *idx, const int64_t *ptr, const double *esd,
+              int64_t *state_mask)
+{
+    RT_REQUIRE(ctx, "null context");
+    RT_TRY(check_tree(nnodes, n, nsites, idx, ptr, esd));
+    RT_REQUIRE(state_mask || nsites == 0, "null state_mask");
+    if (nsites == 0) return RT_OK;
+    RT_HIP(hipSetDevice(ctx->device));
+    dev_tree d;
+    const size_t bytes = (size_t)nsites * nnodes * n * 8;
+    RT_TRY(upload_tree(ctx, d, nnodes, n, idx, ptr, esd, bytes));
+    long *dm = (long *)d.rest;
+    hipError_t e = hipMemcpyAsync(dm, state_mask, bytes, hipMemcpyHostToDevice,
+                                  ctx->stream);
+    if (e == hipSuccess) {
+        if (forward)
+            hipLaunchKernelGGL(set_kernel, dim3(pass_grid(nsites, n)), dim3(64), 0, ctx->stream, (int)nnodes, (int)n,
+                       (long)nsites, d.idx, d.ptr, d.esd, dm);
+        else
+            hipLaunchKernelGGL(pset_kernel, dim3(pass_grid(nsites, n)), dim3(64), 0, ctx->stream, (int)nnodes, (int)n,
+                       (long)nsites, d.idx, d.ptr, d.esd, dm);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(state_mask, dm, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        rt_set_error("mask pass failed: %s", hipGetErrorString(e));
+        return RT_ERR_HIP;
+    }
     return RT_OK;
 }
 
@@ -299,15 +305,13 @@ extern "C" int rt_mcy_esd_get_node_to_pmap(rt_ctx *ctx, int64_t nnodes, int64_t 
     if (nsites == 0) return RT_OK;
     RT_HIP(hipSetDevice(ctx->device));
     dev_tree d;
-    RT_TRY(upload_tree(ctx, d, nnodes, n, idx, ptr, esd));
     const size_t bytes = (size_t)nsites * nnodes * n * 8;
-    long *dm = nullptr;
-    double *dobs = nullptr, *dout = nullptr;
-    hipError_t e = hipMalloc((void **)&dm, bytes);
-    if (e == hipSuccess) e = hipMalloc((void **)&dout, bytes);
-    if (e == hipSuccess && obs_likelihood) e = hipMalloc((void **)&dobs, bytes);
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(dm, state_mask, bytes, hipMemcpyHostToDevice, ctx->stream);
+    const size_t slot = (bytes + 255) & ~(size_t)255;
+    RT_TRY(upload_tree(ctx, d, nnodes, n, idx, ptr, esd, 3 * slot));
+    long *dm = (long *)d.rest;
+    double *dout = (double *)(d.rest + slot);
+    double *dobs = obs_likelihood ? (double *)(d.rest + 2 * slot) : nullptr;
+    hipError_t e = hipMemcpyAsync(dm, state_mask, bytes, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && obs_likelihood)
         e = hipMemcpyAsync(dobs, obs_likelihood, bytes, hipMemcpyHostToDevice,
                            ctx->stream);
@@ -320,9 +324,6 @@ extern "C" int rt_mcy_esd_get_node_to_pmap(rt_ctx *ctx, int64_t nnodes, int64_t 
         e = hipMemcpyAsync(subtree_probability, dout, bytes, hipMemcpyDeviceToHost,
                            ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    hipFree(dm);
-    hipFree(dout);
-    hipFree(dobs);
     if (e != hipSuccess) {
         rt_set_error("pmap pass failed: %s", hipGetErrorString(e));
         return RT_ERR_HIP;
@@ -431,16 +432,17 @@ int distn_pass(rt_ctx *ctx, bool joint, int64_t nnodes, int64_t n, int64_t nsite
     if (nsites == 0) return RT_OK;
     RT_HIP(hipSetDevice(ctx->device));
     dev_tree d;
-    RT_TRY(upload_tree(ctx, d, nnodes, n, idx, ptr, esd));
     const size_t bytes = (size_t)nsites * nnodes * n * 8;
-    double *dp = nullptr, *dd = nullptr, *dj = nullptr, *dr = nullptr;
-    int *ds = nullptr;
-    hipError_t e = hipMalloc((void **)&dp, bytes);
-    if (e == hipSuccess) e = hipMalloc((void **)&dd, bytes);
-    if (e == hipSuccess && joint) e = hipMalloc((void **)&dj, bytes * n);
-    if (e == hipSuccess && root_distn) e = hipMalloc((void **)&dr, n * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&ds, nsites * 4);
-    if (e == hipSuccess) e = hipMemcpyAsync(dp, pmap, bytes, hipMemcpyHostToDevice, ctx->stream);
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_p = 0, o_d = o_p + up(bytes), o_j = o_d + up(bytes),
+                 o_r = o_j + (joint ? up(bytes * n) : 0), o_s = o_r + up((size_t)n * 8),
+                 extra = o_s + up((size_t)nsites * 4);
+    RT_TRY(upload_tree(ctx, d, nnodes, n, idx, ptr, esd, extra));
+    double *dp = (double *)(d.rest + o_p), *dd = (double *)(d.rest + o_d);
+    double *dj = joint ? (double *)(d.rest + o_j) : nullptr;
+    double *dr = root_distn ? (double *)(d.rest + o_r) : nullptr;
+    int *ds = (int *)(d.rest + o_s);
+    hipError_t e = hipMemcpyAsync(dp, pmap, bytes, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && joint)
         e = hipMemcpyAsync(dd, distn, bytes, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && root_distn)
@@ -463,7 +465,6 @@ int distn_pass(rt_ctx *ctx, bool joint, int64_t nnodes, int64_t n, int64_t nsite
     if (e == hipSuccess && status)
         e = hipMemcpyAsync(status, ds, nsites * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    hipFree(dp); hipFree(dd); hipFree(dj); hipFree(dr); hipFree(ds);
     if (e != hipSuccess) {
         rt_set_error("distn pass failed: %s", hipGetErrorString(e));
         return RT_ERR_HIP;
