@@ -491,7 +491,9 @@ def main():
     from raoteh_amd import device, _lib     # fails loudly without the .so
     from raoteh_amd.dist import SocketControl, init_rccl
     ctl = SocketControl(rank, world)
-    ctx = device.Context(local_rank)
+    # RAOTEH_BENCH_ONE_DEVICE=1: every rank on device 0 -- a rehearsal of the N > 1 control flow on
+    # a one-GPU box (RCCL refuses two ranks on one device: the host-socket reduce then runs)
+    ctx = device.Context(0 if os.environ.get('RAOTEH_BENCH_ONE_DEVICE') else local_rank)
 
     if args.also is None:
         also = [w for w in ('c2', 'c5', 'c4') if w != args.workload]
