@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import atexit
 import ctypes
+import weakref
 from ctypes import byref, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p
 
 import numpy as np
@@ -360,6 +361,10 @@ class SiteBatch(object):
         self.model = model
         self._h = handle
         self.nsites = nsites
+        # the C object refers to its model: when both die in one garbage-collection cycle
+        # (a traceback kept them alive) the model may be finalised first, so the model closes
+        # its batches before it goes
+        model._batches.add(self)
 
     def clone(self):
         h = c_void_p()
@@ -400,12 +405,15 @@ class TreeModel(object):
         self.tree = T if isinstance(T, TreeArrays) else TreeArrays(T, root)
         self.nstates = int(nstates)
         self._h = c_void_p()
+        self._batches = weakref.WeakSet()
         ta = self.tree
         _lib.check(_lib.lib().rt_model_create(
             self.ctx._h, ta.nnodes, self.nstates, _ptr(ta.indices, c_int64),
             _ptr(ta.indptr, c_int64), byref(self._h)))
 
     def close(self):
+        for batch in list(getattr(self, '_batches', ())):
+            batch.close()
         if self._h and not _shutting_down:
             _lib.lib().rt_model_destroy(self._h)
             self._h = c_void_p()
