@@ -641,7 +641,7 @@ extern "C" int rt_sites_destroy(rt_sites *s)
     if (s->jit_fn2) rt_jit_ref(s->model->ctx, s->jit_fn2, -1);
     hipFree(s->d_ops); hipFree(s->d_lane_ops); hipFree(s->d_obs); hipFree(s->d_loglik); hipFree(s->d_status);
     if (s->model->ctx->comm_stream) hipStreamSynchronize(s->model->ctx->comm_stream);
-    hipFree(s->d_partial); hipFree(s->d_scratch);
+    hipFree(s->d_partial); hipFree(s->d_scratch); hipFree(s->d_half);
     if (s->totals_slot >= 0) {
         // keep the free list sorted (descending) so that batches created one after
         // the other keep getting neighbouring slots
@@ -792,6 +792,8 @@ static int sites_alloc(rt_sites *s, bool generic)
         s->scratch_bytes = std::max<int64_t>(1, m->max_depth) * n * padded * 8;
         e = hipMalloc((void **)&s->d_scratch, s->scratch_bytes);
     }
+    if (e == hipSuccess && s->jit_halves)      // [tile][half][k-step][lane] (jit.hip)
+        e = hipMalloc((void **)&s->d_half, (size_t)s->nblocks * 2 * ((n + 15) / 16) * 4 * 64 * 8);
     if (e == hipSuccess)
         e = hipMemcpy(s->d_ops, s->ops.data(), s->ops.size() * sizeof(rt_op),
                       hipMemcpyHostToDevice);
@@ -826,17 +828,46 @@ static int sites_alloc(rt_sites *s, bool generic)
 // interpreter kernels only, or exactly the tree-specialised kernel of another batch
 // (the probe batches of verify_jit_kernel).
 // the split-M generator in use: pipelined unless RAOTEH_JIT_SPLIT=serial (A/B runs)
-static std::string split_source(const std::vector<rt_op> &ops, int n, int K, int T, int D, int LA)
+static std::string split_source(const std::vector<rt_op> &ops, int n, int K, int T, int D, int LA,
+                                bool halves = false)
 {
     const char *v = getenv("RAOTEH_JIT_SPLIT");
-    if (v && strcmp(v, "serial") == 0) return rt_jit_mfma_split_source(ops, n, K, T, D, LA);
-    return rt_jit_mfma_split_pipelined_source(ops, n, K, T, D, LA);
+    if (v && strcmp(v, "serial") == 0 && !halves) return rt_jit_mfma_split_source(ops, n, K, T, D, LA);
+    return rt_jit_mfma_split_pipelined_source(ops, n, K, T, D, LA, halves);
+}
+
+// Root halves (jit.hip) for a split-M batch of `ntiles` tiles at one tile per workgroup:
+// a workgroup's time is its chain on the matrix pipe, a CU runs three at a time and the
+// kernel ends with the busiest CU, so what counts is ceil(tiles / CUs) against
+// ceil(2 tiles / CUs) / 2.  Worth it when that is >= 7 % less (the second kernel and the
+// half buffer cost a few us) and the two programs are of comparable length (the longer
+// one bounds the gain).  RAOTEH_JIT_HALVES=0 / 1 overrides.
+static bool want_root_halves(const rt_sites *s, int64_t ntiles)
+{
+    int a = 0, b = 0;
+    rt_jit_root_halves(s->ops, &a, &b);
+    if (a == 0 || b == 0) return false;
+    if (const char *v = getenv("RAOTEH_JIT_HALVES")) return atoi(v) != 0;
+    const double cus = std::max(1, s->model->ctx->num_cus);
+    const double whole = std::ceil((double)ntiles / cus) * (a + b);
+    // 2 ntiles workgroups, alternating A / B: a CU's share in the worst case
+    const double halves = std::ceil(2.0 * (double)ntiles / cus) * 0.5 * 2.0 * std::max(a, b);
+    return halves <= 0.93 * whole;
+}
+
+// the halves form's second kernel
+static int sites_halves_setup(rt_sites *s)
+{
+    RT_TRY(rt_jit_companion(s->model->ctx, s->jit_fn, "rt_jit_combine", &s->jit_combine));
+    s->jit_halves = true;          // sites_alloc allocates d_half
+    return RT_OK;
 }
 
 struct jit_override {
     int mode = 0;             // 0 automatic, 1 interpreter only, 2 exactly these parameters
     int T = 1, S = 64, WG = 1, D = 1, LA = 1, compact = 0;
     bool quad = false;
+    bool halves = false;      // split-M family: the two root programs as separate workgroups
     bool no_solo = false;     // n <= 32: the split-M interpreter kernel, not the one-wave one
 };
 
@@ -849,9 +880,10 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
         const bool split = mfma && (n > 32 || !s->mfma_solo);
         const std::string src =
             !mfma ? rt_jit_lane_source(s->ops, n, K, ov->D, ov->LA, ov->S, ov->WG, ov->compact)
-            : split ? split_source(s->ops, n, K, ov->T, ov->D, ov->LA)
+            : split ? split_source(s->ops, n, K, ov->T, ov->D, ov->LA, ov->halves)
                     : rt_jit_mfma_source(s->ops, n, K, ov->T, ov->D, ov->LA, ov->quad);
         RT_TRY(rt_jit_get(s->model->ctx, src, &s->jit_fn, mfma));
+        if (split && ov->halves) RT_TRY(sites_halves_setup(s));
         s->jit_quad = mfma && !split && ov->quad;
         s->jit_prefetch = ov->D;
         s->jit_lookahead = ov->LA;
@@ -899,10 +931,15 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
             s->jit_prefetch = D;
             s->jit_lookahead = LA;
             int rc = RT_ERR_UNSUPPORTED;
+            bool halves = T == 1 && want_root_halves(s, ntiles);
             for (; T >= 1 && rc == RT_ERR_UNSUPPORTED; --T) {     // fewer tiles if it spills
                 const std::string src =
-                    split_source(s->ops, (int)s->model->n, (int)s->nobs, T, D, LA);
+                    split_source(s->ops, (int)s->model->n, (int)s->nobs, T, D, LA, halves);
                 rc = rt_jit_get(s->model->ctx, src, &s->jit_fn, true, &s->jit_compile_s);
+                if (rc == RT_ERR_UNSUPPORTED && halves) {          // then the whole-tree form
+                    halves = false;
+                    ++T;
+                }
             }
             ++T;
             if (rc != RT_OK && (!forced || rc == RT_ERR_UNSUPPORTED)) {
@@ -912,6 +949,7 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
             if (rc == RT_OK) {
                 s->jit_tiles = T;
                 s->jit_waves = (int)((s->model->n + 15) / 16);
+                if (halves) rc = sites_halves_setup(s);
             }
             return rc;
         }
@@ -1088,8 +1126,8 @@ extern "C" int rt_jit_source(int64_t nnodes, const int64_t *idx, const int64_t *
                              getenv("RAOTEH_JIT_SOURCE_STATES") != nullptr)
         : n <= 32 ? rt_jit_mfma_source(m.ops, (int)n, (int)nobs, T, (int)prefetch, 1,
                                        !(getenv("RAOTEH_JIT_QUAD") && atoi(getenv("RAOTEH_JIT_QUAD")) == 0))
-                  : split_source(m.ops, (int)n, (int)nobs, std::min(T, 3),
-                                             (int)prefetch, 1);
+                  : split_source(m.ops, (int)n, (int)nobs, std::min(T, 3), (int)prefetch, 1,
+                                 getenv("RAOTEH_JIT_HALVES") && atoi(getenv("RAOTEH_JIT_HALVES")));
     RT_REQUIRE((int64_t)src.size() + 1 <= capacity, "buffer too small: %lld bytes needed",
                (long long)src.size() + 1);
     memcpy(buf, src.c_str(), src.size() + 1);
@@ -1196,6 +1234,8 @@ static int sites_create_impl(rt_model *m, int64_t nsites, int kind, int64_t nobs
             s->jit_tiles = 1;
             s->compact_states = 0;
             s->jit_quad = false;
+            s->jit_halves = false;
+            s->jit_combine = nullptr;
         }
     }
     if (rc == RT_OK) rc = sites_alloc(s, generic);
@@ -1301,6 +1341,7 @@ static int verify_jit_kernel(rt_sites *s, int kind)
     same.LA = s->jit_lookahead;
     same.compact = s->compact_states;
     same.quad = s->jit_quad;
+    same.halves = s->jit_halves;
     if (rc == RT_OK)
         rc = sites_create_impl(tm, np, pkind, K, obs_nodes.data(), data, &interp, &si);
     if (rc == RT_OK)
@@ -1361,6 +1402,8 @@ extern "C" int rt_sites_clone(rt_sites *src, rt_sites **out)
     s->jit_waves = src->jit_waves;
     s->jit_tiles = src->jit_tiles;
     s->jit_quad = src->jit_quad;
+    s->jit_halves = src->jit_halves;
+    s->jit_combine = src->jit_combine;
     s->compact_states = src->compact_states;
     s->node_obs = src->node_obs;
     s->ops = src->ops;

@@ -188,6 +188,12 @@ struct rt_sites {
     int jit_tiles2 = 1;
     int64_t jit_split_tiles = 0;
     bool jit_quad = false;          // ... built on v_mfma_f64_4x4x4_4b (reads d_Pquad)
+    // split-M family, root halves (jit.hip): the two root programs run as the even / odd
+    // workgroups of jit_fn and leave their share of the root's accumulator in d_half
+    // ([tile][half][k-step][lane]); jit_combine (same module) finishes the sites
+    bool jit_halves = false;
+    void *jit_combine = nullptr;
+    double *d_half = nullptr;
     // not owned: where the split-M interpreter kernel leaves L_v and M_v of every step
     // (expect_mfma.hip sets them around its own launch)
     double *d_Lout = nullptr, *d_Mout = nullptr;
@@ -241,7 +247,11 @@ std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int 
 std::string rt_jit_mfma_split_source(const std::vector<rt_op> &ops, int n, int K, int T, int D,
                                      int LA);
 std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, int n, int K, int T,
-                                               int D, int LA);
+                                               int D, int LA, bool halves = false);
+// steps of the two root programs the halves form would run (0, 0: the root has < 2 children)
+void rt_jit_root_halves(const std::vector<rt_op> &ops, int *stepsA, int *stepsB);
+// another kernel of the module `fn` came from (the halves form's rt_jit_combine)
+int rt_jit_companion(const rt_ctx *ctx, void *fn, const char *name, void **out);
 int rt_jit_get(rt_ctx *ctx, const std::string &src, void **fn, bool mfma = false,
                double *compile_s = nullptr);
 void rt_jit_ref(const rt_ctx *ctx, void *fn, int delta);

@@ -1270,10 +1270,66 @@ std::vector<pipe_step> pipeline_order(const std::vector<rt_op> &ops, int *nslots
     return out;
 }
 
+// The schedule cut at the root into two programs that run as separate workgroups:
+// A = the subtrees of all children of the root but the last, B = the subtree of the last
+// child, each followed by the root's step.  The root's accumulator is folded in child
+// order, ((c1 * c2) ...) * ck, so (product of A's children) * (B's child) is the
+// interpreter's product bit for bit.  False: the root has fewer than two children.
+bool split_at_root(const std::vector<rt_op> &ops, std::vector<rt_op> *A, std::vector<rt_op> *B)
+{
+    const int nrec = (int)ops.size();
+    if (nrec < 3 || ops[(size_t)nrec - 1].dst >= 0 || ops[(size_t)nrec - 1].pop < 0) return false;
+    std::vector<int> parent((size_t)nrec, -1);
+    {
+        std::vector<std::vector<int>> pending(256);
+        for (int i = 0; i < nrec; ++i) {
+            const rt_op &op = ops[(size_t)i];
+            if (op.pop >= 0) {
+                for (int c : pending[(size_t)op.pop]) parent[(size_t)c] = i;
+                pending[(size_t)op.pop].clear();
+            }
+            if (op.dst >= 0) pending[(size_t)(op.dst & 255)].push_back(i);
+        }
+    }
+    int last_child = -1, nchildren = 0;
+    for (int i = 0; i < nrec - 1; ++i)
+        if (parent[(size_t)i] == nrec - 1) { last_child = i; ++nchildren; }
+    if (nchildren < 2) return false;
+    A->clear();
+    B->clear();
+    for (int i = 0; i < nrec - 1; ++i) {
+        int top = i;
+        while (parent[(size_t)top] != nrec - 1) {
+            if (parent[(size_t)top] < 0) return false;      // not a tree below the root
+            top = parent[(size_t)top];
+        }
+        (top == last_child ? B : A)->push_back(ops[(size_t)i]);
+    }
+    A->push_back(ops[(size_t)nrec - 1]);
+    B->push_back(ops[(size_t)nrec - 1]);
+    return true;
+}
+
 }  // namespace
 
+// work of the two root programs as steps (A, B); (0, 0) when the schedule cannot be cut
+void rt_jit_root_halves(const std::vector<rt_op> &ops, int *stepsA, int *stepsB)
+{
+    std::vector<rt_op> A, B;
+    *stepsA = *stepsB = 0;
+    if (!split_at_root(ops, &A, &B)) return;
+    *stepsA = (int)A.size() - 1;
+    *stepsB = (int)B.size() - 1;
+}
+
+// halves: the two root programs of split_at_root as the even / odd workgroups of one
+// launch (T = 1): twice as many workgroups of half the length, so that a batch of a few
+// tiles per CU spreads evenly (625 tiles on 256 CUs: three on the busiest CU and 2.44 on
+// average; 1 250 half-tiles: 5 halves = 2.5).  Each writes its root accumulator (own
+// rows) to halfbuf[tile][half][k-step][lane]; the module's second kernel, rt_jit_combine,
+// multiplies the two and runs the root step and the site epilogue unchanged.
 std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, int n, int K, int T,
-                                               int D, int LA)
+                                               int D, int LA, bool halves)
 {
     (void)LA;
     // x of a step is published one step early, so its leaf vector must be in registers a
@@ -1284,15 +1340,29 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
     const int KP = (KS + 1) / 2;
     const int XT = NT * 4 * 64;               // doubles of one tile's x image
     int nslots = 1;
-    const std::vector<pipe_step> st = pipeline_order(ops, &nslots);
-    const int nrec = (int)st.size();
-    int nlate = 0;
-    for (const pipe_step &p : st) nlate += p.late;
+    std::vector<std::vector<pipe_step>> programs;
+    if (halves) {
+        std::vector<rt_op> opsA, opsB;
+        if (T != 1 || !split_at_root(ops, &opsA, &opsB)) return std::string();
+        int sa = 1, sb = 1;
+        programs.push_back(pipeline_order(opsA, &sa));
+        programs.push_back(pipeline_order(opsB, &sb));
+        nslots = std::max(sa, sb);
+    } else {
+        programs.push_back(pipeline_order(ops, &nslots));
+    }
+    int nrec_max = 0, nrec_all = 0, nlate = 0;
+    for (const auto &pr : programs) {
+        nrec_max = std::max(nrec_max, (int)pr.size());
+        nrec_all += (int)pr.size();
+        for (const pipe_step &p : pr) nlate += p.late;
+    }
     // a slot popped by step i is read when x(i) is published, which may be one step
     // earlier than in program order of the folds: the deferred fold of step i-1 never
     // targets it (that would make step i late)
     std::ostringstream o;
-    o << "// generated by raoteh_amd/csrc/jit.hip (split-M MFMA family, pipelined): " << nrec
+    o << "// generated by raoteh_amd/csrc/jit.hip (split-M MFMA family, pipelined"
+      << (halves ? ", root halves" : "") << "): " << nrec_all
       << " steps (" << nlate << " serial), " << n << " states, " << K << " observed nodes, " << T
       << " tiles per workgroup of " << NT << " waves, " << nslots << " accumulator slots, prefetch "
       << D << " leaves\n";
@@ -1301,10 +1371,10 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
     const char *trace_env = getenv("RAOTEH_JIT_TRACE");
     const bool trace = trace_env != nullptr;
     const long trace_wg = trace ? atol(trace_env) : 0;
-    if (trace) o << "__device__ unsigned long long rt_trace[" << NT * (nrec + 1) * 3 << "];\n";
+    if (trace) o << "__device__ unsigned long long rt_trace[" << NT * (nrec_max + 1) * 3 << "];\n";
     auto stamp = [&](int i, int which) {
         if (!trace) return;
-        o << "    if (blockIdx.x == " << trace_wg << " && lane == 0) rt_trace[(m * " << (nrec + 1)
+        o << "    if (blockIdx.x == " << trace_wg << " && lane == 0) rt_trace[(m * " << (nrec_max + 1)
           << " + " << i << ") * 3 + " << which << "] = __builtin_readcyclecounter();\n";
     };
     o << "extern \"C\" __global__ void __launch_bounds__(" << 64 * NT
@@ -1313,7 +1383,8 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
          "rt_jit_prune(const double *__restrict__ Pfrag, const rt_d2 *__restrict__ obs,\n"
          "             const double *__restrict__ root_w, double *__restrict__ loglik,\n"
          "             int *__restrict__ status, double *__restrict__ partial,\n"
-         "             long nsites, long nblocks)\n{\n";
+         "             long nsites, long nblocks"
+      << (halves ? ", double *__restrict__ halfbuf" : "") << ")\n{\n";
     // two OBJECTS, not one array of two: step i reads xb<i & 1> while x of step i + 1 is
     // written to the other one, and only for distinct objects does the compiler know that
     // an LDS read may be hoisted above an earlier LDS write (with one array every read of
@@ -1327,7 +1398,12 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
     o << "    __shared__ double red[" << T << "][" << NT << "][16];\n";
     o << "    const int lane = threadIdx.x & 63;\n";
     o << "    const int m = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // row tile of this wave\n";
-    o << "    const long tbase = (long)blockIdx.x * " << T << ";\n";
+    if (halves) {
+        o << "    const long tbase = (long)(blockIdx.x >> 1);\n";
+        o << "    const int half = (int)(blockIdx.x & 1);      // which root program\n";
+    } else {
+        o << "    const long tbase = (long)blockIdx.x * " << T << ";\n";
+    }
     o << "    typedef const __attribute__((address_space(1))) rt_d2 *rt_glb2;\n";
     o << "    rt_glb2 ag = (rt_glb2)Pfrag + (m * " << KP * 64 << " + lane);   // [step][m][k-pair][lane][2]\n";
     o << "    const bool pair1 = 2 * m + 1 < " << KP << ";\n";
@@ -1345,6 +1421,69 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
                 o << "    double a" << sl << "_" << t << "_" << r << " = 1.0;\n";
     }
     o << "    const rt_d2 zero2 = {0.0, 0.0};\n";
+    // the root step: x of the root -> weighted sum over the states (_mc0_dense.py:184-209,
+    // as prune_mfma_kernel); xp = name prefix of the root's x values (xp_<tile>_<row>)
+    auto emit_root_reduce = [&](std::ostream &os, const std::string &xp) {
+        for (int r = 0; r < 4; ++r)
+            os << "    const double w" << r << " = rowok" << r << " ? root_w[16 * m + " << 4 * r
+               << " + (lane >> 4)] : 0.0;\n";
+        for (int t = 0; t < T; ++t) {
+            os << "    {\n    double sacc = 0.0;\n";
+            for (int r = 0; r < 4; ++r) {
+                os << "    negative" << t << " |= rowok" << r << " && (" << xp << "_" << t << "_" << r
+                   << " < 0.0);\n";
+                os << "    sacc += w" << r << " * fmax(" << xp << "_" << t << "_" << r << ", 0.0);\n";
+            }
+            os << "    sacc += __shfl_xor(sacc, 16, 64);\n"
+                  "    sacc += __shfl_xor(sacc, 32, 64);\n"
+                  "    if (lane < 16) red[" << t << "][m][lane] = sacc;\n    }\n";
+        }
+        os << "    __syncthreads();\n";
+        for (int t = 0; t < T; ++t) {
+            os << "    if (m == 0 && lane < 16) {\n        double tot = 0.0;\n";
+            for (int mm = 0; mm < NT; ++mm)
+                os << "        tot += red[" << t << "][" << mm << "][lane];\n";
+            os << "        lik" << t << " = tot;\n    }\n";
+        }
+    };
+    // lanes 0..15 of wave 0 own the 16 sites of a tile
+    auto emit_site_epilogue = [&](std::ostream &os) {
+        for (int t = 0; t < T; ++t) {
+            os << "    {\n"
+                  "    const long site = tile" << t << " * 16 + (lane & 15);\n"
+                  "    const bool ok = lik" << t << " > 0.0;\n"
+                  "    double sum = 0.0, nzero = 0.0;\n"
+                  "    if (m == 0 && lane < 16 && tile" << t << " < nblocks && site < nsites) {\n"
+                  "        loglik[site] = ok ? log(lik" << t << ") : -__builtin_inf();\n"
+                  "        status[site] = (ok ? " << RT_SITE_OK << " : " << RT_SITE_ZERO_PROB
+               << ") | (negative" << t << " ? " << RT_SITE_NEGATIVE << " : 0);\n"
+                  "        sum = ok ? log(lik" << t << ") : 0.0;\n"
+                  "        nzero = ok ? 0.0 : 1.0;\n"
+                  "    }\n"
+                  "    for (int off = 32; off > 0; off >>= 1) {\n"
+                  "        sum += __shfl_xor(sum, off, 64);\n"
+                  "        nzero += __shfl_xor(nzero, off, 64);\n"
+                  "    }\n"
+                  "    if (m == 0 && lane == 0 && tile" << t << " < nblocks) {\n"
+                  "        partial[tile" << t << " * 2] = sum;\n"
+                  "        partial[tile" << t << " * 2 + 1] = nzero;\n"
+                  "    }\n"
+                  "    }\n";
+        }
+    };
+    // the P record of a step is addressed by the step's position in the ORIGINAL schedule
+    // (Pfrag is written in that order): recover it from the node
+    std::vector<int> rec_of_node;
+    {
+        int maxnode = 0;
+        for (const rt_op &op : ops) maxnode = std::max(maxnode, (int)op.node);
+        rec_of_node.assign((size_t)maxnode + 1, -1);
+        for (size_t i = 0; i < ops.size(); ++i) rec_of_node[(size_t)ops[i].node] = (int)i;
+    }
+    for (size_t prog = 0; prog < programs.size(); ++prog) {
+    const std::vector<pipe_step> &st = programs[prog];
+    const int nrec = (int)st.size();
+    if (halves) o << (prog == 0 ? "    if (half == 0) {\n" : "    } else {\n");
     // observation stream positions in ISSUE order (the batch was packed in post-order
     // stream order: position = op.obs)
     std::vector<int> obs_order;
@@ -1360,15 +1499,6 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
                << t << "[" << ((long)pos * KP + 1) * 64 << "]) : zero2;\n";
         }
     };
-    // the P record of a step is addressed by the step's position in the ORIGINAL schedule
-    // (Pfrag is written in that order): recover it from the node
-    std::vector<int> rec_of_node;
-    {
-        int maxnode = 0;
-        for (const rt_op &op : ops) maxnode = std::max(maxnode, (int)op.node);
-        rec_of_node.assign((size_t)maxnode + 1, -1);
-        for (size_t i = 0; i < ops.size(); ++i) rec_of_node[(size_t)ops[i].node] = (int)i;
-    }
     auto emit_a_load = [&](std::ostream &os, int k) {           // k = issue index
         const int rec = rec_of_node[(size_t)st[(size_t)k].op.node];
         for (int q = 0; q < KP; ++q) {
@@ -1441,28 +1571,17 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
         if (op.dst < 0) {
             // root: everything folded, reduce (_mc0_dense.py:184-209), as prune_mfma_kernel
             if (fold_pending) { emit_fold(o, i - 1); fold_pending = false; }
+            if (halves) {
+                // this program's share of the root's accumulator (own rows) -> halfbuf
+                o << "    {\n    double *hb = halfbuf + ((size_t)tbase * 2 + " << prog << ") * " << XT
+                  << " + (4 * m) * 64 + lane;\n";
+                for (int r = 0; r < 4; ++r)
+                    o << "    hb[" << r * 64 << "] = a" << op.pop << "_0_" << r << ";\n";
+                o << "    }\n";
+                continue;
+            }
             emit_x(o, i);
-            for (int r = 0; r < 4; ++r)
-                o << "    const double w" << r << " = rowok" << r << " ? root_w[16 * m + " << 4 * r
-                  << " + (lane >> 4)] : 0.0;\n";
-            for (int t = 0; t < T; ++t) {
-                o << "    {\n    double sacc = 0.0;\n";
-                for (int r = 0; r < 4; ++r) {
-                    o << "    negative" << t << " |= rowok" << r << " && (x" << i << "_" << t << "_" << r
-                      << " < 0.0);\n";
-                    o << "    sacc += w" << r << " * fmax(x" << i << "_" << t << "_" << r << ", 0.0);\n";
-                }
-                o << "    sacc += __shfl_xor(sacc, 16, 64);\n"
-                     "    sacc += __shfl_xor(sacc, 32, 64);\n"
-                     "    if (lane < 16) red[" << t << "][m][lane] = sacc;\n    }\n";
-            }
-            o << "    __syncthreads();\n";
-            for (int t = 0; t < T; ++t) {
-                o << "    if (m == 0 && lane < 16) {\n        double tot = 0.0;\n";
-                for (int mm = 0; mm < NT; ++mm)
-                    o << "        tot += red[" << t << "][" << mm << "][lane];\n";
-                o << "        lik" << t << " = tot;\n    }\n";
-            }
+            emit_root_reduce(o, "x" + std::to_string(i));
             continue;
         }
         dep = "c" + std::to_string(i) + "_0[0]";
@@ -1549,30 +1668,44 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
         prefetched = early_barrier;
     }
     stamp(nrec, 0);
-
-    // lanes 0..15 of wave 0 own the 16 sites of a tile
-    for (int t = 0; t < T; ++t) {
-        o << "    {\n"
-             "    const long site = tile" << t << " * 16 + (lane & 15);\n"
-             "    const bool ok = lik" << t << " > 0.0;\n"
-             "    double sum = 0.0, nzero = 0.0;\n"
-             "    if (m == 0 && lane < 16 && tile" << t << " < nblocks && site < nsites) {\n"
-             "        loglik[site] = ok ? log(lik" << t << ") : -__builtin_inf();\n"
-             "        status[site] = (ok ? " << RT_SITE_OK << " : " << RT_SITE_ZERO_PROB
-          << ") | (negative" << t << " ? " << RT_SITE_NEGATIVE << " : 0);\n"
-             "        sum = ok ? log(lik" << t << ") : 0.0;\n"
-             "        nzero = ok ? 0.0 : 1.0;\n"
-             "    }\n"
-             "    for (int off = 32; off > 0; off >>= 1) {\n"
-             "        sum += __shfl_xor(sum, off, 64);\n"
-             "        nzero += __shfl_xor(nzero, off, 64);\n"
-             "    }\n"
-             "    if (m == 0 && lane == 0 && tile" << t << " < nblocks) {\n"
-             "        partial[tile" << t << " * 2] = sum;\n"
-             "        partial[tile" << t << " * 2 + 1] = nzero;\n"
-             "    }\n"
-             "    }\n";
+    }   // programs
+    if (halves) {
+        o << "    }\n}\n";
+        // ---- second kernel of the module: root step + site epilogue from the two halves
+        const rt_op &root = ops.back();
+        o << "extern \"C\" __global__ void __launch_bounds__(" << 64 * NT << ")\n"
+             "rt_jit_combine(const double *__restrict__ halfbuf, const rt_d2 *__restrict__ obs,\n"
+             "               const double *__restrict__ root_w, double *__restrict__ loglik,\n"
+             "               int *__restrict__ status, double *__restrict__ partial,\n"
+             "               long nsites, long nblocks)\n{\n";
+        o << "    __shared__ double red[1][" << NT << "][16];\n";
+        o << "    const int lane = threadIdx.x & 63;\n";
+        o << "    const int m = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);\n";
+        o << "    const long tile0 = (long)blockIdx.x;\n";
+        for (int r = 0; r < 4; ++r)
+            o << "    const bool rowok" << r << " = 16 * m + " << 4 * r << " + (lane >> 4) < " << n << ";\n";
+        o << "    double lik0 = 0.0;\n    bool negative0 = false;\n";
+        o << "    const double *ha = halfbuf + (size_t)tile0 * " << 2 * XT << " + (4 * m) * 64 + lane;\n";
+        if (root.obs >= 0) {
+            o << "    typedef const __attribute__((address_space(1))) rt_d2 *rt_glb2;\n";
+            o << "    const bool pair1 = 2 * m + 1 < " << KP << ";\n";
+            o << "    const rt_d2 zero2 = {0.0, 0.0};\n";
+            o << "    rt_glb2 g0 = (rt_glb2)obs + (size_t)tile0 * " << (long)K * KP * 64
+              << " + (2 * m * 64 + lane);\n";
+            o << "    const rt_d2 ob_0 = g0[" << (long)root.obs * KP * 64 << "];\n";
+            o << "    const rt_d2 ob_1 = pair1 ? g0[" << ((long)root.obs * KP + 1) * 64 << "] : zero2;\n";
+        }
+        for (int r = 0; r < 4; ++r) {
+            o << "    const double xr_0_" << r << " = ha[" << r * 64 << "] * ha[" << XT + r * 64 << "]";
+            if (root.obs >= 0) o << " * ob_" << (r >> 1) << ((r & 1) ? ".y" : ".x");
+            o << ";\n";
+        }
+        emit_root_reduce(o, "xr");
+        emit_site_epilogue(o);
+        o << "}\n";
+        return o.str();
     }
+    emit_site_epilogue(o);
     o << "}\n";
     return o.str();
 }
@@ -1680,6 +1813,20 @@ void rt_jit_ref(const rt_ctx *ctx, void *fn, int delta)
     }
 }
 
+int rt_jit_companion(const rt_ctx *ctx, void *fn, const char *name, void **out)
+{
+    std::lock_guard<std::mutex> lock(g_jit_mutex);
+    for (auto &kv : g_jit_cache)
+        if (kv.first.first == ctx && (void *)kv.second.fn == fn) {
+            hipFunction_t f = nullptr;
+            RT_HIP(hipModuleGetFunction(&f, kv.second.module, name));
+            *out = (void *)f;
+            return RT_OK;
+        }
+    rt_set_error("kernel not found");
+    return RT_ERR_INVALID;
+}
+
 int rt_jit_verified(const rt_ctx *ctx, void *fn)
 {
     std::lock_guard<std::mutex> lock(g_jit_mutex);
@@ -1772,6 +1919,31 @@ int rt_launch_prune_jit(rt_model *m, rt_sites *s)
         RT_HIP(hipEventRecord(ctx->ev_join, ctx->stream2));
         RT_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         if (ctx->ev_stop) RT_HIP(hipEventRecord(ctx->ev_stop, ctx->stream));
+        return RT_OK;
+    }
+    if (s->jit_halves) {
+        // split-M family, root halves: 2 workgroups per tile, then the combine kernel (one
+        // per tile); a sampled launch is stamped from the first kernel's begin to the
+        // second kernel's end
+        double *half = s->d_half;
+        const double *chalf = s->d_half;
+        void *hargs[] = {&Pord, &obs, &root_w, &loglik, &status, &partial, &nsites, &nblocks, &half};
+        void *cargs[] = {&chalf, &obs, &root_w, &loglik, &status, &partial, &nsites, &nblocks};
+        const unsigned tpb = 64u * (unsigned)s->jit_waves;
+        const unsigned tiles = (unsigned)s->nblocks;
+        if (m->ctx->ev_start) {
+            RT_HIP(hipExtModuleLaunchKernel((hipFunction_t)s->jit_fn, 2u * tiles * tpb, 1, 1, tpb, 1, 1,
+                                            0, m->ctx->stream, hargs, nullptr, m->ctx->ev_start,
+                                            nullptr, 0));
+            RT_HIP(hipExtModuleLaunchKernel((hipFunction_t)s->jit_combine, tiles * tpb, 1, 1, tpb, 1, 1,
+                                            0, m->ctx->stream, cargs, nullptr, nullptr,
+                                            m->ctx->ev_stop, 0));
+        } else {
+            RT_HIP(hipModuleLaunchKernel((hipFunction_t)s->jit_fn, 2u * tiles, 1, 1, tpb, 1, 1, 0,
+                                         m->ctx->stream, hargs, nullptr));
+            RT_HIP(hipModuleLaunchKernel((hipFunction_t)s->jit_combine, tiles, 1, 1, tpb, 1, 1, 0,
+                                         m->ctx->stream, cargs, nullptr));
+        }
         return RT_OK;
     }
     // lane family: jit_waves waves of one site block each per workgroup; MFMA family,

@@ -1552,8 +1552,9 @@ int rt_launch_prune(rt_model *m, rt_sites *s, bool defer_reduce)
                 snprintf(jit_name, sizeof(s->kernel_name), "prune_tree_jit_mfma%s<%d,T%d+T%d>",
                          s->jit_quad ? "4x4" : "", (int)m->n, s->jit_tiles, s->jit_tiles2);
             else
-            snprintf(jit_name, sizeof(s->kernel_name), "prune_tree_jit_mfma%s<%d,T%d>",
-                     s->jit_quad ? "4x4" : "", (int)m->n, s->jit_tiles);
+            snprintf(jit_name, sizeof(s->kernel_name), "prune_tree_jit_mfma%s<%d,T%d%s>",
+                     s->jit_quad ? "4x4" : "", (int)m->n, s->jit_tiles,
+                     s->jit_halves ? ",halves" : "");
         name = jit_name;
     } else if (s->layout == RT_LAYOUT_LANE) {
         switch ((int)m->n) {
