@@ -452,6 +452,44 @@ def measure_next_rows(ctx):
             chains=100000, ms_per_sweep=dt * 1e3, chain_sweeps_per_s=100000 / dt,
             segments_per_chain=rows / 100000.0,
             what='one Rao-Teh sweep of every chain, histories resident on the device')
+        # the reference's optional spectral path (examples/p53/qtop.py): the decomposition of
+        # the one reversible rate matrix is the caller's, once per matrix; a step rebuilds all
+        # edges from it (csrc/spectral.hip) instead of running expm per edge
+        from raoteh_amd import _lib, _spectral, device
+        for name, nsites in (('c3', 10000), ('c2', 100000)):
+            cfg = synth.make_config(name, nsites=nsites)
+            t0 = time.perf_counter()
+            A, lam, B, D = _spectral.decompose_rate_matrix(cfg['Q_default'], cfg['root_distn'])
+            decompose_s = time.perf_counter() - t0
+            model = device.TreeModel(cfg['T'], cfg['root'], cfg['nstates'], ctx=ctx)
+            model.set_root_distn(cfg['root_distn'])
+            batch = model.upload_sites(cfg['leaves'], synth.leaf_likelihoods(cfg), kind='dense')
+            model.set_rates(Q_default=cfg['Q_default'])
+            ll_expm, _ = model.log_likelihoods(batch)
+            model.set_rates_spectral(A, lam, B, D=D)
+            ll_spec, _ = model.log_likelihoods(batch)
+            for _ in range(10):
+                model.step(batch)
+            ctx.sync()
+            ctx.set_timing(1)
+            ctx.reset_timing()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                model.step(batch)
+            ctx.sync()
+            dt = (time.perf_counter() - t0) / 50
+            ems, ecnt, ename = ctx.kernel_time(_lib.RT_K_EXPM)
+            ctx.set_timing(0)
+            out['spectral_step_%s' % name] = dict(
+                sites=nsites, ms_per_step_every_launch_timed=dt * 1e3, kernel=ename,
+                avg_kernel_us=ems / max(ecnt, 1) * 1e3, host_decomposition_s=decompose_s,
+                max_rel_diff_loglik_vs_expm=float(np.max(np.abs(ll_spec - ll_expm) /
+                                                         np.abs(ll_expm))),
+                what='one step with every edge rebuilt from the spectral decomposition of the '
+                     'one reversible rate matrix (no cache between steps; the decomposition '
+                     'itself is once per matrix, on the host as in the reference)')
+            batch.close()
+            model.close()
     except Exception as exc:                      # noqa: BLE001 -- a side measurement
         out['error'] = repr(exc)
     return out

@@ -98,6 +98,10 @@ int         rt_ctx_kernel_time(rt_ctx *ctx, int kernel, double *total_ms,
 int rt_expm(rt_ctx *ctx, int64_t n, int64_t count,
             const double *Q, int64_t nq, const int64_t *q_index,
             const double *t, double *P, int32_t *info);
+/* getp_spectral_v2 (examples/p53/qtop.py:76-88) at `count` branch lengths in one launch:
+ * P[b] = A diag(exp(lam t[b])) B, diagonal 1 where D == 0 (D may be NULL).  n <= 64.    */
+int rt_expm_spectral(rt_ctx *ctx, int64_t n, int64_t count, const double *A,
+            const double *lam, const double *B, const double *D, const double *t, double *P);
 
 /* The three pyfelscore passes of _mcy_dense.py:261-291, batched over
  * `nsites` independent sites that share the tree and the transitions:
@@ -223,6 +227,16 @@ int rt_model_destroy(rt_model *model);
  * branch length of the edge above node v (t[0] ignored).                    */
 int rt_model_set_rates(rt_model *model, const double *Q, int64_t nq,
             const int64_t *node_q, const double *t);
+/* ONE time-reversible rate matrix given by its spectral decomposition, the reference's
+ * optional fast path (examples/p53/qtop.py:128-152 decompose_spectral_v2, :76-88
+ * getp_spectral_v2): Q = S diag(D), eigh(diag(sqrt D) S diag(sqrt D)) = U diag(lam) U^T,
+ * A = diag(1/sqrt D) U (rows of states with D == 0 zero), B = U^T diag(sqrt D).  Every edge
+ * gets P_e = A diag(exp(lam t_e)) B, and P_e[i][i] = 1 where D[i] == 0 (D may be NULL: no
+ * such state).  The decomposition is the caller's (once per Q); this call and every later
+ * rt_model_recompute_transitions / rt_step rebuild all edges from it in one launch, until
+ * rt_model_set_rates is called again.  A, B f64[n][n]; lam, D f64[n]; t as above.  n <= 64. */
+int rt_model_set_rates_spectral(rt_model *model, const double *A, const double *lam,
+            const double *B, const double *D, const double *t);
 /* Re-run the per-edge expm from the Q / node_q / t already resident on the
  * device (what an optimiser or MCMC loop does after changing rates in place;
  * also one benchmark step).                                                 */

@@ -185,6 +185,31 @@ def device_expm_order_and_squarings(n, norm1):
 
 
 # ---------------------------------------------------------------------------
+# the optional spectral path of one reversible rate matrix (examples/p53/qtop.py)
+# ---------------------------------------------------------------------------
+
+def spectral_decompose_v2(S, D):
+    """qtop.py:128-150 (decompose_spectral + decompose_spectral_v2): Q = S diag(D) ->
+    (A, lam, B) with A = diag(pseudo_reciprocal(sqrt D)) U, B = U^T diag(sqrt D),
+    eigh(diag(sqrt D) S diag(sqrt D)) = (lam, U)."""
+    S = np.asarray(S, dtype=np.float64)
+    D = np.asarray(D, dtype=np.float64)
+    r = np.sqrt(D)
+    lam, U = scipy.linalg.eigh(r[:, None] * S * r[None, :])
+    with np.errstate(divide='ignore'):
+        rinv = np.where(r == 0, r, np.reciprocal(r))
+    return rinv[:, None] * U, lam, U.T * r[None, :]
+
+
+def spectral_getp_v2(D, A, lam, B, t):
+    """qtop.py:76-88 (getp_spectral_v2 over reconstruct_spectral_v2, :283-288)."""
+    P = np.dot(np.asarray(A) * np.exp(t * np.asarray(lam))[None, :], np.asarray(B))
+    off = np.asarray(D) == 0
+    P[off, off] = 1
+    return P
+
+
+# ---------------------------------------------------------------------------
 # tree marshalling (reference: _mcy_dense.py:246-255, _density.py:104-180)
 # ---------------------------------------------------------------------------
 

@@ -92,6 +92,9 @@ SIGNATURES = {
                                 POINTER(c_void_p)]),
     'rt_model_destroy': (c_int, [c_void_p]),
     'rt_model_set_rates': (c_int, [c_void_p, _p_f64, c_int64, _p_i64, _p_f64]),
+    'rt_model_set_rates_spectral': (c_int, [c_void_p, _p_f64, _p_f64, _p_f64, _p_f64, _p_f64]),
+    'rt_expm_spectral': (c_int, [c_void_p, c_int64, c_int64, _p_f64, _p_f64, _p_f64, _p_f64,
+                                 _p_f64, _p_f64]),
     'rt_model_recompute_transitions': (c_int, [c_void_p]),
     'rt_model_set_transitions': (c_int, [c_void_p, _p_f64]),
     'rt_model_get_transitions': (c_int, [c_void_p, _p_f64]),

@@ -368,7 +368,7 @@ extern "C" int rt_model_destroy(rt_model *m)
     hipSetDevice(m->ctx->device);
     hipStreamSynchronize(m->ctx->stream);
     hipFree(m->d_indices); hipFree(m->d_indptr); hipFree(m->d_ops); hipFree(m->d_P);
-    hipFree(m->d_Pfrag); hipFree(m->d_Pquad); hipFree(m->d_root); hipFree(m->d_Q); hipFree(m->d_qidx);
+    hipFree(m->d_Pfrag); hipFree(m->d_Pquad); hipFree(m->d_root); hipFree(m->d_Q); hipFree(m->d_spec); hipFree(m->d_qidx);
     hipFree(m->d_t); hipFree(m->d_info); hipFree(m->d_step_of_node);
     delete m;
     return RT_OK;
@@ -452,6 +452,18 @@ static int model_run_expm(rt_model *m)
     // a reduction deferred by the previous rt_step rides on this launch
     rt_reduce_args red;
     const bool carry = rt_take_pending_reduce(m->ctx, &red);
+    if (m->spectral) {
+        const size_t nn = (size_t)m->n * m->n;
+        RT_TRY(rt_launch_spectral(m->ctx, m->n, m->nnodes, m->d_spec, m->d_spec + 2 * nn,
+                                  m->d_spec + nn, m->spectral_has_D ? m->d_spec + 2 * nn + m->n
+                                                                    : nullptr,
+                                  m->d_qidx, m->d_t, m->d_P, m->d_info, m->d_step_of_node,
+                                  m->n <= 4 ? 0 : 1, m->d_Pfrag, carry ? &red : nullptr,
+                                  m->d_Pquad));
+        m->have_P = true;
+        m->frag_dirty = false;
+        return RT_OK;
+    }
     RT_TRY(rt_launch_expm(m->ctx, m->n, m->nnodes, m->d_Q, m->d_qidx, m->d_t, m->d_P,
                           m->d_info, m->d_step_of_node, m->n <= 4 ? 0 : 1, m->d_Pfrag,
                           carry ? &red : nullptr, m->d_Pquad));
@@ -505,13 +517,98 @@ extern "C" int rt_model_set_rates(rt_model *m, const double *Q, int64_t nq,
         RT_HIP(hipMemcpy(m->d_t, tt.data(), m->nnodes * 8, hipMemcpyHostToDevice));
         m->h_t = tt;
     }
+    m->spectral = false;
     return model_run_expm(m);
+}
+
+// One reversible rate matrix given by its decomposition (examples/p53/qtop.py:128-152):
+// every edge's transition matrix is rebuilt from it (spectral.hip) now and at every later
+// rt_model_recompute_transitions / rt_step, until rt_model_set_rates is called again.
+extern "C" int rt_model_set_rates_spectral(rt_model *m, const double *A, const double *lam,
+                                           const double *B, const double *D, const double *t)
+{
+    RT_REQUIRE(m && A && lam && B && t, "null pointer");
+    if (m->n > 64) {
+        rt_set_error("spectral reconstruction: n=%lld > 64", (long long)m->n);
+        return RT_ERR_UNSUPPORTED;
+    }
+    RT_HIP(hipSetDevice(m->ctx->device));
+    const size_t n = (size_t)m->n, nn = n * n;
+    std::vector<int32_t> qi((size_t)m->nnodes, 0);
+    std::vector<double> tt((size_t)m->nnodes);
+    qi[0] = -1;
+    tt[0] = 0.0;
+    for (int64_t v = 1; v < m->nnodes; ++v) {
+        RT_REQUIRE(std::isfinite(t[v]), "branch length of node %lld is not finite", (long long)v);
+        tt[(size_t)v] = t[v];
+    }
+    for (size_t i = 0; i < n; ++i)
+        RT_REQUIRE(std::isfinite(lam[i]) && (!D || D[i] >= 0.0), "eigenvalue / weight %zu", i);
+    if (!m->d_spec) RT_HIP(hipMalloc((void **)&m->d_spec, (2 * nn + 2 * n) * 8));
+    RT_HIP(hipStreamSynchronize(m->ctx->stream));
+    RT_HIP(hipMemcpy(m->d_spec, A, nn * 8, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(m->d_spec + nn, B, nn * 8, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(m->d_spec + 2 * nn, lam, n * 8, hipMemcpyHostToDevice));
+    if (D) RT_HIP(hipMemcpy(m->d_spec + 2 * nn + n, D, n * 8, hipMemcpyHostToDevice));
+    m->spectral_has_D = D != nullptr;
+    if (qi != m->h_qidx) {
+        RT_HIP(hipMemcpy(m->d_qidx, qi.data(), m->nnodes * 4, hipMemcpyHostToDevice));
+        m->h_qidx = qi;
+    }
+    if (tt != m->h_t) {
+        RT_HIP(hipMemcpy(m->d_t, tt.data(), m->nnodes * 8, hipMemcpyHostToDevice));
+        m->h_t = tt;
+    }
+    m->spectral = true;
+    return model_run_expm(m);
+}
+
+// getp_spectral_v2 (qtop.py:76-88) for `count` branch lengths in one launch: host in, host out
+extern "C" int rt_expm_spectral(rt_ctx *ctx, int64_t n, int64_t count, const double *A,
+                                const double *lam, const double *B, const double *D,
+                                const double *t, double *P)
+{
+    RT_REQUIRE(ctx, "null context");
+    RT_REQUIRE(n >= 1 && count >= 0, "bad sizes");
+    RT_REQUIRE(A && lam && B && t && P, "null array");
+    if (n > 64) {
+        rt_set_error("spectral reconstruction: n=%lld > 64", (long long)n);
+        return RT_ERR_UNSUPPORTED;
+    }
+    if (count == 0) return RT_OK;
+    RT_HIP(hipSetDevice(ctx->device));
+    const size_t nn = (size_t)n * n;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_A = 0, o_B = o_A + up(nn * 8), o_lam = o_B + up(nn * 8), o_D = o_lam + up(n * 8),
+                 o_t = o_D + up(n * 8), o_P = o_t + up(count * 8), total = o_P + up(count * nn * 8);
+    RT_TRY(rt_scratch_reserve(ctx, total));
+    unsigned char *base = ctx->d_scratch;
+    double *dA = (double *)(base + o_A), *dB = (double *)(base + o_B), *dl = (double *)(base + o_lam),
+           *dD = (double *)(base + o_D), *dt = (double *)(base + o_t), *dP = (double *)(base + o_P);
+    int rc = RT_OK;
+    hipError_t e = hipMemcpyAsync(dA, A, nn * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dB, B, nn * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dl, lam, n * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && D) e = hipMemcpyAsync(dD, D, n * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dt, t, count * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        rc = rt_launch_spectral(ctx, n, count, dA, dl, dB, D ? dD : nullptr, nullptr, dt, dP, nullptr,
+                                nullptr, 0, nullptr);
+    if (e == hipSuccess && rc == RT_OK)
+        e = hipMemcpyAsync(P, dP, count * nn * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && rc == RT_OK) e = hipStreamSynchronize(ctx->stream);
+    if (rc != RT_OK) return rc;
+    if (e != hipSuccess) {
+        rt_set_error("rt_expm_spectral: %s", hipGetErrorString(e));
+        return RT_ERR_HIP;
+    }
+    return RT_OK;
 }
 
 extern "C" int rt_model_recompute_transitions(rt_model *m)
 {
     RT_REQUIRE(m, "null model");
-    RT_REQUIRE(m->d_Q, "rt_model_set_rates has not been called");
+    RT_REQUIRE(m->d_Q || m->spectral, "rt_model_set_rates has not been called");
     RT_HIP(hipSetDevice(m->ctx->device));
     return model_run_expm(m);
 }
@@ -1470,7 +1567,8 @@ extern "C" int rt_step(rt_model *m, rt_sites *s, int recompute_transitions)
 {
     RT_REQUIRE(m && s, "null pointer");
     RT_REQUIRE(s->model == m, "the site batch belongs to another model");
-    RT_REQUIRE(!recompute_transitions || m->d_Q, "rt_model_set_rates has not been called");
+    RT_REQUIRE(!recompute_transitions || m->d_Q || m->spectral,
+               "rt_model_set_rates has not been called");
     RT_REQUIRE(recompute_transitions || m->have_P,
                "the model has no transition matrices yet");
     RT_HIP(hipSetDevice(m->ctx->device));

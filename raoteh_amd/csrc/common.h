@@ -91,6 +91,7 @@ struct rt_ctx {
     struct rt_sites *pending_reduce = nullptr;
     size_t expm_attr_lds = 0;      // dynamic-LDS attribute already granted to expm_kernel
     size_t expm_ts_attr_lds[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ... to the Taylor kernels (per NT)
+    size_t spectral_attr_lds[4] = {0, 0, 0, 0};              // ... to spectral_kernel<NT>
     double *d_expm_scratch = nullptr;   // matrices of the order > 64 Taylor kernel (grow-only)
     void *expect_cache = nullptr;       // expect_mfma.hip: model + packed batch of the last call
     hipStream_t stream2 = nullptr;      // side stream of two-kernel pruning launches (lazy)
@@ -133,6 +134,10 @@ struct rt_model {
     // states cost 5 x 5 instructions of 16 cycles instead of 2 x 5 of 64)
     double *d_Pquad = nullptr;
     double *d_root = nullptr;       // [n] root weights (ones if unset)
+    // rt_model_set_rates_spectral: A [n][n], B [n][n], lam [n], D [n] of the decomposition
+    // (spectral.hip); while `spectral` is set the transitions are rebuilt from these
+    double *d_spec = nullptr;
+    bool spectral = false, spectral_has_D = false;
     double *d_Q = nullptr;          // rate matrices of the last set_rates
     int64_t q_capacity = 0;
     int32_t *d_qidx = nullptr;      // [nnodes]
@@ -222,6 +227,12 @@ int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
                    int32_t *d_info, const int32_t *d_step_of_node, int frag_kind,
                    double *d_Pfrag, const rt_reduce_args *fused_reduce = nullptr,
                    double *d_Pquad = nullptr);
+// spectral.hip: P_e = A diag(exp(lam t_e)) B per edge, outputs as rt_launch_expm's
+int rt_launch_spectral(rt_ctx *ctx, int64_t n, int64_t count, const double *d_A,
+                       const double *d_lam, const double *d_B, const double *d_D,
+                       const int32_t *d_qidx, const double *d_t, double *d_P, int32_t *d_info,
+                       const int32_t *d_step_of_node, int frag_kind, double *d_Pfrag,
+                       const rt_reduce_args *fused_reduce = nullptr, double *d_Pquad = nullptr);
 // the pending reduction, handed to the next expm launch (-> true) ...
 bool rt_take_pending_reduce(rt_ctx *ctx, rt_reduce_args *out);
 // ... or launched on its own now (no-op when nothing is pending)

@@ -1054,6 +1054,19 @@ expm_small_kernel(int count, const double *__restrict__ Q, const int *__restrict
 // up to 6 products plus an LU factorisation with predicated row swaps for the Pade form
 // above -- this kernel is one wave of dependent register arithmetic, and on config 2 it
 // sits in front of a 34 us pruning kernel in every step.
+// 1 / i! as a compile-time expression: with the Horner loop unrolled every coefficient is an
+// instruction literal.  (Indexed by the per-lane order m, the table in constant memory was
+// a per-lane gather -- one dependent memory round trip for the seed of the recurrence and one
+// more per Horner step, most of this kernel's 6.8 us on config 2.)
+__device__ __forceinline__ constexpr double inv_fact_lit(int i)
+{
+    constexpr double f[16] = {
+        1.0, 1.0, 0.5, 1.0 / 6.0, 1.0 / 24.0, 1.0 / 120.0, 1.0 / 720.0, 1.0 / 5040.0,
+        1.0 / 40320.0, 1.0 / 362880.0, 1.0 / 3628800.0, 1.0 / 39916800.0, 1.0 / 479001600.0,
+        1.0 / 6227020800.0, 1.0 / 87178291200.0, 1.0 / 1307674368000.0};
+    return f[i];
+}
+
 template <int N>
 __global__ void __launch_bounds__(256)
 expm_small_taylor_kernel(int count, const double *__restrict__ Q, const int *__restrict__ qidx,
@@ -1069,8 +1082,17 @@ expm_small_taylor_kernel(int count, const double *__restrict__ Q, const int *__r
     if (b >= count) return;
     constexpr int NN = N * N;
     double *Pb = P + (long)b * NN;
+    // every load of the lane is issued at once: matrix 0 is fetched before the lane knows
+    // which matrix it uses (one rate matrix for all edges is the common case; the others
+    // pay a second fetch)
     const int qi = qidx[b];
     const int step = step_of_node ? step_of_node[b] : -1;
+    const double t = tt[b];
+    SmallMat<N> A;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) A.a[i][j] = Q[i * N + j];
     if (qi < 0) {                              // root slot: zeros (_density.py:171)
 #pragma unroll
         for (int e = 0; e < NN; ++e) Pb[e] = 0.0;
@@ -1080,13 +1102,17 @@ expm_small_taylor_kernel(int count, const double *__restrict__ Q, const int *__r
             for (int e = 0; e < NN; ++e) Pfrag[(long)step * NN + e] = 0.0;
         return;
     }
-    const double *Qb = Q + (long)qi * NN;
-    const double t = tt[b];
-    SmallMat<N> A;
+    if (qi > 0) {
+        const double *Qb = Q + (long)qi * NN;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) A.a[i][j] = Qb[i * N + j];
+    }
 #pragma unroll
     for (int i = 0; i < N; ++i)
 #pragma unroll
-        for (int j = 0; j < N; ++j) A.a[i][j] = Qb[i * N + j] * t;
+        for (int j = 0; j < N; ++j) A.a[i][j] *= t;
     double nrm = 0.0;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
@@ -1095,15 +1121,16 @@ expm_small_taylor_kernel(int count, const double *__restrict__ Q, const int *__r
         for (int i = 0; i < N; ++i) cs += fabs(A.a[i][j]);
         nrm = fmax(nrm, cs);
     }
+    // (the thresholds of c_theta_taylor as literals)
     int m = 15, s = 0;
     if (!(nrm < 1e300)) m = -1;
-    else if (nrm <= c_theta_taylor[0]) m = 3;
-    else if (nrm <= c_theta_taylor[1]) m = 6;
-    else if (nrm <= c_theta_taylor[2]) m = 9;
-    else if (nrm <= c_theta_taylor[3]) m = 12;
-    else if (nrm > c_theta_taylor[4]) {
+    else if (nrm <= 1.3863479e-5) m = 3;
+    else if (nrm <= 9.0656564e-3) m = 6;
+    else if (nrm <= 8.9577602e-2) m = 9;
+    else if (nrm <= 2.9961589e-1) m = 12;
+    else if (nrm > 6.4108352e-1) {
         int e;
-        const double f = frexp(nrm / c_theta_taylor[4], &e);
+        const double f = frexp(nrm / 6.4108352e-1, &e);
         s = (f == 0.5) ? e - 1 : e;
         if (s < 0) s = 0;
     }
@@ -1125,23 +1152,32 @@ expm_small_taylor_kernel(int count, const double *__restrict__ Q, const int *__r
         SmallMat<N> A2, A3;
         sm_mul(A, A, A2);
         sm_mul(A, A2, A3);
-        const int q = m / 3;
-        {
-            const int base = 3 * (q - 1);
-            sm_comb(X, c_inv_fact[base + 1], A, c_inv_fact[base + 2], A2, c_inv_fact[m], A3,
-                    c_inv_fact[base]);
-        }
-        for (int jj = q - 2; jj >= 0; --jj) {
-            SmallMat<N> Y;
-            sm_mul(A3, X, Y);
-            // X = Y + c A + c A^2 + c I
+        const int q = m / 3;                   // 1..5
+        // seed: c[3(q-1)] I + c[3(q-1)+1] A + c[3(q-1)+2] A^2 + c[3q] A^3
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-            for (int i = 0; i < N; ++i)
+        for (int qq = 1; qq <= 5; ++qq)
+            if (q == qq) {
+                s0 = inv_fact_lit(3 * qq - 3);
+                s1 = inv_fact_lit(3 * qq - 2);
+                s2 = inv_fact_lit(3 * qq - 1);
+                s3 = inv_fact_lit(3 * qq);
+            }
+        sm_comb(X, s1, A, s2, A2, s3, A3, s0);
 #pragma unroll
-                for (int j = 0; j < N; ++j)
-                    X.a[i][j] = Y.a[i][j] + (c_inv_fact[3 * jj + 1] * A.a[i][j] +
-                                             c_inv_fact[3 * jj + 2] * A2.a[i][j] +
-                                             (i == j ? c_inv_fact[3 * jj] : 0.0));
+        for (int jj = 3; jj >= 0; --jj) {
+            if (jj <= q - 2) {
+                SmallMat<N> Y;
+                sm_mul(A3, X, Y);
+                // X = Y + c A + c A^2 + c I
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+#pragma unroll
+                    for (int j = 0; j < N; ++j)
+                        X.a[i][j] = Y.a[i][j] + (inv_fact_lit(3 * jj + 1) * A.a[i][j] +
+                                                 inv_fact_lit(3 * jj + 2) * A2.a[i][j] +
+                                                 (i == j ? inv_fact_lit(3 * jj) : 0.0));
+            }
         }
         for (int r = 0; r < s; ++r) sm_mul(X, X, X);
     }

@@ -136,6 +136,23 @@ class Context(object):
             _ptr(P, c_double), _ptr(info, c_int32)))
         return (P, info) if return_info else P
 
+    def expm_spectral(self, A, lam, B, t, D=None):
+        """P[b] = A diag(exp(lam t[b])) B, diagonal 1 where D == 0: the reference's
+        getp_spectral_v2 (examples/p53/qtop.py:76-88) at all branch lengths in one launch."""
+        A, lam, B = _f64(A), _f64(lam), _f64(B)
+        n = lam.shape[0]
+        if A.shape != (n, n) or B.shape != (n, n):
+            raise ValueError('expected the array to be square')
+        t = np.atleast_1d(_f64(t))
+        D = None if D is None else _f64(D)
+        if D is not None and D.shape != (n,):
+            raise ValueError('D must have one entry per state')
+        P = np.empty((t.shape[0], n, n), dtype=np.float64)
+        _lib.check(_lib.lib().rt_expm_spectral(
+            self._h, n, t.shape[0], _ptr(A, c_double), _ptr(lam, c_double), _ptr(B, c_double),
+            None if D is None else _ptr(D, c_double), _ptr(t, c_double), _ptr(P, c_double)))
+        return P
+
     def _pass_args(self, indices, indptr, esd, arr):
         indices, indptr, esd = _i64(indices), _i64(indptr), _f64(esd)
         nnodes, n = esd.shape[0], esd.shape[1]
@@ -449,6 +466,26 @@ class TreeModel(object):
         _lib.check(_lib.lib().rt_model_set_rates(
             self._h, _ptr(Q, c_double), Q.shape[0],
             None if nq is None else _ptr(nq, c_int64), _ptr(t, c_double)))
+
+    def set_rates_spectral(self, A, lam, B, D=None, t=None):
+        """One time-reversible rate matrix given by its spectral decomposition
+        (raoteh_amd._spectral.decompose_spectral_v2, examples/p53/qtop.py:128-152): every
+        edge's P = A diag(exp(lam t)) B on the device, now and at every later step()."""
+        A, lam, B = _f64(A), _f64(lam), _f64(B)
+        n = self.nstates
+        if A.shape != (n, n) or B.shape != (n, n) or lam.shape != (n,):
+            raise ValueError('expected the array to be square')
+        D = None if D is None else _f64(D)
+        if D is not None and D.shape != (n,):
+            raise ValueError('D must have one entry per state')
+        if t is None:
+            t = self.tree.branch_lengths()
+        t = _f64(t)
+        if t.shape != (self.tree.nnodes,):
+            raise ValueError('t must have one entry per node')
+        _lib.check(_lib.lib().rt_model_set_rates_spectral(
+            self._h, _ptr(A, c_double), _ptr(lam, c_double), _ptr(B, c_double),
+            None if D is None else _ptr(D, c_double), _ptr(t, c_double)))
 
     def recompute_transitions(self):
         _lib.check(_lib.lib().rt_model_recompute_transitions(self._h))

@@ -67,6 +67,72 @@ def test_expm_matches_scipy_fixture(ra):
             assert tuple(info[k]) == (m, s)
 
 
+def test_spectral_reconstruction_matches_the_reference_qtop(ra):
+    """csrc/spectral.hip through rt_expm_spectral and rt_model_set_rates_spectral against
+    examples/p53/qtop.py's own getp_spectral_v2 outputs (tests/golden/spectral.json), and
+    the likelihood of a tree whose edges come from the spectral path against the one whose
+    edges come from expm."""
+    from raoteh_amd import _spectral
+    fx = load_golden('spectral')
+    for c in fx['cases']:
+        D, A, lam, B = (np.array(c[k]) for k in ('D', 'A', 'lam', 'B'))
+        n = c['n']
+        want = np.array(c['P_spectral'])
+        # entries are sums of n products of magnitude <= max|A| max|B|
+        atol = 1e-15 * n * np.abs(A).max() * np.abs(B).max()
+        got = _spectral.getp_spectral_v2(D, A, lam, B, np.array(c['t']))
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=atol)
+        np.testing.assert_allclose(_spectral.getp_spectral_v2(D, A, lam, B, c['t'][0]), want[0],
+                                   rtol=1e-12, atol=atol)
+        assert (got[:, D == 0, D == 0] == 1).all()
+        # the resident path: a random tree, P of every edge in the layouts the pruning
+        # kernels read; likelihoods against the same tree with the fixture's matrices set
+        # directly
+        rng = np.random.RandomState(n)
+        T, root, leaves = ra.synth.random_tree(12, seed=n)
+        for a, b in T.edges():
+            T[a][b]['weight'] = float(rng.choice(c['t']))
+        model = ra.device.TreeModel(T, root, n)
+        model.set_rates_spectral(A, lam, B, D=D)
+        esd = model.get_transitions()
+        ts = model.tree.branch_lengths()
+        for v in range(1, model.tree.nnodes):
+            k = c['t'].index(ts[v])
+            np.testing.assert_allclose(esd[v], want[k], rtol=1e-12, atol=atol)
+        assert not esd[0].any()
+        w = np.where(D > 0, D, 0.0)
+        model.set_root_distn(w)
+        states = rng.randint(1, n, size=(40, len(leaves))).astype(np.uint8)
+        batch = model.upload_sites(leaves, states, kind='state')
+        ll, st = model.log_likelihoods(batch)
+        model.step(batch)                      # rebuilds the edges from the decomposition
+        ll_step, _ = model.fetch_log_likelihoods(batch)
+        np.testing.assert_array_equal(ll, ll_step)
+        twin = ra.device.TreeModel(T, root, n)
+        twin.set_transitions(esd)
+        twin.set_root_distn(w)
+        ll2, st2 = twin.log_likelihoods(twin.upload_sites(leaves, states, kind='state'))
+        np.testing.assert_array_equal(ll, ll2)
+        if 'P_expm' in c and n > 4:
+            # ... and against expm of the same rate matrix (Q = S diag(D) = A diag(lam) B)
+            Q = (A * lam[None, :]) @ B
+            Q[D == 0] = 0.0
+            full = ra.device.TreeModel(T, root, n)
+            full.set_rates(Q=Q, t=ts)
+            full.set_root_distn(w)
+            ll3, _ = full.log_likelihoods(full.upload_sites(leaves, states, kind='state'))
+            ok = st == 0
+            # the spectral form holds entries of P to an ABSOLUTE 1e-14..1e-13 (qtop.py:606
+            # tests atol = 1e-14 at n = 4; cancellation among n terms of size |A||B|), the
+            # expm kernels hold small entries relatively: on these random matrices (stationary
+            # weights down to 1e-4) and on uniformly random leaf states (for the codon matrix:
+            # three-substitution entries of P(0.004) ~ 1e-9) the log-likelihoods agree to ~1e-7;
+            # on data simulated from the model to 1e-11 (bench.py, spectral_step_c3)
+            np.testing.assert_allclose(ll[ok], ll3[ok], rtol=1e-5)
+    with pytest.raises(Exception):
+        ra.ctx.expm_spectral(np.eye(70), np.zeros(70), np.eye(70), [0.1])
+
+
 def test_expm_against_own_algorithm_restated(ra):
     rng = np.random.RandomState(7)
     for n in (1, 2, 5, 17, 32, 47, 62):

@@ -487,3 +487,33 @@ def test_poisson_split_and_merge_keep_lengths_and_order():
     assert c.tolist() == [0, 0, 0, 1] and e.tolist() == [1, 1, 2, 1]
     np.testing.assert_allclose(l, [.3, .3, .9, 1.3])
     assert s.tolist() == [2, 1, 1, 0]
+
+
+def test_spectral_host_mirror_decomposition():
+    """raoteh_amd/_spectral.py (host side of examples/p53/qtop.py:104-150) against the
+    reference's own factors in tests/golden/spectral.json; no device call."""
+    from conftest import load_golden
+    from oracle import oracle_numpy as orc
+    from raoteh_amd import _spectral
+    fx = load_golden('spectral')
+    for c in fx['cases']:
+        if 'S' not in c:
+            continue
+        S, D = np.array(c['S']), np.array(c['D'])
+        A, lam, B = _spectral.decompose_spectral_v2(S, D)
+        np.testing.assert_allclose(lam, np.array(c['lam']), rtol=1e-10, atol=1e-12)
+        assert not A[D == 0].any()
+        for k, t in enumerate(c['t']):
+            np.testing.assert_allclose(orc.spectral_getp_v2(D, A, lam, B, t),
+                                       np.array(c['P_spectral'][k]), rtol=1e-10, atol=1e-13)
+    # a reversible matrix given with its distribution; and a non-reversible one
+    mg = load_golden('p53_mg94')
+    Q = np.array(mg['Q_offdiagonal'])
+    Q -= np.diag(Q.sum(axis=1))
+    A, lam, B, D = _spectral.decompose_rate_matrix(Q, mg['distn'])
+    np.testing.assert_allclose((A * lam[None, :]) @ B, Q, rtol=0, atol=1e-12)
+    Qbad = np.array([[-1.0, 1.0, 0.0], [0.0, -1.0, 1.0], [1.0, 0.0, -1.0]])
+    with pytest.raises(ValueError):
+        _spectral.decompose_rate_matrix(Qbad, [1 / 3.0] * 3)
+    with pytest.raises(ValueError):
+        _spectral.decompose_spectral(np.eye(3), [0.5, -0.1, 0.6])

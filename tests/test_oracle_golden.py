@@ -311,3 +311,28 @@ def test_chunk_forest_against_the_reference_chunk_trees():
             for row, (v, k, na, nb) in enumerate(rec['pieces']):
                 if nb == v:
                     assert int(node[c, v]) == int(piece[c * len(rec['pieces']) + row]) - lo
+
+
+def test_spectral_restatement_matches_the_reference_qtop():
+    """tests/golden/spectral.json: examples/p53/qtop.py's own decomposition and
+    reconstruction of its own random reversible rate matrices (first state of zero
+    stationary probability) and of the p53 codon matrix; next to scipy's expm of the same
+    matrix -- what qtop.py:587-609 (test_spectral_v2_expm) compares, at its atol."""
+    fx = load_golden('spectral')
+    for c in fx['cases']:
+        D, A, lam, B = (np.array(c[k]) for k in ('D', 'A', 'lam', 'B'))
+        for k, t in enumerate(c['t']):
+            got = orc.spectral_getp_v2(D, A, lam, B, t)
+            np.testing.assert_allclose(got, np.array(c['P_spectral'][k]), rtol=1e-13, atol=1e-15)
+            if k < len(c.get('P_expm', ())):
+                np.testing.assert_allclose(got, np.array(c['P_expm'][k]), rtol=0,
+                                           atol=1e-14 if c['n'] == 4 else 1e-12)
+        if 'S' in c:
+            # eigenvectors are fixed up to sign (and order within an eigenspace): compare
+            # what the factors reconstruct
+            A2, lam2, B2 = orc.spectral_decompose_v2(np.array(c['S']), D)
+            np.testing.assert_allclose(np.sort(lam2), np.sort(lam), rtol=1e-10, atol=1e-12)
+            for t in c['t']:
+                np.testing.assert_allclose(orc.spectral_getp_v2(D, A2, lam2, B2, t),
+                                           orc.spectral_getp_v2(D, A, lam, B, t),
+                                           rtol=1e-10, atol=1e-13)

@@ -917,6 +917,52 @@ def fixture_chunk_trees(mods, ncases=30):
     return dict(cases=cases)
 
 
+def fixture_spectral(mods):
+    """The reference's optional spectral path (examples/p53/qtop.py): its own random
+    reversible rate matrices (random_reversible_rate_matrix, :346-379: the first state has
+    zero stationary probability), the decomposition decompose_spectral_v2 (:142-150) and
+    getp_spectral_v2 (:76-88) at several branch lengths, next to getp_rate_matrix
+    (scipy.linalg.expm, :24-28) of the same matrix -- the two things qtop.py's own
+    test_spectral_v2_expm (:587-609) compares; plus the MG94 codon matrix of p53.py.
+    numpy.testing.run_module_suite no longer exists (qtop.py:16 imports it for its
+    __main__): the harness provides a stand-in."""
+    import numpy.testing as npt
+    if not hasattr(npt, 'run_module_suite'):
+        npt.run_module_suite = lambda *a, **k: None
+    sys.path.insert(0, REF + '/examples/p53')
+    import qtop
+    cases = []
+    np.random.seed(1234)                       # the seed of qtop.py:588
+    for n, ts in ((4, (0.23,)), (4, (0.01, 1.7)), (7, (0.05, 0.4, 3.0)), (20, (0.1, 2.5)),
+                  (33, (0.9,)), (61, (0.003, 1.4)), (64, (0.5,))):
+        S, D = qtop.random_reversible_rate_matrix(n)
+        if n == 4:                             # (its atol of 1e-15 is for the n = 4 of its tests)
+            qtop.assert_SD_reversible_rate_matrix(S, D)
+        Q = np.dot(S, np.diag(D))
+        A, lam, B = qtop.decompose_spectral_v2(S, D)
+        case = dict(n=n, D=D.tolist(), A=A.tolist(), lam=lam.tolist(), B=B.tolist(), t=list(ts),
+                    P_spectral=[qtop.getp_spectral_v2(D, A, lam, B, t).tolist() for t in ts])
+        if n <= 20:                            # (kept small: the large cases carry P_spectral only)
+            case['S'] = S.tolist()
+            case['P_expm'] = [qtop.getp_rate_matrix(Q, t).tolist() for t in ts]
+        cases.append(case)
+    # the codon matrix of the p53 example (tests/golden/p53_mg94.json holds the matrix itself):
+    # S = Q diag(1 / distn), D = distn
+    mg = fixture_p53_mg94(mods)
+    Q = np.array(mg['Q_offdiagonal'])
+    Q -= np.diag(Q.sum(axis=1))
+    D = np.array(mg['distn'])
+    S = Q / D[None, :]
+    S = 0.5 * (S + S.T)
+    A, lam, B = qtop.decompose_spectral_v2(S, D)
+    ts = (0.004, 0.31)
+    cases.append(dict(
+        n=len(D), mg94=True, D=D.tolist(), A=A.tolist(), lam=lam.tolist(), B=B.tolist(),
+        t=list(ts), P_spectral=[qtop.getp_spectral_v2(D, A, lam, B, t).tolist() for t in ts],
+        P_expm=[qtop.getp_rate_matrix(np.dot(S, np.diag(D)), ts[0]).tolist()]))
+    return dict(cases=cases)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(os.path.dirname(HERE),
@@ -947,6 +993,7 @@ def main():
         blinking=lambda: fixture_blinking(mods),
         forest=lambda: fixture_forest(mods),
         chunk_trees=lambda: fixture_chunk_trees(mods),
+        spectral=lambda: fixture_spectral(mods),
     )
     only = args.only.split(',') if args.only else list(makers)
     fixtures = dict((name, makers[name]()) for name in only)
