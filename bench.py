@@ -278,7 +278,7 @@ def run_workload(name, ctx, ctl, rank, world, reduce_kind, steps, warmup, args,
     assert np.isfinite(totals[0]) and totals[1] == 0, totals
     sampled = {}
     for key, kid in (('expm', _lib.RT_K_EXPM), ('prune', _lib.RT_K_PRUNE),
-                     ('reduce', _lib.RT_K_REDUCE)):
+                     ('reduce', _lib.RT_K_REDUCE), ('combine', _lib.RT_K_COMBINE)):
         ms, cnt, _ = ctx.kernel_time(kid)
         sampled[key] = dict(avg_us=(ms / cnt * 1e3) if cnt else None, launches=cnt)
 
@@ -292,6 +292,9 @@ def run_workload(name, ctx, ctl, rank, world, reduce_kind, steps, warmup, args,
     prune_ms, prune_cnt, prune_name = ctx.kernel_time(_lib.RT_K_PRUNE)
     expm_ms, expm_cnt, expm_name = ctx.kernel_time(_lib.RT_K_EXPM)
     red_ms, red_cnt, _ = ctx.kernel_time(_lib.RT_K_REDUCE)
+    # root-halves launches (csrc/jit.hip): the pruning slot holds the first kernel (all the
+    # arithmetic: what `roofline` prices), this slot the combine kernel that follows it
+    comb_ms, comb_cnt, comb_name = ctx.kernel_time(_lib.RT_K_COMBINE)
     ctx.set_timing(0)
 
     # ---- the interpreter kernel a fresh topology gets before (or without) its
@@ -397,6 +400,7 @@ def run_workload(name, ctx, ctl, rank, world, reduce_kind, steps, warmup, args,
         'kernels_us': {'expm': expm_ms / max(expm_cnt, 1) * 1e3,
                        'prune': avg_prune_s * 1e6,
                        'reduce': red_ms / max(red_cnt, 1) * 1e3,
+                       'combine': (comb_ms / comb_cnt * 1e3) if comb_cnt else None,
                        'expm_kernel': expm_name,
                        'launches_timed': prune_cnt,
                        'sampled_in_timed_region': sampled},

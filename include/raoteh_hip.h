@@ -63,7 +63,8 @@ extern "C" {
 #define RT_K_EXPM            0
 #define RT_K_PRUNE           1
 #define RT_K_REDUCE          2
-#define RT_K_COUNT           3
+#define RT_K_COMBINE         3   /* second kernel of a root-halves pruning launch */
+#define RT_K_COUNT           4
 
 typedef struct rt_ctx   rt_ctx;     /* one per GPU / process                 */
 typedef struct rt_model rt_model;   /* tree + transition matrices on device  */

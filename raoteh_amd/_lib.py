@@ -27,7 +27,7 @@ RT_ERR_SINGULAR = -6
 RT_ERR_ZERO_PROB = -7
 
 RT_OBS_DENSE, RT_OBS_STATE, RT_OBS_MASK = 0, 1, 2
-RT_K_EXPM, RT_K_PRUNE, RT_K_REDUCE = 0, 1, 2
+RT_K_EXPM, RT_K_PRUNE, RT_K_REDUCE, RT_K_COMBINE = 0, 1, 2, 3
 RT_SITE_ZERO_PROB = 1
 RT_SITE_NEGATIVE = 4
 

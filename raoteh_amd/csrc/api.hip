@@ -210,6 +210,31 @@ void rt_time_end(rt_ctx *ctx, int kernel, hipEvent_t start)
     if (s.pending.size() > 4096) drain_slot(s, false);
 }
 
+bool rt_time_extra_begin(rt_ctx *ctx, int kernel, const char *name, hipEvent_t *a, hipEvent_t *b)
+{
+    *a = *b = nullptr;
+    rt_timing_slot &s = ctx->slots[kernel];
+    if (name && name[0]) snprintf(s.name, sizeof(s.name), "%s", name);
+    if (!ctx->ev_start) return false;
+    hipEvent_t x = slot_event(s), y = slot_event(s);
+    if (!x || !y) {
+        if (x) s.pool.push_back(x);
+        if (y) s.pool.push_back(y);
+        return false;
+    }
+    *a = x;
+    *b = y;
+    return true;
+}
+
+void rt_time_extra_end(rt_ctx *ctx, int kernel, hipEvent_t a, hipEvent_t b)
+{
+    if (!a) return;
+    rt_timing_slot &s = ctx->slots[kernel];
+    s.pending.emplace_back(a, b);
+    if (s.pending.size() > 4096) drain_slot(s, false);
+}
+
 // ---- expm, host pointers ----------------------------------------------------------------
 
 extern "C" int rt_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *Q,
@@ -890,7 +915,8 @@ static int sites_alloc(rt_sites *s, bool generic)
         e = hipMalloc((void **)&s->d_scratch, s->scratch_bytes);
     }
     if (e == hipSuccess && s->jit_halves)      // [tile][half][k-step][lane] (jit.hip)
-        e = hipMalloc((void **)&s->d_half, (size_t)s->nblocks * 2 * ((n + 15) / 16) * 4 * 64 * 8);
+        e = hipMalloc((void **)&s->d_half,       // (padded to whole groups of <= 8 tiles)
+                      (size_t)(s->nblocks + 8) * 2 * ((n + 15) / 16) * 4 * 64 * 8);
     if (e == hipSuccess)
         e = hipMemcpy(s->d_ops, s->ops.data(), s->ops.size() * sizeof(rt_op),
                       hipMemcpyHostToDevice);
@@ -1021,24 +1047,35 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
             // workgroups, one per CU), 253 us at T = 2; a config-4 shard (7 813 tiles)
             // 1 984 us at T = 2, 2 040 us at T = 1, 2 303 us at T = 3.
             int T = (ntiles >= 2048 && s->ops.size() <= 300) ? 2 : 1;
-            if (const char *v = getenv("RAOTEH_JIT_TILES")) T = std::min(3, std::max(1, atoi(v)));
+            bool halves = T == 1 && want_root_halves(s, ntiles);
+            // Root halves with as many half-tiles per workgroup as make the launch ONE round
+            // of at most one workgroup per CU (3..5 independent chains per SIMD keep the pipe
+            // full, the whole register file): no dependence on where the dispatcher puts a
+            // second round.  Config 3: 1 250 half-tiles = 250 workgroups of 5 on 256 CUs.
+            if (halves && !getenv("RAOTEH_JIT_HALVES_T1")) {
+                const int64_t cus = std::max(1, s->model->ctx->num_cus);
+                const int64_t th = (2 * ntiles + cus - 1) / cus;
+                if (th >= 3 && th <= 5 && s->ops.size() <= 300) T = (int)th;
+            }
+            if (const char *v = getenv("RAOTEH_JIT_TILES"))
+                T = std::min(halves ? 5 : 3, std::max(1, atoi(v)));
             int D = 2, LA = 1;     // leaves fetched ahead (the pipelined generator needs >= 2)
             if (const char *v = getenv("RAOTEH_JIT_PREFETCH")) D = std::max(1, atoi(v));
             if (const char *v = getenv("RAOTEH_JIT_LOOKAHEAD")) LA = std::max(1, atoi(v));
             s->jit_prefetch = D;
             s->jit_lookahead = LA;
             int rc = RT_ERR_UNSUPPORTED;
-            bool halves = T == 1 && want_root_halves(s, ntiles);
-            for (; T >= 1 && rc == RT_ERR_UNSUPPORTED; --T) {     // fewer tiles if it spills
+            // fewer tiles if it spills: halves at T, halves at one tile, then the whole tree
+            while (rc == RT_ERR_UNSUPPORTED) {
                 const std::string src =
                     split_source(s->ops, (int)s->model->n, (int)s->nobs, T, D, LA, halves);
                 rc = rt_jit_get(s->model->ctx, src, &s->jit_fn, true, &s->jit_compile_s);
-                if (rc == RT_ERR_UNSUPPORTED && halves) {          // then the whole-tree form
-                    halves = false;
-                    ++T;
-                }
+                if (rc != RT_ERR_UNSUPPORTED) break;
+                if (halves && T > 1) T = 1;
+                else if (halves) halves = false;
+                else if (T > 1) --T;
+                else break;
             }
-            ++T;
             if (rc != RT_OK && (!forced || rc == RT_ERR_UNSUPPORTED)) {
                 s->jit_fn = nullptr;           // the interpreter kernel runs
                 return RT_OK;
@@ -1217,13 +1254,15 @@ extern "C" int rt_jit_source(int64_t nnodes, const int64_t *idx, const int64_t *
     for (auto &op : m.ops)
         if (node_obs[(size_t)op.node] >= 0) op.obs = k++;
     const int LA = getenv("RAOTEH_JIT_LOOKAHEAD") ? std::max(1, atoi(getenv("RAOTEH_JIT_LOOKAHEAD"))) : 2;
-    const int T = getenv("RAOTEH_JIT_TILES") ? std::min(4, std::max(1, atoi(getenv("RAOTEH_JIT_TILES")))) : 2;
+    const int T = getenv("RAOTEH_JIT_TILES") ? std::min(5, std::max(1, atoi(getenv("RAOTEH_JIT_TILES")))) : 2;
     const std::string src = n <= 4
         ? rt_jit_lane_source(m.ops, (int)n, (int)nobs, (int)prefetch, LA, 64, 4,
                              getenv("RAOTEH_JIT_SOURCE_STATES") != nullptr)
-        : n <= 32 ? rt_jit_mfma_source(m.ops, (int)n, (int)nobs, T, (int)prefetch, 1,
+        : n <= 32 ? rt_jit_mfma_source(m.ops, (int)n, (int)nobs, std::min(T, 4), (int)prefetch, 1,
                                        !(getenv("RAOTEH_JIT_QUAD") && atoi(getenv("RAOTEH_JIT_QUAD")) == 0))
-                  : split_source(m.ops, (int)n, (int)nobs, std::min(T, 3), (int)prefetch, 1,
+                  : split_source(m.ops, (int)n, (int)nobs,
+                                 getenv("RAOTEH_JIT_HALVES") && atoi(getenv("RAOTEH_JIT_HALVES"))
+                                     ? T : std::min(T, 3), (int)prefetch, 1,
                                  getenv("RAOTEH_JIT_HALVES") && atoi(getenv("RAOTEH_JIT_HALVES")));
     RT_REQUIRE((int64_t)src.size() + 1 <= capacity, "buffer too small: %lld bytes needed",
                (long long)src.size() + 1);

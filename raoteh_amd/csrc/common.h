@@ -214,6 +214,10 @@ struct rt_sites {
 
 void rt_time_begin(rt_ctx *ctx, int kernel, const char *name, hipEvent_t *start);
 void rt_time_end(rt_ctx *ctx, int kernel, hipEvent_t start);
+// a second kernel inside a launch that is being sampled (ctx->ev_start set): its own pair of
+// events in its own slot; false = not timed (a, b stay null)
+bool rt_time_extra_begin(rt_ctx *ctx, int kernel, const char *name, hipEvent_t *a, hipEvent_t *b);
+void rt_time_extra_end(rt_ctx *ctx, int kernel, hipEvent_t a, hipEvent_t b);
 
 // the reduction a launch may carry in one extra workgroup (partial == nullptr: none)
 struct rt_reduce_args {

@@ -1323,9 +1323,10 @@ void rt_jit_root_halves(const std::vector<rt_op> &ops, int *stepsA, int *stepsB)
 }
 
 // halves: the two root programs of split_at_root as the even / odd workgroups of one
-// launch (T = 1): twice as many workgroups of half the length, so that a batch of a few
-// tiles per CU spreads evenly (625 tiles on 256 CUs: three on the busiest CU and 2.44 on
-// average; 1 250 half-tiles: 5 halves = 2.5).  Each writes its root accumulator (own
+// launch: twice as many workgroups of half the length, so that a batch of a few tiles per
+// CU spreads evenly (625 tiles on 256 CUs: three on the busiest CU and 2.44 on average;
+// 1 250 half-tiles: 5 halves = 2.5 -- as 250 workgroups of T = 5 half-tiles each, one per
+// CU, or as 1 250 workgroups of one, three at a time per CU).  Each writes its root accumulator (own
 // rows) to halfbuf[tile][half][k-step][lane]; the module's second kernel, rt_jit_combine,
 // multiplies the two and runs the root step and the site epilogue unchanged.
 std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, int n, int K, int T,
@@ -1343,7 +1344,7 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
     std::vector<std::vector<pipe_step>> programs;
     if (halves) {
         std::vector<rt_op> opsA, opsB;
-        if (T != 1 || !split_at_root(ops, &opsA, &opsB)) return std::string();
+        if (!split_at_root(ops, &opsA, &opsB)) return std::string();
         int sa = 1, sb = 1;
         programs.push_back(pipeline_order(opsA, &sa));
         programs.push_back(pipeline_order(opsB, &sb));
@@ -1399,7 +1400,7 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
     o << "    const int lane = threadIdx.x & 63;\n";
     o << "    const int m = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // row tile of this wave\n";
     if (halves) {
-        o << "    const long tbase = (long)(blockIdx.x >> 1);\n";
+        o << "    const long tbase = (long)(blockIdx.x >> 1) * " << T << ";\n";
         o << "    const int half = (int)(blockIdx.x & 1);      // which root program\n";
     } else {
         o << "    const long tbase = (long)blockIdx.x * " << T << ";\n";
@@ -1573,11 +1574,14 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
             if (fold_pending) { emit_fold(o, i - 1); fold_pending = false; }
             if (halves) {
                 // this program's share of the root's accumulator (own rows) -> halfbuf
-                o << "    {\n    double *hb = halfbuf + ((size_t)tbase * 2 + " << prog << ") * " << XT
-                  << " + (4 * m) * 64 + lane;\n";
-                for (int r = 0; r < 4; ++r)
-                    o << "    hb[" << r * 64 << "] = a" << op.pop << "_0_" << r << ";\n";
-                o << "    }\n";
+                // (the buffer is padded to whole groups of T tiles: no bounds check)
+                for (int t = 0; t < T; ++t) {
+                    o << "    {\n    double *hb = halfbuf + ((size_t)tile" << t << " * 2 + " << prog
+                      << ") * " << XT << " + (4 * m) * 64 + lane;\n";
+                    for (int r = 0; r < 4; ++r)
+                        o << "    hb[" << r * 64 << "] = a" << op.pop << "_" << t << "_" << r << ";\n";
+                    o << "    }\n";
+                }
                 continue;
             }
             emit_x(o, i);
@@ -1671,7 +1675,11 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
     }   // programs
     if (halves) {
         o << "    }\n}\n";
-        // ---- second kernel of the module: root step + site epilogue from the two halves
+        // ---- second kernel of the module: root step + site epilogue from the two halves,
+        // one tile per workgroup whatever T is
+        const int T_main = T;
+        (void)T_main;
+        T = 1;
         const rt_op &root = ops.back();
         o << "extern \"C\" __global__ void __launch_bounds__(" << 64 * NT << ")\n"
              "rt_jit_combine(const double *__restrict__ halfbuf, const rt_d2 *__restrict__ obs,\n"
@@ -1923,23 +1931,26 @@ int rt_launch_prune_jit(rt_model *m, rt_sites *s)
     }
     if (s->jit_halves) {
         // split-M family, root halves: 2 workgroups per tile, then the combine kernel (one
-        // per tile); a sampled launch is stamped from the first kernel's begin to the
-        // second kernel's end
+        // per tile); in a sampled launch each kernel gets its own begin / end stamps (the
+        // pruning slot holds the first kernel, RT_K_COMBINE the second)
         double *half = s->d_half;
         const double *chalf = s->d_half;
         void *hargs[] = {&Pord, &obs, &root_w, &loglik, &status, &partial, &nsites, &nblocks, &half};
         void *cargs[] = {&chalf, &obs, &root_w, &loglik, &status, &partial, &nsites, &nblocks};
         const unsigned tpb = 64u * (unsigned)s->jit_waves;
         const unsigned tiles = (unsigned)s->nblocks;
+        const unsigned groups = (unsigned)((s->nblocks + s->jit_tiles - 1) / s->jit_tiles);
         if (m->ctx->ev_start) {
-            RT_HIP(hipExtModuleLaunchKernel((hipFunction_t)s->jit_fn, 2u * tiles * tpb, 1, 1, tpb, 1, 1,
+            hipEvent_t ca = nullptr, cb = nullptr;
+            rt_time_extra_begin(m->ctx, RT_K_COMBINE, "rt_jit_combine", &ca, &cb);
+            RT_HIP(hipExtModuleLaunchKernel((hipFunction_t)s->jit_fn, 2u * groups * tpb, 1, 1, tpb, 1, 1,
                                             0, m->ctx->stream, hargs, nullptr, m->ctx->ev_start,
-                                            nullptr, 0));
-            RT_HIP(hipExtModuleLaunchKernel((hipFunction_t)s->jit_combine, tiles * tpb, 1, 1, tpb, 1, 1,
-                                            0, m->ctx->stream, cargs, nullptr, nullptr,
                                             m->ctx->ev_stop, 0));
+            RT_HIP(hipExtModuleLaunchKernel((hipFunction_t)s->jit_combine, tiles * tpb, 1, 1, tpb, 1, 1,
+                                            0, m->ctx->stream, cargs, nullptr, ca, cb, 0));
+            rt_time_extra_end(m->ctx, RT_K_COMBINE, ca, cb);
         } else {
-            RT_HIP(hipModuleLaunchKernel((hipFunction_t)s->jit_fn, 2u * tiles, 1, 1, tpb, 1, 1, 0,
+            RT_HIP(hipModuleLaunchKernel((hipFunction_t)s->jit_fn, 2u * groups, 1, 1, tpb, 1, 1, 0,
                                          m->ctx->stream, hargs, nullptr));
             RT_HIP(hipModuleLaunchKernel((hipFunction_t)s->jit_combine, tiles, 1, 1, tpb, 1, 1, 0,
                                          m->ctx->stream, cargs, nullptr));

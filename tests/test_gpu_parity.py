@@ -672,16 +672,17 @@ def test_tree_specialised_kernel_is_bit_identical(ra, n):
         # n > 4 (MFMA family): 1..4 site tiles per wave instead
         # (n > 32: tiles per workgroup of NT waves, at most 3)
         # n > 32, 'h': the two root programs as separate workgroups + the combine kernel
+        # ('h5': five half-tiles per workgroup)
         variants = (((0, 0), (1, 64), (1, 49), (1, 7)) if n <= 4 else
                     ((0, 0), (1, 64), (1, 2), (1, 3), (1, 4)) if n <= 32 else
-                    ((0, 0), (1, 64), (1, 2), (1, 3), (1, 'h')))
+                    ((0, 0), (1, 64), (1, 2), (1, 3), (1, 'h'), (1, 'h5')))
         for jit, bs in variants:
             ra.lib.check(set_option(b'jit', jit))
             if n <= 4:
                 ra.lib.check(set_option(b'jit_block_sites', bs))
             elif jit:
-                os.environ['RAOTEH_JIT_TILES'] = str(1 if bs in (64, 'h') else bs)
-                os.environ['RAOTEH_JIT_HALVES'] = '1' if bs == 'h' else '0'
+                os.environ['RAOTEH_JIT_TILES'] = str(1 if bs in (64, 'h') else 5 if bs == 'h5' else bs)
+                os.environ['RAOTEH_JIT_HALVES'] = '1' if bs in ('h', 'h5') else '0'
             try:
                 batch = model.upload_sites(obs_nodes, dense, kind='dense')
                 ll, st = model.log_likelihoods(batch)
@@ -699,7 +700,8 @@ def test_tree_specialised_kernel_is_bit_identical(ra, n):
         for key in variants[1:]:
             assert out[key][3].startswith('prune_tree_jit'), out[key][3]
             # (a root with one child cannot be cut)
-            assert ('halves' in out[key][3]) == (key[1] == 'h' and T.degree(root) > 1), out[key][3]
+            assert ('halves' in out[key][3]) == (key[1] in ('h', 'h5') and T.degree(root) > 1), \
+                out[key][3]
             np.testing.assert_array_equal(out[0, 0][0], out[key][0])
             np.testing.assert_array_equal(out[0, 0][1], out[key][1])
             assert out[key][2][1] == out[0, 0][2][1] and out[key][2][2] == nsites

@@ -55,6 +55,11 @@ prune = None
 for k in out.get('FETCH_SIZE', {}):
     if 'prune' in k and 'pack' not in k:
         prune = k
+# the tree-specialised kernel is the measured path when the batch got one (the interpreter
+# kernel's few launches in the same trace are bench.py's side measurement)
+for k in out.get('FETCH_SIZE', {}):
+    if k.startswith('rt_jit_prune'):
+        prune = k
 if prune:
     f = out['FETCH_SIZE'][prune]['avg_kb'] * 1024.0
     wr = out.get('WRITE_SIZE', {}).get(prune, {}).get('avg_kb', 0.0) * 1024.0
