@@ -1488,8 +1488,8 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
     // observation stream positions in ISSUE order (the batch was packed in post-order
     // stream order: position = op.obs)
     std::vector<int> obs_order;
-    for (const pipe_step &p : st)
-        if (p.op.obs >= 0) obs_order.push_back(p.op.obs);
+    for (const pipe_step &p : st)      // (halves: the root's own observation is the combine kernel's)
+        if (p.op.obs >= 0 && !(halves && p.op.dst < 0)) obs_order.push_back(p.op.obs);
     std::vector<int> obs_rank((size_t)std::max(K, 1), -1);
     for (size_t k = 0; k < obs_order.size(); ++k) obs_rank[(size_t)obs_order[k]] = (int)k;
     auto emit_obs_load = [&](std::ostream &os, int pos) {       // pos = stream position (op.obs)

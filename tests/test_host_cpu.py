@@ -517,3 +517,60 @@ def test_spectral_host_mirror_decomposition():
         _spectral.decompose_rate_matrix(Qbad, [1 / 3.0] * 3)
     with pytest.raises(ValueError):
         _spectral.decompose_spectral(np.eye(3), [0.5, -0.1, 0.6])
+
+
+def test_root_halves_source_covers_every_step_once(monkeypatch):
+    """Split-M family, root halves (csrc/jit.hip split_at_root): the two root programs
+    together hold every product of the tree exactly once, each reads its own leaves only,
+    each ends by storing its share of the root's accumulator, and the module's second
+    kernel multiplies the shares in child order.  Random trees (roots with 1..4 children,
+    observed internal nodes), no device."""
+    import ctypes
+    import re
+    from raoteh_amd import _lib, synth
+    from raoteh_amd._tree import TreeArrays
+    p64 = ctypes.POINTER(ctypes.c_int64)
+    buf = ctypes.create_string_buffer(1 << 24)
+    monkeypatch.setenv('RAOTEH_JIT_HALVES', '1')
+    seen_cut = 0
+    for seed, nnodes, n, tiles in ((1, 9, 33, 1), (2, 14, 61, 1), (3, 23, 64, 5), (4, 31, 48, 3),
+                                   (5, 12, 61, 2), (6, 5, 40, 1)):
+        T, root, leaves = synth.random_tree(nnodes, seed=seed, max_children=4)
+        ta = TreeArrays(T, root)
+        inner = [v for v in T if v not in leaves]
+        obs_nodes = list(leaves) + inner[::2]
+        obs = np.array(sorted(ta.node_to_index[v] for v in obs_nodes), dtype=np.int64)
+        monkeypatch.setenv('RAOTEH_JIT_TILES', str(tiles))
+        rc = _lib.lib().rt_jit_source(
+            ta.nnodes, ta.indices.ctypes.data_as(p64), ta.indptr.ctypes.data_as(p64),
+            n, len(obs), obs.ctypes.data_as(p64), 2, buf, len(buf))
+        nchildren = T.degree(root)
+        if nchildren < 2:
+            # nothing to cut: the generator returns no source and the caller keeps the
+            # whole-tree form
+            assert rc < 0 or buf.value == b''
+            continue
+        _lib.check(rc)
+        seen_cut += 1
+        src = buf.value.decode()
+        ks = (n + 3) // 4
+        kp = (ks + 1) // 2
+        steps = ta.nnodes - 1
+        main, combine = src.split('rt_jit_combine(')
+        assert main.count('__builtin_amdgcn_mfma_f64_16x16x4f64') == steps * ks * tiles
+        assert len(re.findall(r'const rt_d2 A\d+_\d+ = [^;]*ag\[', main)) == steps * kp
+        progA, progB = main.split('    } else {\n', 1)
+        assert 'if (half == 0) {' in progA
+        # every observed non-root node is fetched by exactly one of the two programs
+        nonroot_obs = len(obs) - (1 if ta.node_to_index[root] in obs else 0)
+        loads = [set(re.findall(r'const rt_d2 o(\d+)_0_0 = ', p)) for p in (progA, progB)]
+        assert not (loads[0] & loads[1])
+        assert len(loads[0] | loads[1]) == nonroot_obs
+        for k, prog in enumerate((progA, progB)):
+            assert len(re.findall(r'double \*hb = halfbuf \+ \(\(size_t\)tile\d+ \* 2 \+ %d\)' % k,
+                                  prog)) == tiles
+        # the second kernel: product of the two shares (times the root's own observation)
+        assert len(re.findall(r'const double xr_0_\d = ha\[\d+\] \* ha\[\d+\]', combine)) == 4
+        assert ('ob_0' in combine) == (ta.node_to_index[root] in obs)
+        assert 'loglik[site]' in combine and 'loglik[site]' not in main
+    assert seen_cut >= 4
