@@ -673,6 +673,21 @@ expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ 
     double *Pb = P + (long)b * nn;
     const int qi = qidx[b];
     const int step = step_of_node ? step_of_node[b] : -1;
+    // LDS-resident sizes: rate matrix 0 is fetched before the workgroup knows which matrix
+    // it uses (one rate matrix for all edges is the common case; the others fetch again), so
+    // that the index and the matrix are one memory round trip, not two
+    constexpr int RP0 = GLOBAL ? 1 : TPB / RN;
+    constexpr int PER0 = GLOBAL ? 1 : (RN + RP0 - 1) / RP0;
+    double q0[PER0];
+    if (!GLOBAL) {
+        const int jc = tid % RN, g = tid / RN;
+#pragma unroll
+        for (int u = 0; u < PER0; ++u) {
+            const int i = g + u * RP0;
+            q0[u] = (g < RP0 && i < n && jc < n) ? Q[i * n + jc] : 0.0;
+        }
+    }
+    const double t_early = tt[b];
     if (qi < 0) {                              // root slot: zeros (_density.py:171)
         for (int e = tid; e < nn; e += TPB) Pb[e] = 0.0;
         if (info && tid == 0) { info[2 * b] = 0; info[2 * b + 1] = 0; }
@@ -688,7 +703,7 @@ expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ 
         return;
     }
     const double *Qb = Q + (long)qi * nn;
-    const double t = tt[b];
+    const double t = t_early;
     // A = Q t, zero-padded.  Thread = (column j, row group g): rows g, g + RP, ... of one
     // column -- consecutive threads read consecutive addresses, no index division, all of a
     // thread's loads in flight together (n <= 64: 16 of them), and the column's |.| sum
@@ -702,11 +717,15 @@ expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ 
         const bool active = g < RP;
         double v[PER];
         double part = 0.0;
+        if (qi > 0) {                                // (block-uniform)
 #pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int i = g + u * RP;
-            v[u] = (active && i < n && jc < n) ? Qb[i * n + jc] * t : 0.0;
+            for (int u = 0; u < PER; ++u) {
+                const int i = g + u * RP;
+                q0[u] = (active && i < n && jc < n) ? Qb[i * n + jc] : 0.0;
+            }
         }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) v[u] = q0[u] * t;
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int i = g + u * RP;
