@@ -397,7 +397,9 @@ def run_workload(name, ctx, ctl, rank, world, reduce_kind, steps, warmup, args,
                    'upload_and_pack_s': upload_s,
                    'interpreter_kernel': interp},
         'roofline': roof,
-        'kernels_us': {'expm': expm_ms / max(expm_cnt, 1) * 1e3,
+        # (expm None: the pruning launch computed the transitions itself -- n <= 4, one launch
+        # per step, kernel name '...,expm>')
+        'kernels_us': {'expm': (expm_ms / expm_cnt * 1e3) if expm_cnt else None,
                        'prune': avg_prune_s * 1e6,
                        'reduce': red_ms / max(red_cnt, 1) * 1e3,
                        'combine': (comb_ms / comb_cnt * 1e3) if comb_cnt else None,

@@ -395,6 +395,7 @@ extern "C" int rt_model_destroy(rt_model *m)
     hipFree(m->d_indices); hipFree(m->d_indptr); hipFree(m->d_ops); hipFree(m->d_P);
     hipFree(m->d_Pfrag); hipFree(m->d_Pquad); hipFree(m->d_root); hipFree(m->d_Q); hipFree(m->d_spec); hipFree(m->d_qidx);
     hipFree(m->d_t); hipFree(m->d_info); hipFree(m->d_step_of_node);
+    hipFree(m->d_qidx_step); hipFree(m->d_t_step);
     delete m;
     return RT_OK;
 }
@@ -447,6 +448,8 @@ extern "C" int rt_model_create(rt_ctx *ctx, int64_t nnodes, int64_t n,
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_qidx, nnodes * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_t, nnodes * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_info, nnodes * 8);
+    if (e == hipSuccess && n <= 4) e = hipMalloc((void **)&m->d_qidx_step, nnodes * 4);
+    if (e == hipSuccess && n <= 4) e = hipMalloc((void **)&m->d_t_step, nnodes * 8);
     if (e == hipSuccess && nnodes > 1)
         e = hipMemcpy(m->d_indices, idx, (nnodes - 1) * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(m->d_indptr, ptr, (nnodes + 1) * 8, hipMemcpyHostToDevice);
@@ -468,6 +471,33 @@ extern "C" int rt_model_create(rt_ctx *ctx, int64_t nnodes, int64_t n,
         return e == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_HIP;
     }
     *out = m;
+    return RT_OK;
+}
+
+// rate-matrix index and branch length of every edge, by node and (n <= 4) by schedule step:
+// an optimiser changes the rates far more often than the assignment of matrices to edges or
+// the branch lengths, so these go up only when they differ from what the device holds
+static int model_upload_edge_parameters(rt_model *m, const std::vector<int32_t> &qi,
+                                        const std::vector<double> &tt)
+{
+    if (qi != m->h_qidx) {
+        RT_HIP(hipMemcpy(m->d_qidx, qi.data(), m->nnodes * 4, hipMemcpyHostToDevice));
+        m->h_qidx = qi;
+        if (m->d_qidx_step) {
+            std::vector<int32_t> by_step(m->ops.size());
+            for (size_t k = 0; k < m->ops.size(); ++k) by_step[k] = qi[(size_t)m->ops[k].node];
+            RT_HIP(hipMemcpy(m->d_qidx_step, by_step.data(), by_step.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
+    if (tt != m->h_t) {
+        RT_HIP(hipMemcpy(m->d_t, tt.data(), m->nnodes * 8, hipMemcpyHostToDevice));
+        m->h_t = tt;
+        if (m->d_t_step) {
+            std::vector<double> by_step(m->ops.size());
+            for (size_t k = 0; k < m->ops.size(); ++k) by_step[k] = tt[(size_t)m->ops[k].node];
+            RT_HIP(hipMemcpy(m->d_t_step, by_step.data(), by_step.size() * 8, hipMemcpyHostToDevice));
+        }
+    }
     return RT_OK;
 }
 
@@ -534,14 +564,7 @@ extern "C" int rt_model_set_rates(rt_model *m, const double *Q, int64_t nq,
     RT_HIP(hipMemcpy(m->d_Q, Q, nq * nn * 8, hipMemcpyHostToDevice));
     // an optimiser changes the rates far more often than the assignment of matrices
     // to edges or the branch lengths: those go up only when they differ
-    if (qi != m->h_qidx) {
-        RT_HIP(hipMemcpy(m->d_qidx, qi.data(), m->nnodes * 4, hipMemcpyHostToDevice));
-        m->h_qidx = qi;
-    }
-    if (tt != m->h_t) {
-        RT_HIP(hipMemcpy(m->d_t, tt.data(), m->nnodes * 8, hipMemcpyHostToDevice));
-        m->h_t = tt;
-    }
+    RT_TRY(model_upload_edge_parameters(m, qi, tt));
     m->spectral = false;
     return model_run_expm(m);
 }
@@ -576,14 +599,7 @@ extern "C" int rt_model_set_rates_spectral(rt_model *m, const double *A, const d
     RT_HIP(hipMemcpy(m->d_spec + 2 * nn, lam, n * 8, hipMemcpyHostToDevice));
     if (D) RT_HIP(hipMemcpy(m->d_spec + 2 * nn + n, D, n * 8, hipMemcpyHostToDevice));
     m->spectral_has_D = D != nullptr;
-    if (qi != m->h_qidx) {
-        RT_HIP(hipMemcpy(m->d_qidx, qi.data(), m->nnodes * 4, hipMemcpyHostToDevice));
-        m->h_qidx = qi;
-    }
-    if (tt != m->h_t) {
-        RT_HIP(hipMemcpy(m->d_t, tt.data(), m->nnodes * 8, hipMemcpyHostToDevice));
-        m->h_t = tt;
-    }
+    RT_TRY(model_upload_edge_parameters(m, qi, tt));
     m->spectral = true;
     return model_run_expm(m);
 }
@@ -763,7 +779,7 @@ extern "C" int rt_sites_destroy(rt_sites *s)
     if (s->jit_fn2) rt_jit_ref(s->model->ctx, s->jit_fn2, -1);
     hipFree(s->d_ops); hipFree(s->d_lane_ops); hipFree(s->d_obs); hipFree(s->d_loglik); hipFree(s->d_status);
     if (s->model->ctx->comm_stream) hipStreamSynchronize(s->model->ctx->comm_stream);
-    hipFree(s->d_partial); hipFree(s->d_scratch); hipFree(s->d_half);
+    hipFree(s->d_partial); hipFree(s->d_partial_alt); hipFree(s->d_scratch); hipFree(s->d_half);
     if (s->totals_slot >= 0) {
         // keep the free list sorted (descending) so that batches created one after
         // the other keep getting neighbouring slots
@@ -899,6 +915,10 @@ static int sites_alloc(rt_sites *s, bool generic)
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_partial, s->npartials * 16);
     // entries no kernel writes (padding of the last workgroup) must read as zero
     if (e == hipSuccess) e = hipMemset(s->d_partial, 0, s->npartials * 16);
+    if (e == hipSuccess && s->jit_fused) {
+        e = hipMalloc((void **)&s->d_partial_alt, s->npartials * 16);
+        if (e == hipSuccess) e = hipMemset(s->d_partial_alt, 0, s->npartials * 16);
+    }
     if (e == hipSuccess) {
         rt_ctx *ctx = m->ctx;
         if (!ctx->totals_free.empty()) {
@@ -991,6 +1011,7 @@ struct jit_override {
     int T = 1, S = 64, WG = 1, D = 1, LA = 1, compact = 0;
     bool quad = false;
     bool halves = false;      // split-M family: the two root programs as separate workgroups
+    bool fuse = false;        // lane family: the kernel can compute its own transitions
     bool no_solo = false;     // n <= 32: the split-M interpreter kernel, not the one-wave one
 };
 
@@ -1002,7 +1023,8 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
         const bool mfma = s->layout == RT_LAYOUT_MFMA;
         const bool split = mfma && (n > 32 || !s->mfma_solo);
         const std::string src =
-            !mfma ? rt_jit_lane_source(s->ops, n, K, ov->D, ov->LA, ov->S, ov->WG, ov->compact)
+            !mfma ? rt_jit_lane_source(s->ops, n, K, ov->D, ov->LA, ov->S, ov->WG, ov->compact,
+                                       ov->fuse)
             : split ? split_source(s->ops, n, K, ov->T, ov->D, ov->LA, ov->halves)
                     : rt_jit_mfma_source(s->ops, n, K, ov->T, ov->D, ov->LA, ov->quad);
         RT_TRY(rt_jit_get(s->model->ctx, src, &s->jit_fn, mfma));
@@ -1015,6 +1037,7 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
             s->block_sites = ov->S;
             s->jit_waves = ov->WG;
             s->compact_states = ov->compact;
+            s->jit_fused = ov->fuse;
         } else if (split) {
             s->jit_waves = (n + 15) / 16;
         }
@@ -1214,8 +1237,14 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
     if (const char *v = getenv("RAOTEH_JIT_WAVES")) WG = atoi(v);
     S = std::min(64, std::max(1, S));
     WG = std::min(8, std::max(1, WG));
+    // RAOTEH_JIT_FUSE_EXPM=1: the kernel that can run a whole step in ONE launch (jit.hip).
+    // Correct (test_single_launch_step_is_the_two_launch_step) and NOT the default: measured on
+    // config 2 the fused kernel takes 39.3 us where the plain one takes 33.0 and the expm
+    // launch 4.8 -- every workgroup repeats the ~6 us of load + dependent f64 latency of the
+    // exponentials at its start, with its HBM stream idle -- and the step 41.8 us against 41.1.
+    const bool fuse = getenv("RAOTEH_JIT_FUSE_EXPM") && atoi(getenv("RAOTEH_JIT_FUSE_EXPM")) != 0;
     const std::string src =
-        rt_jit_lane_source(s->ops, (int)s->model->n, (int)s->nobs, D, LA, S, WG, states);
+        rt_jit_lane_source(s->ops, (int)s->model->n, (int)s->nobs, D, LA, S, WG, states, fuse);
     s->jit_prefetch = D;
     s->jit_lookahead = LA;
     const int rc = rt_jit_get(s->model->ctx, src, &s->jit_fn, false, &s->jit_compile_s);
@@ -1229,6 +1258,7 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
         s->block_sites = S;
         s->jit_waves = WG;
         s->compact_states = states;
+        s->jit_fused = fuse;
     }
     return rc;
 }
@@ -1257,7 +1287,8 @@ extern "C" int rt_jit_source(int64_t nnodes, const int64_t *idx, const int64_t *
     const int T = getenv("RAOTEH_JIT_TILES") ? std::min(5, std::max(1, atoi(getenv("RAOTEH_JIT_TILES")))) : 2;
     const std::string src = n <= 4
         ? rt_jit_lane_source(m.ops, (int)n, (int)nobs, (int)prefetch, LA, 64, 4,
-                             getenv("RAOTEH_JIT_SOURCE_STATES") != nullptr)
+                             getenv("RAOTEH_JIT_SOURCE_STATES") != nullptr,
+                             getenv("RAOTEH_JIT_FUSE_EXPM") && atoi(getenv("RAOTEH_JIT_FUSE_EXPM")) != 0)
         : n <= 32 ? rt_jit_mfma_source(m.ops, (int)n, (int)nobs, std::min(T, 4), (int)prefetch, 1,
                                        !(getenv("RAOTEH_JIT_QUAD") && atoi(getenv("RAOTEH_JIT_QUAD")) == 0))
                   : split_source(m.ops, (int)n, (int)nobs,
@@ -1372,6 +1403,7 @@ static int sites_create_impl(rt_model *m, int64_t nsites, int kind, int64_t nobs
             s->jit_quad = false;
             s->jit_halves = false;
             s->jit_combine = nullptr;
+            s->jit_fused = false;
         }
     }
     if (rc == RT_OK) rc = sites_alloc(s, generic);
@@ -1478,6 +1510,7 @@ static int verify_jit_kernel(rt_sites *s, int kind)
     same.compact = s->compact_states;
     same.quad = s->jit_quad;
     same.halves = s->jit_halves;
+    same.fuse = s->jit_fused;
     if (rc == RT_OK)
         rc = sites_create_impl(tm, np, pkind, K, obs_nodes.data(), data, &interp, &si);
     if (rc == RT_OK)
@@ -1540,6 +1573,7 @@ extern "C" int rt_sites_clone(rt_sites *src, rt_sites **out)
     s->jit_quad = src->jit_quad;
     s->jit_halves = src->jit_halves;
     s->jit_combine = src->jit_combine;
+    s->jit_fused = src->jit_fused;
     s->compact_states = src->compact_states;
     s->node_obs = src->node_obs;
     s->ops = src->ops;
@@ -1611,10 +1645,14 @@ extern "C" int rt_step(rt_model *m, rt_sites *s, int recompute_transitions)
     RT_REQUIRE(recompute_transitions || m->have_P,
                "the model has no transition matrices yet");
     RT_HIP(hipSetDevice(m->ctx->device));
-    if (recompute_transitions) RT_TRY(model_run_expm(m));
-    // the batch sum is reduced by the next step's expm launch (or by whoever reads the
-    // totals first): two launches per step instead of three
-    return rt_launch_prune(m, s, true);
+    // n <= 4 and a tree-specialised kernel: the pruning launch computes the transitions from
+    // the resident rates itself (and carries the previous step's batch sum): ONE launch
+    const bool fuse = recompute_transitions && s->jit_fused && s->jit_fn && !m->spectral &&
+                      m->d_Q && !getenv("RAOTEH_NO_DEFER_REDUCE");
+    if (recompute_transitions && !fuse) RT_TRY(model_run_expm(m));
+    // the batch sum is reduced by the next step's first launch (or by whoever reads the
+    // totals first)
+    return rt_launch_prune(m, s, true, fuse);
 }
 
 extern "C" int rt_sites_get_logliks(rt_sites *s, double *loglik, int32_t *status)

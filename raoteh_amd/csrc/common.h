@@ -144,6 +144,11 @@ struct rt_model {
     double *d_t = nullptr;          // [nnodes]
     int32_t *d_info = nullptr;      // [nnodes][2]
     int32_t *d_step_of_node = nullptr;  // [nnodes] schedule step of each node
+    // the same rate-matrix indices / branch lengths in STEP order (the root's step: -1, 0): a
+    // lane kernel that computes its own transitions reads them at its thread index, with no
+    // step -> node lookup in front of the loads (n <= 4 only)
+    int32_t *d_qidx_step = nullptr;
+    double *d_t_step = nullptr;
     bool have_P = false;
     bool frag_dirty = true;
 };
@@ -196,6 +201,12 @@ struct rt_sites {
     // split-M family, root halves (jit.hip): the two root programs run as the even / odd
     // workgroups of jit_fn and leave their share of the root's accumulator in d_half
     // ([tile][half][k-step][lane]); jit_combine (same module) finishes the sites
+    // lane family: the kernel can compute the transition matrices of a step in its own
+    // prologue (jit.hip, `fuse`); rt_step then launches ONE kernel.  The batch sum of step j
+    // rides as an extra workgroup of step j + 1's launch while that launch writes its own
+    // partial sums: two buffers, swapped at every such launch
+    bool jit_fused = false;
+    double *d_partial_alt = nullptr;
     bool jit_halves = false;
     void *jit_combine = nullptr;
     double *d_half = nullptr;
@@ -253,10 +264,17 @@ int rt_flush_reduce(rt_ctx *ctx);
             hipLaunchKernelGGL(kern, grid, block, lds, (ctx)->stream, __VA_ARGS__);     \
     } while (0)
 int rt_launch_pfrag(rt_model *m);
-int rt_launch_prune(rt_model *m, rt_sites *s, bool defer_reduce = false);
+// fuse_expm: the pruning launch computes the transitions from the resident rates itself
+// (batches with jit_fused only) and carries the pending reduction
+int rt_launch_prune(rt_model *m, rt_sites *s, bool defer_reduce = false, bool fuse_expm = false);
+// what such a launch is handed besides the pruning arguments
+struct rt_fuse_args {
+    rt_reduce_args red;     // partial == nullptr: nothing carried
+    bool expm = false;      // compute the transitions (else copy the resident table)
+};
 // jit.hip
 std::string rt_jit_lane_source(const std::vector<rt_op> &ops, int n, int K, int D, int LA,
-                               int S, int WG, int compact = 0);
+                               int S, int WG, int compact = 0, bool fuse = false);
 std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int T, int D, int LA,
                                bool quad = false);
 std::string rt_jit_mfma_split_source(const std::vector<rt_op> &ops, int n, int K, int T, int D,
@@ -277,7 +295,7 @@ int rt_jit_verified(const rt_ctx *ctx, void *fn);
 void rt_jit_set_verified(const rt_ctx *ctx, void *fn, bool ok);
 void rt_jit_release(const rt_ctx *ctx);
 int rt_jit_read_global(const rt_ctx *ctx, void *fn, const char *name, void *dst, size_t bytes);
-int rt_launch_prune_jit(rt_model *m, rt_sites *s);
+int rt_launch_prune_jit(rt_model *m, rt_sites *s, const rt_fuse_args *fuse = nullptr);
 // a batch that runs the interpreter kernels only (no tree-specialised kernel is compiled)
 int rt_sites_create_interpreter(rt_model *m, int64_t nsites, int kind, int64_t nobs,
                                 const int64_t *obs_nodes, const void *data, rt_sites **out);

@@ -883,41 +883,9 @@ expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ 
 // swaps + back substitution.
 // ---------------------------------------------------------------------------
 
-template <int N>
-struct SmallMat {
-    double a[N][N];
-};
-
-template <int N>
-__device__ __forceinline__ void sm_mul(const SmallMat<N> &A, const SmallMat<N> &B,
-                                       SmallMat<N> &C)
-{
-    SmallMat<N> T;
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            double acc = A.a[i][0] * B.a[0][j];
-#pragma unroll
-            for (int k = 1; k < N; ++k) acc = fma(A.a[i][k], B.a[k][j], acc);
-            T.a[i][j] = acc;
-        }
-    C = T;
-}
-
-// C = alpha*A + beta*B + gamma*Cin + delta*I   (any of the matrices may be unused)
-template <int N>
-__device__ __forceinline__ void sm_comb(SmallMat<N> &out, double ca, const SmallMat<N> &A,
-                                        double cb, const SmallMat<N> &B, double cc,
-                                        const SmallMat<N> &C, double ci)
-{
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-#pragma unroll
-        for (int j = 0; j < N; ++j)
-            out.a[i][j] = ca * A.a[i][j] + cb * B.a[i][j] + cc * C.a[i][j] +
-                          (i == j ? ci : 0.0);
-}
+#define RT_SHARED_SOURCE(...) __VA_ARGS__
+#include "expm_small.inc"
+#undef RT_SHARED_SOURCE
 
 template <int N>
 __global__ void __launch_bounds__(256)
@@ -1073,19 +1041,10 @@ expm_small_kernel(int count, const double *__restrict__ Q, const int *__restrict
 // up to 6 products plus an LU factorisation with predicated row swaps for the Pade form
 // above -- this kernel is one wave of dependent register arithmetic, and on config 2 it
 // sits in front of a 34 us pruning kernel in every step.
-// 1 / i! as a compile-time expression: with the Horner loop unrolled every coefficient is an
-// instruction literal.  (Indexed by the per-lane order m, the table in constant memory was
-// a per-lane gather -- one dependent memory round trip for the seed of the recurrence and one
-// more per Horner step, most of this kernel's 6.8 us on config 2.)
-__device__ __forceinline__ constexpr double inv_fact_lit(int i)
-{
-    constexpr double f[16] = {
-        1.0, 1.0, 0.5, 1.0 / 6.0, 1.0 / 24.0, 1.0 / 120.0, 1.0 / 720.0, 1.0 / 5040.0,
-        1.0 / 40320.0, 1.0 / 362880.0, 1.0 / 3628800.0, 1.0 / 39916800.0, 1.0 / 479001600.0,
-        1.0 / 6227020800.0, 1.0 / 87178291200.0, 1.0 / 1307674368000.0};
-    return f[i];
-}
-
+// (inv_fact_lit of expm_small.inc: 1 / i! as a compile-time expression -- with the Horner loop
+// unrolled every coefficient is an instruction literal.  Indexed by the per-lane order m, the
+// table in constant memory was a per-lane gather: one dependent memory round trip for the
+// seed of the recurrence and one more per Horner step.)
 template <int N>
 __global__ void __launch_bounds__(256)
 expm_small_taylor_kernel(int count, const double *__restrict__ Q, const int *__restrict__ qidx,
@@ -1132,74 +1091,12 @@ expm_small_taylor_kernel(int count, const double *__restrict__ Q, const int *__r
     for (int i = 0; i < N; ++i)
 #pragma unroll
         for (int j = 0; j < N; ++j) A.a[i][j] *= t;
-    double nrm = 0.0;
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        double cs = 0.0;
-#pragma unroll
-        for (int i = 0; i < N; ++i) cs += fabs(A.a[i][j]);
-        nrm = fmax(nrm, cs);
-    }
-    // (the thresholds of c_theta_taylor as literals)
-    int m = 15, s = 0;
-    if (!(nrm < 1e300)) m = -1;
-    else if (nrm <= 1.3863479e-5) m = 3;
-    else if (nrm <= 9.0656564e-3) m = 6;
-    else if (nrm <= 8.9577602e-2) m = 9;
-    else if (nrm <= 2.9961589e-1) m = 12;
-    else if (nrm > 6.4108352e-1) {
-        int e;
-        const double f = frexp(nrm / 6.4108352e-1, &e);
-        s = (f == 0.5) ? e - 1 : e;
-        if (s < 0) s = 0;
-    }
-    if (info) { info[2 * b] = m; info[2 * b + 1] = s; }
+    // the arithmetic itself: expm_small.inc, shared with the lane kernels that compute their
+    // own transition matrices (jit.hip)
     SmallMat<N> X;
-    if (m < 0) {
-#pragma unroll
-        for (int i = 0; i < N; ++i)
-#pragma unroll
-            for (int j = 0; j < N; ++j) X.a[i][j] = __builtin_nan("");
-    } else {
-        if (s > 0) {
-            const double sc = ldexp(1.0, -s);
-#pragma unroll
-            for (int i = 0; i < N; ++i)
-#pragma unroll
-                for (int j = 0; j < N; ++j) A.a[i][j] *= sc;
-        }
-        SmallMat<N> A2, A3;
-        sm_mul(A, A, A2);
-        sm_mul(A, A2, A3);
-        const int q = m / 3;                   // 1..5
-        // seed: c[3(q-1)] I + c[3(q-1)+1] A + c[3(q-1)+2] A^2 + c[3q] A^3
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-        for (int qq = 1; qq <= 5; ++qq)
-            if (q == qq) {
-                s0 = inv_fact_lit(3 * qq - 3);
-                s1 = inv_fact_lit(3 * qq - 2);
-                s2 = inv_fact_lit(3 * qq - 1);
-                s3 = inv_fact_lit(3 * qq);
-            }
-        sm_comb(X, s1, A, s2, A2, s3, A3, s0);
-#pragma unroll
-        for (int jj = 3; jj >= 0; --jj) {
-            if (jj <= q - 2) {
-                SmallMat<N> Y;
-                sm_mul(A3, X, Y);
-                // X = Y + c A + c A^2 + c I
-#pragma unroll
-                for (int i = 0; i < N; ++i)
-#pragma unroll
-                    for (int j = 0; j < N; ++j)
-                        X.a[i][j] = Y.a[i][j] + (inv_fact_lit(3 * jj + 1) * A.a[i][j] +
-                                                 inv_fact_lit(3 * jj + 2) * A2.a[i][j] +
-                                                 (i == j ? inv_fact_lit(3 * jj) : 0.0));
-            }
-        }
-        for (int r = 0; r < s; ++r) sm_mul(X, X, X);
-    }
+    int m, s;
+    rt_expm_small_taylor<N>(A, X, m, s);
+    if (info) { info[2 * b] = m; info[2 * b + 1] = s; }
 #pragma unroll
     for (int i = 0; i < N; ++i)
 #pragma unroll

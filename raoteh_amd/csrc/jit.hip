@@ -43,6 +43,18 @@ struct jit_entry {
     bool rejected = false;          // compiled, loaded, and found WRONG on the probe batch
 };
 
+// source text shared with the library's own kernels (expm_small.inc, reduce_body.inc): the
+// n <= 4 exponential and the fixed-order batch sum, for lane kernels that compute the
+// transition matrices of a step in their prologue (`fuse`)
+#define RT_SHARED_SOURCE(...) #__VA_ARGS__
+const char *const k_expm_small_src =
+#include "expm_small.inc"
+    ;
+const char *const k_reduce_src =
+#include "reduce_body.inc"
+    ;
+#undef RT_SHARED_SOURCE
+
 std::mutex g_jit_mutex;
 std::map<std::pair<const rt_ctx *, std::string>, jit_entry> g_jit_cache;   // (context, source)
 
@@ -99,8 +111,16 @@ static std::string half_pair_load(const std::string &addr, bool nontemporal)
 // and lane ([block][word][lane]).  64 bytes per site instead of 2 KB: the kernel is
 // no longer bound by HBM; the arithmetic is unchanged, so the results are those of
 // the dense encoding bit for bit.
+// fuse: the kernel can compute the transition matrices itself.  With `fq` non-null every
+// workgroup runs the n <= 4 exponential of every edge into its LDS copy of the P table
+// (thread = step; the text of the library's own kernel, expm_small.inc) instead of copying the
+// table the expm launch left in global memory; workgroup 0 also leaves the matrices where
+// that launch would have left them (esd order, step order, order / squarings), and one extra
+// workgroup at the end of the grid may carry the pending batch-sum reduction, as an expm
+// launch does.  One launch per step instead of two: on config 2 the boundary between two
+// dependent launches costs more than the small kernel behind it.
 std::string rt_jit_lane_source(const std::vector<rt_op> &ops, int n, int K, int D, int LA,
-                               int S, int WG, int compact)
+                               int S, int WG, int compact, bool fuse)
 {
     const bool states = compact != 0;       // 1: uint8 states, 2: allowed-set masks (bytes)
     const bool masks = compact == 2;
@@ -118,6 +138,12 @@ std::string rt_jit_lane_source(const std::vector<rt_op> &ops, int n, int K, int 
       << K << " observed nodes, prefetch distance " << D << " leaves / " << LA
       << " P records, " << S << " sites per wave, " << WG << " waves per workgroup\n";
     o << "typedef double rt_d2 __attribute__((ext_vector_type(2)));\n";
+    if (fuse) {
+        o << k_expm_small_src << "\n" << k_reduce_src << "\n";
+        o << "__constant__ short rt_step_node[" << nrec << "] = {";
+        for (int i = 0; i < nrec; ++i) o << (i ? ", " : "") << (int)ops[(size_t)i].node;
+        o << "};\n";
+    }
     // WG waves per workgroup share one copy of the step-ordered P table in LDS
     // (16 KB for 64 leaves x 4 states).  The host picks S (and WG = 1 by default)
     // so that a batch that fits the chip in one round puts the same number of
@@ -155,7 +181,19 @@ std::string rt_jit_lane_source(const std::vector<rt_op> &ops, int n, int K, int 
          "rt_jit_prune(const double *__restrict__ Pord, const rt_d2 *__restrict__ obs,\n"
          "             const double *__restrict__ root_w, double *__restrict__ loglik,\n"
          "             int *__restrict__ status, double *__restrict__ partial,\n"
-         "             long nsites, long nblocks)\n{\n";
+         "             long nsites, long nblocks";
+    if (fuse)
+        o << ",\n             const double *__restrict__ fq, const int *__restrict__ fqidx,\n"
+             "             const double *__restrict__ ftt, double *__restrict__ fP,\n"
+             "             double *__restrict__ fPord, int *__restrict__ finfo,\n"
+             "             const double *__restrict__ red_partial, long red_npartials,\n"
+             "             double *__restrict__ red_totals, double red_nsites";
+    o << ")\n{\n";
+    if (fuse)
+        o << "    if (red_partial && blockIdx.x == gridDim.x - 1) {      // the carried reduction\n"
+             "        rt_reduce_partials_body(red_partial, red_npartials, red_totals, red_nsites);\n"
+             "        return;\n"
+             "    }\n";
     o << "    __shared__ __attribute__((aligned(16))) double pl[" << total + (total & 1) << "];\n";
     if (G > 0) o << "    __shared__ double pg[" << G * n * W << "];\n";
     o << "    const int lane = threadIdx.x & 63;\n";
@@ -218,6 +256,56 @@ std::string rt_jit_lane_source(const std::vector<rt_op> &ops, int n, int K, int 
     // (LDS and VMEM each return in order).
     // the HBM stream starts first; the P table (L2) is staged behind it
     for (int k = 0; k < std::min(D, K); ++k) emit_load(k);
+    if (fuse) {
+        const int NN = n * n;
+        o << "    if (fq) {\n"
+             "        for (int k = threadIdx.x; k < " << nrec << "; k += " << NT << ") {\n"
+             "            const int qi = fqidx[k];      // in step order: no lookup before the loads\n"
+             "            const double t = ftt[k];\n"
+             "            SmallMat<" << n << "> A, X;\n"
+             "            _Pragma(\"unroll\")\n"
+             "            for (int i = 0; i < " << n << "; ++i)\n"
+             "                _Pragma(\"unroll\")\n"
+             "                for (int j = 0; j < " << n << "; ++j) A.a[i][j] = fq[i * " << n << " + j];\n"
+             "            int em = 0, es = 0;\n"
+             "            if (qi < 0) {             // the root's step: zeros (_density.py:171)\n"
+             "                _Pragma(\"unroll\")\n"
+             "                for (int i = 0; i < " << n << "; ++i)\n"
+             "                    _Pragma(\"unroll\")\n"
+             "                    for (int j = 0; j < " << n << "; ++j) X.a[i][j] = 0.0;\n"
+             "            } else {\n"
+             "                if (qi > 0) {\n"
+             "                    const double *Qb = fq + (long)qi * " << NN << ";\n"
+             "                    _Pragma(\"unroll\")\n"
+             "                    for (int i = 0; i < " << n << "; ++i)\n"
+             "                        _Pragma(\"unroll\")\n"
+             "                        for (int j = 0; j < " << n << "; ++j) A.a[i][j] = Qb[i * " << n << " + j];\n"
+             "                }\n"
+             "                _Pragma(\"unroll\")\n"
+             "                for (int i = 0; i < " << n << "; ++i)\n"
+             "                    _Pragma(\"unroll\")\n"
+             "                    for (int j = 0; j < " << n << "; ++j) A.a[i][j] *= t;\n"
+             "                rt_expm_small_taylor<" << n << ">(A, X, em, es);\n"
+             "            }\n"
+             "            _Pragma(\"unroll\")\n"
+             "            for (int i = 0; i < " << n << "; ++i)\n"
+             "                _Pragma(\"unroll\")\n"
+             "                for (int j = 0; j < " << n << "; ++j) {\n"
+             "                    pl[k * " << NN << " + i * " << n << " + j] = X.a[i][j];\n"
+             "                }\n"
+             "            if (blockIdx.x == 0) {\n"
+             "                const int node = rt_step_node[k];\n"
+             "                _Pragma(\"unroll\")\n"
+             "                for (int e = 0; e < " << NN << "; ++e) {\n"
+             "                    fPord[(long)k * " << NN << " + e] = X.a[e / " << n << "][e % " << n << "];\n"
+             "                    fP[(long)node * " << NN << " + e] = X.a[e / " << n << "][e % " << n << "];\n"
+             "                }\n"
+             "                finfo[2 * node] = em;\n"
+             "                finfo[2 * node + 1] = es;\n"
+             "            }\n"
+             "        }\n"
+             "    } else\n";
+    }
     o << "    {\n"
          "        const rt_d2 *src = (const rt_d2 *)Pord;\n"
          "        rt_d2 *dst = (rt_d2 *)pl;\n"
@@ -1884,8 +1972,38 @@ void rt_jit_release(const rt_ctx *ctx)
     }
 }
 
-int rt_launch_prune_jit(rt_model *m, rt_sites *s)
+int rt_launch_prune_jit(rt_model *m, rt_sites *s, const rt_fuse_args *fuse)
 {
+    if (s->jit_fused && s->layout == RT_LAYOUT_LANE) {
+        // lane kernel with the fused prologue: the same kernel runs a plain pruning launch
+        // (fq == nullptr: it copies the resident P table) and a whole step
+        static const rt_fuse_args none;
+        const rt_fuse_args &f = fuse ? *fuse : none;
+        const double *Pord = m->d_Pfrag, *obs = s->d_obs, *root_w = m->d_root;
+        double *loglik = s->d_loglik, *partial = s->d_partial;
+        int *status = s->d_status;
+        long nsites = (long)s->nsites, nblocks = (long)s->nblocks;
+        const double *fq = f.expm ? m->d_Q : nullptr, *ftt = m->d_t_step;
+        const int *fqidx = m->d_qidx_step;
+        double *fP = m->d_P, *fPord = m->d_Pfrag;
+        int *finfo = m->d_info;
+        const double *rp = f.red.partial;
+        long rn = f.red.npartials;
+        double *rtot = f.red.totals;
+        double rns = f.red.nsites;
+        void *args[] = {&Pord, &obs, &root_w, &loglik, &status, &partial, &nsites, &nblocks,
+                        &fq, &fqidx, &ftt, &fP, &fPord, &finfo, &rp, &rn, &rtot, &rns};
+        const int wg = s->jit_waves;
+        const unsigned groups = (unsigned)((s->nblocks + wg - 1) / wg) + (rp ? 1u : 0u);
+        if (m->ctx->ev_start)
+            RT_HIP(hipExtModuleLaunchKernel((hipFunction_t)s->jit_fn, groups * 64u * wg, 1, 1, 64 * wg,
+                                            1, 1, 0, m->ctx->stream, args, nullptr,
+                                            m->ctx->ev_start, m->ctx->ev_stop, 0));
+        else
+            RT_HIP(hipModuleLaunchKernel((hipFunction_t)s->jit_fn, groups, 1, 1, 64 * wg, 1, 1, 0,
+                                         m->ctx->stream, args, nullptr));
+        return RT_OK;
+    }
     const double *Pord = s->jit_quad ? m->d_Pquad : m->d_Pfrag;
     const double *obs = s->d_obs;
     const double *root_w = m->d_root;

@@ -1526,27 +1526,42 @@ int rt_flush_reduce(rt_ctx *ctx)
     return RT_OK;
 }
 
-int rt_launch_prune(rt_model *m, rt_sites *s, bool defer_reduce)
+int rt_launch_prune(rt_model *m, rt_sites *s, bool defer_reduce, bool fuse_expm)
 {
     rt_ctx *ctx = m->ctx;
     const char *name = "";
     hipEvent_t ev = nullptr;
-    // a reduction still pending reads d_partial of ITS batch: if that is this batch, it
-    // must run before the pruning kernel overwrites the partial sums
-    if (ctx->pending_reduce) RT_TRY(rt_flush_reduce(ctx));
+    rt_fuse_args fuse;
+    if (fuse_expm && s->jit_fused && s->jit_fn) {
+        // one launch: transitions from the resident rates in the kernel's prologue, the pending
+        // reduction (of whichever batch) in an extra workgroup.  That reduction reads the
+        // partial sums of ITS batch while this launch writes its own: if it is this batch,
+        // the two must be different buffers
+        fuse.expm = true;
+        if (!rt_take_pending_reduce(ctx, &fuse.red) && ctx->pending_reduce) RT_TRY(rt_flush_reduce(ctx));
+        std::swap(s->d_partial, s->d_partial_alt);
+        m->have_P = true;
+        m->frag_dirty = false;        // workgroup 0 leaves the step-ordered table behind
+    } else {
+        fuse_expm = false;
+        // a reduction still pending reads d_partial of ITS batch: if that is this batch, it
+        // must run before the pruning kernel overwrites the partial sums
+        if (ctx->pending_reduce) RT_TRY(rt_flush_reduce(ctx));
+    }
     // which family this batch was packed for
     const bool generic = s->d_scratch != nullptr;
-    if (!generic) RT_TRY(rt_launch_pfrag(m));
+    if (!generic && !fuse_expm) RT_TRY(rt_launch_pfrag(m));
     rt_time_begin(ctx, RT_K_PRUNE, "", &ev);
     int rc;
     char *jit_name = s->kernel_name;
     if (generic) rc = launch_generic(m, s, &name);
     else if (s->jit_fn) {
-        rc = rt_launch_prune_jit(m, s);
+        rc = rt_launch_prune_jit(m, s, s->jit_fused ? &fuse : nullptr);
         if (s->layout == RT_LAYOUT_LANE)
-            snprintf(jit_name, sizeof(s->kernel_name), "prune_tree_jit<%d,D%d%s>", (int)m->n,
+            snprintf(jit_name, sizeof(s->kernel_name), "prune_tree_jit<%d,D%d%s%s>", (int)m->n,
                      s->jit_prefetch, s->compact_states == 1 ? ",states"
-                                      : s->compact_states == 2 ? ",masks" : "");
+                                      : s->compact_states == 2 ? ",masks" : "",
+                     fuse_expm ? ",expm" : "");
         else
             if (s->jit_fn2)
                 snprintf(jit_name, sizeof(s->kernel_name), "prune_tree_jit_mfma%s<%d,T%d+T%d>",

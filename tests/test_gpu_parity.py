@@ -1308,6 +1308,73 @@ def test_reversible_model_rerooting_invariance_full_batch(ra):
             np.testing.assert_allclose(ll, base, rtol=1e-10)
 
 
+@pytest.mark.parametrize('n', [1, 2, 3, 4])
+def test_single_launch_step_is_the_two_launch_step(ra, n):
+    """n <= 4, tree-specialised lane kernel: rt_step runs ONE launch -- the kernel computes
+    the exponential of every edge in its prologue (the text of the library's expm kernel,
+    csrc/expm_small.inc), workgroup 0 leaves the matrices where the expm launch would have,
+    an extra workgroup carries the previous step's batch sum.  Bit for bit the two-launch step:
+    transition matrices, order / squarings, log-likelihoods, totals; one rate matrix for
+    all edges and one per edge; the same batch in consecutive steps (two partial-sum buffers)."""
+    rng = np.random.RandomState(40 + n)
+    T, root, leaves = ra.synth.balanced_tree(16, seed=3)
+    nedges = T.number_of_edges()
+    set_option = ra.lib.lib().rt_set_option
+    for per_edge in (False, True):
+        nq = nedges if per_edge else 1
+        Q = rng.exponential(size=(nq, n, n)) * rng.choice([1e-3, 0.3, 4.0], size=(nq, 1, 1))
+        for q in Q:
+            np.fill_diagonal(q, 0)
+            q -= np.diag(q.sum(axis=1))
+        model = ra.device.TreeModel(T, root, n)
+        ta = model.tree
+        node_q = np.zeros(ta.nnodes, dtype=np.int64)
+        if per_edge:
+            node_q[1:] = rng.permutation(nedges)
+        t = np.concatenate([[0.0], rng.uniform(0.01, 2.0, size=ta.nnodes - 1)])
+        w = rng.uniform(0.1, 1.0, size=n)
+        dense = rng.uniform(0.05, 1.0, size=(3000, len(leaves), n))
+        ra.lib.check(set_option(b'jit', 1))
+        try:
+            out = {}
+            for fused in ('1', '0'):
+                os.environ['RAOTEH_JIT_FUSE_EXPM'] = fused
+                model.set_rates(Q=Q, node_q=node_q, t=t)
+                model.set_root_distn(w)
+                b1 = model.upload_sites(leaves, dense[:2000], kind='dense')
+                b2 = model.upload_sites(leaves, dense[2000:], kind='dense')
+                P0, info0 = model.get_transitions(), model.expm_info()
+                model.prune(b1)
+                model.prune(b2)
+                ref = (model.fetch_log_likelihoods(b1), model.fetch_totals(b1), model.fetch_totals(b2))
+                assert ',expm' not in ra.ctx.kernel_time(1)[2]
+                # poison what a step must rebuild
+                model.set_transitions(np.full_like(P0, 0.25))
+                for b in (b1, b1, b2, b1):
+                    model.step(b)
+                assert (',expm' in ra.ctx.kernel_time(1)[2]) == (fused == '1'), ra.ctx.kernel_time(1)
+                np.testing.assert_array_equal(model.get_transitions(), P0)
+                np.testing.assert_array_equal(model.expm_info(), info0)
+                got = (model.fetch_log_likelihoods(b1), model.fetch_totals(b1), model.fetch_totals(b2))
+                for a, b in zip(ref, got):
+                    np.testing.assert_array_equal(a[0] if isinstance(a, tuple) else a,
+                                                  b[0] if isinstance(b, tuple) else b)
+                # a step without recomputation, and a plain launch, still see the right table
+                model.step(b2, recompute_transitions=False)
+                model.prune(b1)
+                np.testing.assert_array_equal(model.fetch_totals(b2), ref[2])
+                np.testing.assert_array_equal(model.fetch_totals(b1), ref[1])
+                out[fused] = (P0, ref[0][0])
+                b1.close()
+                b2.close()
+            np.testing.assert_array_equal(out['1'][0], out['0'][0])
+            np.testing.assert_array_equal(out['1'][1], out['0'][1])
+        finally:
+            ra.lib.check(set_option(b'jit', -1))
+            os.environ.pop('RAOTEH_JIT_FUSE_EXPM', None)
+        model.close()
+
+
 def test_deferred_reduce_gives_the_same_totals(ra):
     # rt_step leaves the fixed-order reduction of the batch sum to the next expm launch
     # (one extra workgroup) or to whoever reads the totals first; the numbers are those
