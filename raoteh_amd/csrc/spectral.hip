@@ -56,6 +56,8 @@ spectral_kernel(int n, int count, const double *__restrict__ A, const double *__
     // every global load of the workgroup is issued before the first dependent use (the index
     // of the rate matrix included: the root's workgroups load operands they do not need)
     const double t = tt[b];
+    // (the stationary weight of row 16m + tid, for the diagonal fix after the product)
+    const double dw = (D && tid < 16 && 16 * m + tid < n) ? D[16 * m + tid] : 1.0;
     // B: thread = (column, row group); A: 16 x RN entries, consecutive threads along a row
     constexpr int RP = TPB / RN;
     constexpr int PER = (RN + RP - 1) / RP;
@@ -120,12 +122,13 @@ spectral_kernel(int n, int count, const double *__restrict__ A, const double *__
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int il = 4 * r + (lane >> 4), j = 16 * c + (lane & 15);
-            // states the stationary distribution gives no mass: the row of A is zero there;
-            // the reference sets the diagonal entry to one (qtop.py:86-87)
-            const bool fix = D && 16 * m + il == j && j < n && D[j] == 0.0;
-            Xs[il * LD + j] = fix ? 1.0 : acc[r];
+            Xs[il * LD + j] = acc[r];
         }
     }
+    __syncthreads();
+    // states the stationary distribution gives no mass: the row of A is zero there; the
+    // reference sets the diagonal entry to one (qtop.py:86-87)
+    if (dw == 0.0) Xs[tid * LD + 16 * m + tid] = 1.0;
     __syncthreads();
     for (int e = tid; e < 16 * RN; e += TPB) {
         const int il = e / RN, j = e % RN;
