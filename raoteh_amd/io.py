@@ -2,7 +2,8 @@
 Input formats of the reference's examples: sequential-paragraph PHYLIP codon
 alignments, newick trees and the genetic-code table
 (examples/p53/app_helper.py:80-139,158-183), the MG94 codon model builder
-(examples/p53/create_mg94.py:23-142), and site-pattern compression.  Host-side
+(examples/p53/create_mg94.py:23-142), the rate-matrix text format of
+craoteh/README.rst:1-10, and site-pattern compression.  Host-side
 only; the parsers are written from the formats, not from the reference's
 dendropy-based readers.
 """
@@ -14,7 +15,7 @@ import networkx as nx
 import numpy as np
 
 __all__ = ['read_phylip', 'read_newick', 'read_genetic_code', 'mg94_from_code',
-           'alignment_to_states', 'compress_patterns']
+           'alignment_to_states', 'compress_patterns', 'read_rate_matrix', 'write_rate_matrix']
 
 
 def read_phylip(path_or_file):
@@ -186,3 +187,64 @@ def compress_patterns(data):
     _, first, inverse, counts = np.unique(view, return_index=True, return_inverse=True,
                                           return_counts=True)
     return data[first], inverse.astype(np.int64), counts.astype(np.int64)
+
+
+def read_rate_matrix(path_or_file):
+    """The primary-process rate-matrix text format of craoteh/README.rst:1-10: the first
+    line holds the number of states N (states 0 .. N-1), every further non-empty line a
+    whitespace-separated triple `source_state sink_state rate`; missing entries are zero
+    and the diagonal is determined by the rows summing to zero.  -> f64[N, N].
+    ValueError: a state out of range, a negative or non-finite rate, a diagonal or
+    repeated entry, a malformed line."""
+    fin = open(path_or_file) if isinstance(path_or_file, str) else path_or_file
+    try:
+        lines = [ln.split('#', 1)[0].strip() for ln in fin]
+    finally:
+        if isinstance(path_or_file, str):
+            fin.close()
+    lines = [ln for ln in lines if ln]
+    if not lines:
+        raise ValueError('empty rate matrix file')
+    head = lines[0].split()
+    if len(head) != 1 or not head[0].isdigit() or int(head[0]) < 1:
+        raise ValueError('the first line must hold the number of states')
+    n = int(head[0])
+    Q = np.zeros((n, n), dtype=np.float64)
+    seen = set()
+    for ln in lines[1:]:
+        parts = ln.split()
+        if len(parts) != 3:
+            raise ValueError('expected `source sink rate`, got %r' % ln)
+        try:
+            a, b, r = int(parts[0]), int(parts[1]), float(parts[2])
+        except ValueError:
+            raise ValueError('expected `source sink rate`, got %r' % ln)
+        if not (0 <= a < n and 0 <= b < n):
+            raise ValueError('state out of range in %r' % ln)
+        if a == b:
+            raise ValueError('diagonal entries are determined automatically: %r' % ln)
+        if not np.isfinite(r) or r < 0:
+            raise ValueError('rates must be finite and non-negative: %r' % ln)
+        if (a, b) in seen:
+            raise ValueError('repeated entry %r' % ln)
+        seen.add((a, b))
+        Q[a, b] = r
+    Q[np.arange(n), np.arange(n)] = -Q.sum(axis=1)
+    return Q
+
+
+def write_rate_matrix(Q, path_or_file):
+    """Inverse of read_rate_matrix: N, then one tab-separated triple per nonzero
+    off-diagonal rate (repr of the float: the file reads back bit for bit)."""
+    Q = np.asarray(Q, dtype=np.float64)
+    if Q.ndim != 2 or Q.shape[0] != Q.shape[1]:
+        raise ValueError('expected the array to be square')
+    fout = open(path_or_file, 'w') if isinstance(path_or_file, str) else path_or_file
+    try:
+        fout.write('%d\n' % Q.shape[0])
+        for a, b in zip(*np.nonzero(Q)):
+            if a != b:
+                fout.write('%d\t%d\t%r\n' % (a, b, float(Q[a, b])))
+    finally:
+        if isinstance(path_or_file, str):
+            fout.close()

@@ -92,3 +92,24 @@ def test_oracle_p53_total_log_likelihood_is_stable():
     for k in np.flatnonzero(counts > 1)[:5]:
         rows = np.flatnonzero(inverse == k)
         assert np.ptp(ll[rows]) == 0.0
+
+
+def test_rate_matrix_text_format_round_trip(tmp_path):
+    """craoteh/README.rst:1-10: N on the first line, `source sink rate` triples, missing
+    entries zero, diagonal from the row sums."""
+    import io as _io
+    from raoteh_amd import io as rio, synth
+    text = '3\n0\t1\t0.5\n1 2 2.0\n\n2\t0\t1e-3  # a comment\n'
+    Q = rio.read_rate_matrix(_io.StringIO(text))
+    np.testing.assert_array_equal(Q, [[-0.5, 0.5, 0.0], [0.0, -2.0, 2.0], [1e-3, 0.0, -1e-3]])
+    Qm, _ = synth.mg94()
+    path = str(tmp_path / 'mg94.rates')
+    rio.write_rate_matrix(Qm, path)
+    back = rio.read_rate_matrix(path)
+    off = ~np.eye(len(Qm), dtype=bool)
+    np.testing.assert_array_equal(back[off], Qm[off])
+    np.testing.assert_allclose(np.diag(back), np.diag(Qm), rtol=1e-13)
+    for bad in ('', 'x\n', '2\n0 2 1.0\n', '2\n0 0 1.0\n', '2\n0 1 -1\n', '2\n0 1 1\n0 1 2\n',
+                '2\n0 1\n', '2\n0 1 nan\n'):
+        with pytest.raises(ValueError):
+            rio.read_rate_matrix(_io.StringIO(bad))
