@@ -75,24 +75,29 @@ def main():
         only = os.environ.get('SOAK_ONLY')
         if only is not None and cases != int(only):
             for _ in range(2):
-                rng.randint(1, 5); rng.choice([64, 56, 33, 5])
+                rng.randint(1, 6); rng.choice([64, 56, 33, 5]); rng.choice(['', '0', '1'])
             cases += 1
             continue
         model = device.TreeModel(T, root, n, ctx=ctx)
         model.set_transitions(esd)
         model.set_root_distn(w)
         out = []
-        variants = [(0, None, None)]
+        # (jit, tiles, sites per wave, root halves: '' = the library's own policy; n > 32 only)
+        variants = [(0, None, None, '')]
         for _ in range(2):
-            variants.append((1, int(rng.randint(1, 5)), int(rng.choice([64, 56, 33, 5]))))
+            variants.append((1, int(rng.randint(1, 6)), int(rng.choice([64, 56, 33, 5])),
+                             str(rng.choice(['', '0', '1']))))
         if only is not None:
-            variants = [(0, None, None)] + [(1, t, 64) for t in (1, 2, 3, 4)]
+            variants = [(0, None, None, '')] + [(1, t, 64, h) for t in (1, 2, 3, 4, 5)
+                                                for h in ('0', '1')]
             print('case', cases, dict(n=n, nnodes=nnodes, nsites=nsites, nobs=len(obs_nodes),
                   nleaves=len(leaves), depth=None))
-        for jit, tiles, bs in variants:
+        for jit, tiles, bs, halves in variants:
             _lib.check(set_option(b'jit', jit))
             if jit:
                 os.environ['RAOTEH_JIT_TILES'] = str(tiles)
+                if halves:
+                    os.environ['RAOTEH_JIT_HALVES'] = halves
                 _lib.check(set_option(b'jit_block_sites', bs if n <= 4 else 0))
             try:
                 if jit and states is not None:
@@ -101,11 +106,12 @@ def main():
                     batch = model.upload_sites(obs_nodes, dense, kind='dense')
                 ll, st = model.log_likelihoods(batch)
                 tot = model.fetch_totals(batch)
-                out.append((ll, st, tot, ctx.kernel_time(1)[2], (jit, tiles, bs)))
+                out.append((ll, st, tot, ctx.kernel_time(1)[2], (jit, tiles, bs, halves)))
             finally:
                 _lib.check(set_option(b'jit', -1))
                 _lib.check(set_option(b'jit_block_sites', 0))
                 os.environ.pop('RAOTEH_JIT_TILES', None)
+                os.environ.pop('RAOTEH_JIT_HALVES', None)
         ref = out[0]
         if only is not None:
             ok = wst == 0
@@ -135,10 +141,13 @@ def main():
                                               kernel=ref[3]))
                 sys.exit(1)
         cases += 1
+        nhalves = globals().setdefault('_nhalves', 0) + sum('halves' in o[3] for o in out)
+        globals()['_nhalves'] = nhalves
         if cases % 25 == 0:
-            print('%d cases, %.0f s, worst relative error vs oracle %.2e' % (
-                cases, time.time() - t0, worst), flush=True)
-    print('soak: %d cases clean, worst relative error vs oracle %.2e' % (cases, worst))
+            print('%d cases, %.0f s, worst relative error vs oracle %.2e, %d root-halves kernels' % (
+                cases, time.time() - t0, worst, nhalves), flush=True)
+    print('soak: %d cases clean (%d root-halves kernels among them), worst relative error vs oracle %.2e' % (
+        cases, globals().get('_nhalves', 0), worst))
 
 
 if __name__ == '__main__':
