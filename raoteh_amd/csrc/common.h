@@ -91,7 +91,6 @@ struct rt_ctx {
     struct rt_sites *pending_reduce = nullptr;
     size_t expm_attr_lds = 0;      // dynamic-LDS attribute already granted to expm_kernel
     size_t expm_ts_attr_lds[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ... to the Taylor kernels (per NT)
-    size_t spectral_attr_lds[4] = {0, 0, 0, 0};              // ... to spectral_kernel<NT>
     double *d_expm_scratch = nullptr;   // matrices of the order > 64 Taylor kernel (grow-only)
     void *expect_cache = nullptr;       // expect_mfma.hip: model + packed batch of the last call
     hipStream_t stream2 = nullptr;      // side stream of two-kernel pruning launches (lazy)

@@ -1765,8 +1765,6 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
         o << "    }\n}\n";
         // ---- second kernel of the module: root step + site epilogue from the two halves,
         // one tile per workgroup whatever T is
-        const int T_main = T;
-        (void)T_main;
         T = 1;
         const rt_op &root = ops.back();
         o << "extern \"C\" __global__ void __launch_bounds__(" << 64 * NT << ")\n"

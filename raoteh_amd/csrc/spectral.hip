@@ -9,7 +9,7 @@
 // B = U^T diag(sqrt D)).  The decomposition is once per rate matrix and stays with the caller
 // (raoteh_amd/_spectral.py uses numpy's eigh, as the reference uses scipy's); this file is the
 // per-branch-length part, which the reference runs as 2 numpy products per edge and site
-// batch: here one workgroup per edge, the product on the f64 matrix pipe, the result left in
+// batch: here one workgroup per (edge, row tile), the product on the f64 matrix pipe, the result left in
 // the layouts the pruning kernels read (esd_transitions, Pfrag, Pquad) exactly as the expm
 // kernels leave it (expm.hip).  n <= 64.
 #include "common.h"
