@@ -1428,6 +1428,23 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
     const int KS = (n + 3) / 4;
     const int KP = (KS + 1) / 2;
     const int XT = NT * 4 * 64;               // doubles of one tile's x image
+    // n = 4 KS - 3: the last k-step holds ONE real state (the codon model: state 60 of 61), an
+    // MFMA of which three quarters multiply zeros.  Then the chain stops one k-step early and
+    // the last state's term is added on the vector ALU when the result is folded:
+    // c[r] = fma(P[16 m + 4 r + (lane >> 4)][n - 1], x[n - 1][lane & 15], c[r]) -- the matrix
+    // pipe adds the k-steps of a chain in order, each as fused multiply-adds in k order, and
+    // the three padded terms are exact zeros, so this is the chain's last MFMA bit for bit
+    // (the probe verification agrees: bit-identical at T = 5).  The four P values of a lane sit
+    // in its wave's A fragment of that k-step at lanes 4 r + (lane >> 4).
+    // MEASURED, AND NOT THE DEFAULT (RAOTEH_JIT_LASTK=1 turns it on): config 3, root halves,
+    // T = 5: 176.3 us against 173.1 with the MFMA -- the 16th MFMA of a chain costs 70 pipe
+    // cycles, its replacement 8 cross-lane reads per step + 5 LDS reads and 20 v_fma_f64 per
+    // step in the shadow, and 16 more live registers in a kernel that already keeps 250
+    // values in AGPRs; at T = 1 and T = 2 the register budget no longer holds (scratch: the
+    // kernel is rejected and the interpreter runs).
+    const bool lastk = (n % 4 == 1) && KS >= 4 && getenv("RAOTEH_JIT_LASTK") &&
+                       atoi(getenv("RAOTEH_JIT_LASTK")) != 0;
+    const int KSM = lastk ? KS - 1 : KS;      // k-steps on the matrix pipe
     int nslots = 1;
     std::vector<std::vector<pipe_step>> programs;
     if (halves) {
@@ -1599,6 +1616,13 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
                 os << "    const rt_d2 A" << k << "_" << q << " = ag[" << at << "];\n";
         }
     };
+    // (lastk) this lane's four entries of column n - 1 of P, from the A fragment of issue step k
+    auto emit_pcol = [&](std::ostream &os, int k) {
+        if (!lastk) return;
+        for (int r = 0; r < 4; ++r)
+            os << "    const double pc" << k << "_" << r << " = __shfl(A" << k << "_" << ((KS - 1) >> 1)
+               << (((KS - 1) & 1) ? ".y" : ".x") << ", " << 4 * r << " + (lane >> 4), 64);\n";
+    };
     // own rows of x for issue step k
     auto emit_x = [&](std::ostream &os, int k) {
         const rt_op &op = st[(size_t)k].op;
@@ -1630,6 +1654,14 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
         const rt_op &op = st[(size_t)k].op;
         const int d = op.dst & 255;
         const bool first = (op.dst >> 8) != 0;
+        if (lastk)
+            for (int t = 0; t < T; ++t) {
+                os << "    const double xl" << k << "_" << t << " = xb" << k % 3 << "[" << t << "]["
+                   << (KS - 1) * 64 << " + (lane & 15)];\n";
+                for (int r = 0; r < 4; ++r)
+                    os << "    c" << k << "_" << t << "[" << r << "] = fma(pc" << k << "_" << r << ", xl" << k
+                       << "_" << t << ", c" << k << "_" << t << "[" << r << "]);\n";
+            }
         for (int t = 0; t < T; ++t)
             for (int r = 0; r < 4; ++r)
                 os << "    a" << d << "_" << t << "_" << r << (first ? " = " : " *= ") << "c" << k << "_"
@@ -1637,7 +1669,7 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
     };
     // ---- prologue -----------------------------------------------------------------------
     for (int k = 0; k < std::min(D, (int)obs_order.size()); ++k) emit_obs_load(o, obs_order[(size_t)k]);
-    if (nrec > 0 && st[0].op.dst >= 0) emit_a_load(o, 0);
+    if (nrec > 0 && st[0].op.dst >= 0) { emit_a_load(o, 0); emit_pcol(o, 0); }
     o << "    {\n";
     if (st[0].op.dst >= 0) {
         emit_publish(o, 0);
@@ -1695,6 +1727,8 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
         if (i + 1 < nrec && st[(size_t)(i + 1)].op.dst >= 0) emit_a_load(sh, i + 1);
         if (fold_pending) { emit_fold(sh, i - 1); fold_pending = false; }
         if (have_next && !next_root && !next_late) emit_publish(sh, i + 1);
+        // (behind everything else: the fragment it reads was requested at the top of this shadow)
+        if (i + 1 < nrec && st[(size_t)(i + 1)].op.dst >= 0) emit_pcol(sh, i + 1);
         std::vector<std::string> shadow;
         {
             const std::string all = sh.str();
@@ -1708,13 +1742,13 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
         for (int t = 0; t < T; ++t) o << "    rt_d4 c" << i << "_" << t << " = {0.0, 0.0, 0.0, 0.0};\n";
         // MFMAs, MFMA results and LDS writes keep their order across these barriers; LDS
         // reads, global reads and scalar instructions may move (0x100 | 0x20 | 0x4)
-        const int nmfma = KS * T;
+        const int nmfma = KSM * T;
         const int lead = std::min(2 * T, nmfma);          // MFMAs before the first shadow slice
         const int slots = std::max(1, nmfma - lead - 2 * T);   // ... none behind the last 2 T
         size_t next_sh = 0;
         int issued = 0;
         const bool early_barrier = have_next && !next_root && !next_late && KS >= 4;
-        for (int kk = 0; kk < KS; ++kk)
+        for (int kk = 0; kk < KSM; ++kk)
             for (int t = 0; t < T; ++t) {
                 if (early_barrier && issued == nmfma - T) {
                     // the shadow is empty: x of step i + 1 is on its way to LDS
