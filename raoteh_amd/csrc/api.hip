@@ -777,7 +777,7 @@ extern "C" int rt_sites_destroy(rt_sites *s)
     // an all-reduce of this batch's totals may still be in flight on the comm stream
     rt_jit_ref(s->model->ctx, s->jit_fn, -1);
     if (s->jit_fn2) rt_jit_ref(s->model->ctx, s->jit_fn2, -1);
-    hipFree(s->d_ops); hipFree(s->d_lane_ops); hipFree(s->d_obs); hipFree(s->d_loglik); hipFree(s->d_status);
+    hipFree(s->d_ops); hipFree(s->d_lane_ops); hipFree(s->d_lane_ops_a); hipFree(s->d_lane_ops_b); hipFree(s->d_obs); hipFree(s->d_loglik); hipFree(s->d_status);
     if (s->model->ctx->comm_stream) hipStreamSynchronize(s->model->ctx->comm_stream);
     hipFree(s->d_partial); hipFree(s->d_partial_alt); hipFree(s->d_scratch); hipFree(s->d_half);
     if (s->totals_slot >= 0) {
@@ -795,11 +795,10 @@ extern "C" int rt_sites_destroy(rt_sites *s)
 
 // Lane-kernel program: simulate the register cache of the top accumulator and
 // turn slots into LDS byte offsets (see LOP_* in prune.hip).
-static std::vector<int32_t> lane_program(const rt_sites *s, int64_t slot_bytes, bool fuse)
+static std::vector<int32_t> lane_program(const std::vector<rt_op> &ops, int64_t slot_bytes, bool fuse)
 {
     enum { INTERNAL = 1, X_CUR = 2, FIRST = 4, ROOT = 8, SPILL = 16, DST_CUR = 32, OBS = 64,
            FAST = 128, CHERRY = 256 };
-    const std::vector<rt_op> &ops = s->ops;
     std::vector<int32_t> prog;
     prog.reserve(ops.size() * 4);
     int cur = -1;                              // slot cached in registers
@@ -881,6 +880,8 @@ static int program_stack_slots(const std::vector<int32_t> &prog, int64_t slot_by
     return (int)(top / slot_bytes) + 1;
 }
 
+static bool want_root_halves(const rt_sites *s, int64_t ntiles);
+
 static int sites_alloc(rt_sites *s, bool generic)
 {
     rt_model *m = s->model;
@@ -951,12 +952,52 @@ static int sites_alloc(rt_sites *s, bool generic)
         // MFMA split-M 4 (own rows), MFMA solo the whole message (NT*4)
         const int64_t slot_bytes = s->layout == RT_LAYOUT_LANE ? n * 512
                                  : s->mfma_solo ? ((n + 15) / 16) * 4 * 512 : 2048;
-        const std::vector<int32_t> prog = lane_program(s, slot_bytes, fuse);
+        const std::vector<int32_t> prog = lane_program(s->ops, slot_bytes, fuse);
         s->lane_nprog = (int64_t)(prog.size() / 4) - 1;     // without the sentinel
         s->lane_stack_slots = program_stack_slots(prog, slot_bytes);
         e = hipMalloc((void **)&s->d_lane_ops, prog.size() * 4);
         if (e == hipSuccess)
             e = hipMemcpy(s->d_lane_ops, prog.data(), prog.size() * 4, hipMemcpyHostToDevice);
+        // Split-M interpreter kernel, root halves (prune.hip): what a batch of a few tiles
+        // per CU runs while it has no tree-specialised kernel (a fresh topology) -- the same
+        // cut and the same policy as the specialised kernel's (want_root_halves).
+        // RAOTEH_INTERP_HALVES=0 / 1 overrides.
+        std::vector<rt_op> opsA, opsB;
+        bool ih = e == hipSuccess && s->layout == RT_LAYOUT_MFMA && !s->mfma_solo && n <= 64 &&
+                  rt_split_at_root(s->ops, &opsA, &opsB);
+        if (ih) {
+            if (const char *v = getenv("RAOTEH_INTERP_HALVES")) ih = atoi(v) != 0;
+            else ih = want_root_halves(s, s->nblocks);
+        }
+        if (ih) {
+            // the root's own observation is the combine kernel's; B's only child of the root
+            // is a first child there
+            s->half_kroot = opsA.back().obs;
+            opsA.back().obs = -1;
+            opsB.back().obs = -1;
+            rt_op &bc = opsB[opsB.size() - 2];
+            bc.dst = (bc.dst & 255) | 256;
+            const std::vector<int32_t> pa = lane_program(opsA, slot_bytes, false);
+            const std::vector<int32_t> pb = lane_program(opsB, slot_bytes, false);
+            s->lane_stack_slots = std::max(s->lane_stack_slots,
+                                           std::max(program_stack_slots(pa, slot_bytes),
+                                                    program_stack_slots(pb, slot_bytes)));
+            s->half_nops[0] = (int)opsA.size();
+            s->half_nops[1] = (int)opsB.size();
+            s->half_rec1 = (int)opsA.size() - 1;
+            s->half_kobs1 = 0;
+            for (size_t k = 0; k + 1 < opsA.size(); ++k) s->half_kobs1 += opsA[k].obs >= 0;
+            e = hipMalloc((void **)&s->d_lane_ops_a, pa.size() * 4);
+            if (e == hipSuccess) e = hipMalloc((void **)&s->d_lane_ops_b, pb.size() * 4);
+            if (e == hipSuccess)
+                e = hipMemcpy(s->d_lane_ops_a, pa.data(), pa.size() * 4, hipMemcpyHostToDevice);
+            if (e == hipSuccess)
+                e = hipMemcpy(s->d_lane_ops_b, pb.data(), pb.size() * 4, hipMemcpyHostToDevice);
+            if (e == hipSuccess && !s->d_half)
+                e = hipMalloc((void **)&s->d_half,
+                              (size_t)(s->nblocks + 8) * 2 * ((n + 15) / 16) * 4 * 64 * 8);
+            s->interp_halves = e == hipSuccess;
+        }
     }
     if (e != hipSuccess) {
         rt_set_error("rt_sites: %s", hipGetErrorString(e));

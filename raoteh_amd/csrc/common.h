@@ -209,6 +209,13 @@ struct rt_sites {
     bool jit_halves = false;
     void *jit_combine = nullptr;
     double *d_half = nullptr;
+    // the same cut for the split-M INTERPRETER kernel (prune.hip rt_interp_halves), used while
+    // the batch has no tree-specialised kernel: the two root programs, the P record and the
+    // stream position the second one starts at, the root's own stream position (-1: none)
+    bool interp_halves = false;
+    int32_t *d_lane_ops_a = nullptr, *d_lane_ops_b = nullptr;
+    int half_nops[2] = {0, 0};
+    int half_rec1 = 0, half_kobs1 = 0, half_kroot = -1;
     // not owned: where the split-M interpreter kernel leaves L_v and M_v of every step
     // (expect_mfma.hip sets them around its own launch)
     double *d_Lout = nullptr, *d_Mout = nullptr;
@@ -282,6 +289,9 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
                                                int D, int LA, bool halves = false);
 // steps of the two root programs the halves form would run (0, 0: the root has < 2 children)
 void rt_jit_root_halves(const std::vector<rt_op> &ops, int *stepsA, int *stepsB);
+// the cut itself: A = the subtrees of all children of the root but the last, B = the last
+// child's subtree, each followed by the root's step (both contiguous runs of `ops`)
+bool rt_split_at_root(const std::vector<rt_op> &ops, std::vector<rt_op> *A, std::vector<rt_op> *B);
 // another kernel of the module `fn` came from (the halves form's rt_jit_combine)
 int rt_jit_companion(const rt_ctx *ctx, void *fn, const char *name, void **out);
 int rt_jit_get(rt_ctx *ctx, const std::string &src, void **fn, bool mfma = false,

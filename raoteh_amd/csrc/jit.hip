@@ -1400,6 +1400,11 @@ bool split_at_root(const std::vector<rt_op> &ops, std::vector<rt_op> *A, std::ve
 
 }  // namespace
 
+bool rt_split_at_root(const std::vector<rt_op> &ops, std::vector<rt_op> *A, std::vector<rt_op> *B)
+{
+    return split_at_root(ops, A, B);
+}
+
 // work of the two root programs as steps (A, B); (0, 0) when the schedule cannot be cut
 void rt_jit_root_halves(const std::vector<rt_op> &ops, int *stepsA, int *stepsB)
 {

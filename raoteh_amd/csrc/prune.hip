@@ -594,6 +594,20 @@ prune_lanedma_kernel(const double *__restrict__ Pord,   // [nrec][N][N]
 // the pending accumulators (LDS stack, 2 KB per slot per wave).  A workgroup is
 // 4 waves (3 when NT = 3) = 4/NT site tiles; nothing but x crosses waves.
 
+// Root halves of the interpreter kernel (the cut of jit.hip's split_at_root, for trees that
+// have no tree-specialised kernel yet): even workgroups run the program of the subtrees of
+// all children of the root but the last, odd ones the program of the last child's subtree;
+// each ends at ITS root step by storing its share of the root's accumulator (own rows) to
+// halfbuf[tile][half][k-step][lane]; prune_mfma_combine_kernel finishes the sites.  The
+// second program's steps are records rec1.. of the P table and its leaves positions kobs1..
+// of the observation stream (both programs are contiguous runs of the post-order schedule).
+struct rt_interp_halves {
+    const int4_t *prog1 = nullptr;   // program of the last child's subtree
+    int nops0 = 0, nops1 = 0;        // steps of the two programs (root step included)
+    int rec1 = 0, kobs1 = 0;
+    double *halfbuf = nullptr;       // null: the whole tree in one program
+};
+
 template <int NT, int KS, bool STORE>
 __global__ void __launch_bounds__((NT == 3 ? 3 : 4) * 64)
 prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
@@ -602,7 +616,7 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
                   const double *__restrict__ root_w, int n, int lds_slots,
                   double *__restrict__ loglik, int *__restrict__ status,
                   double *__restrict__ partial, long nsites, long nblocks16,
-                  double *__restrict__ Lout, double *__restrict__ Mout)
+                  double *__restrict__ Lout, double *__restrict__ Mout, rt_interp_halves hv)
 {
     // Lout / Mout (optional): own rows of L_v and of the message M_v = P_v L_v of every step,
     // [step][tile][m][r][lane] -- what the downward pass and the site sums of the expectation
@@ -617,9 +631,18 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tile = wave / NT;
     const int m = wave - tile * NT;
-    const long gt = (long)blockIdx.x * TILES + tile;      // global site tile
+    const bool halves = !STORE && hv.halfbuf != nullptr;
+    const int half = halves ? (int)(blockIdx.x & 1) : 0;
+    const long bidx = halves ? (long)(blockIdx.x >> 1) : (long)blockIdx.x;
+    const long gt = bidx * TILES + tile;                   // global site tile
     const bool live = gt < nblocks16;
     const long blk = live ? gt : nblocks16 - 1;           // keep barriers uniform
+    if (halves) {
+        nops = half ? hv.nops1 : hv.nops0;
+        if (half) prog = hv.prog1;
+    }
+    const int rec0 = half ? hv.rec1 : 0;                   // P record of this program's step 0
+    const int kobs0 = half ? hv.kobs1 : 0;                 // stream position of its first leaf
 
     double *xb = (double *)smem + tile * XB;               // [TILES][XB], single buffer
     double *red = (double *)smem + TILES * XB;             // [TILES][NT][16]
@@ -629,8 +652,8 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
 
     const RT_CONST_AS int4_t *prog_c = (const RT_CONST_AS int4_t *)prog;
     // A fragments of this wave: [op][m][q][lane][2]
-    const double *ag = Pfrag + ((size_t)m * KP * 64 + lane) * 2;
     constexpr size_t ASTRIDE = (size_t)NT * KP * 128;
+    const double *ag = Pfrag + (size_t)rec0 * ASTRIDE + ((size_t)m * KP * 64 + lane) * 2;
     // observation pairs holding this wave's own rows 4m..4m+3: q = 2m, 2m+1
     const double *og = obs + (size_t)blk * K * (KP * 128) + lane * 2;
 
@@ -640,19 +663,19 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
     for (int j = 0; j < 4; ++j) on[j] = 1.0;
 
     int4_t op = prog_c[0];
-    int knext = 0;                // stream position `on` holds / will hold
+    int knext = kobs0;            // stream position `on` holds / will hold
 #pragma unroll
     for (int q = 0; q < KP; ++q) {
         const double2 v = *(const double2 *)(ag + q * 128);
         an[2 * q] = v.x;
         an[2 * q + 1] = v.y;
     }
-    if (K > 0) {
+    if (knext < K) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int q = 2 * m + h;
             double2 v = {0.0, 0.0};
-            if (q < KP) v = *(const double2 *)(og + (size_t)q * 128);
+            if (q < KP) v = *(const double2 *)(og + ((size_t)knext * KP + q) * 128);
             on[2 * h] = v.x;
             on[2 * h + 1] = v.y;
         }
@@ -689,6 +712,16 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
             for (int r = 0; r < 4; ++r) lo[r * 64] = x[r];
         }
         if (flags & LOP_ROOT) {
+            if (halves) {
+                // this program's share of the root's accumulator (the root's own observation
+                // is the combine kernel's: the half programs' root step carries none)
+                if (live) {
+                    double *hb = hv.halfbuf + ((size_t)gt * 2 + half) * (NT * 256) + (m * 4) * 64 + lane;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hb[r * 64] = x[r];
+                }
+                return;
+            }
             double s = 0.0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -778,6 +811,75 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
     }
 
     // lanes 0..15 of wave m == 0 own the 16 sites of the tile
+    const long site = blk * 16 + (lane & 15);
+    const bool valid = live && m == 0 && lane < 16 && site < nsites;
+    double sum, nzero;
+    finish_site(lik, negative, valid, loglik, status, site, sum, nzero);
+    sum = wave_sum(sum);
+    nzero = wave_sum(nzero);
+    if (lane == 0) {
+        const long gwv = (long)blockIdx.x * WAVES + wave;
+        partial[gwv * 2] = sum;
+        partial[gwv * 2 + 1] = nzero;
+    }
+}
+
+// Second kernel of a root-halves interpreter launch: the root's accumulator is the product of
+// the two shares (in child order: the interpreter's own product bit for bit), times the root's
+// observation if it has one (stream position kroot), then the root step and the site epilogue
+// of prune_mfma_kernel unchanged -- same workgroup shape, same partial sums per wave.
+template <int NT>
+__global__ void __launch_bounds__((NT == 3 ? 3 : 4) * 64)
+prune_mfma_combine_kernel(const double *__restrict__ halfbuf, const double *__restrict__ obs,
+                          int K, int KP, int kroot, const double *__restrict__ root_w, int n,
+                          double *__restrict__ loglik, int *__restrict__ status,
+                          double *__restrict__ partial, long nsites, long nblocks16)
+{
+    constexpr int WAVES = (NT == 3) ? 3 : 4;
+    constexpr int TILES = WAVES / NT;
+    __shared__ double red[TILES * NT * 16];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = wave / NT;
+    const int m = wave - tile * NT;
+    const long gt = (long)blockIdx.x * TILES + tile;
+    const bool live = gt < nblocks16;
+    const long blk = live ? gt : nblocks16 - 1;
+    const double *ha = halfbuf + (size_t)blk * 2 * (NT * 256) + (m * 4) * 64 + lane;
+    double x[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = ha[r * 64] * ha[NT * 256 + r * 64];
+    if (kroot >= 0) {
+        const double *og = obs + (size_t)blk * K * (KP * 128) + lane * 2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = 2 * m + h;
+            double2 v = {0.0, 0.0};
+            if (q < KP) v = *(const double2 *)(og + ((size_t)kroot * KP + q) * 128);
+            x[2 * h] *= v.x;
+            x[2 * h + 1] *= v.y;
+        }
+    }
+    double lik = 0.0;
+    bool negative = false;
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 16 * m + 4 * r + (lane >> 4);
+        const double w = row < n ? root_w[row] : 0.0;
+        negative |= (row < n) && (x[r] < 0.0);
+        s += w * fmax(x[r], 0.0);
+    }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (lane < 16) red[(tile * NT + m) * 16 + lane] = s;
+    __syncthreads();
+    if (m == 0 && lane < 16) {
+        double tot = 0.0;
+#pragma unroll
+        for (int mm = 0; mm < NT; ++mm) tot += red[(tile * NT + mm) * 16 + lane];
+        lik = tot;
+    }
     const long site = blk * 16 + (lane & 15);
     const bool valid = live && m == 0 && lane < 16 && site < nsites;
     double sum, nzero;
@@ -1428,19 +1530,51 @@ static int launch_mfma_inst(rt_model *m, rt_sites *s)
     auto kern = s->d_Lout ? prune_mfma_kernel<NT, KS, true> : prune_mfma_kernel<NT, KS, false>;
     RT_HIP(hipFuncSetAttribute((const void *)kern,
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    rt_interp_halves hv;
+    if (s->interp_halves && !s->d_Lout) {
+        // the two root programs as even / odd workgroups, then the combine kernel
+        hv.prog1 = (const int4_t *)s->d_lane_ops_b;
+        hv.nops0 = s->half_nops[0];
+        hv.nops1 = s->half_nops[1];
+        hv.rec1 = s->half_rec1;
+        hv.kobs1 = s->half_kobs1;
+        hv.halfbuf = s->d_half;
+        RT_LAUNCH_TIMED(m->ctx, kern, dim3(2 * grid), dim3(WAVES * 64), lds,
+                           m->d_Pfrag, (const int4_t *)s->d_lane_ops_a, hv.nops0,
+                           s->d_obs, (int)s->nobs, m->d_root, (int)m->n, lds_slots,
+                           s->d_loglik, s->d_status, s->d_partial, (long)s->nsites,
+                           (long)s->nblocks, s->d_Lout, s->d_Mout, hv);
+        hipEvent_t ca = nullptr, cb = nullptr;
+        rt_time_extra_begin(m->ctx, RT_K_COMBINE, "prune_mfma_combine", &ca, &cb);
+        auto ckern = prune_mfma_combine_kernel<NT>;
+        const double *chalf = s->d_half;
+        if (ca)
+            hipExtLaunchKernelGGL(ckern, dim3(grid), dim3(WAVES * 64), 0, m->ctx->stream, ca, cb, 0,
+                                  chalf, (const double *)s->d_obs, (int)s->nobs, (KS + 1) / 2,
+                                  s->half_kroot, (const double *)m->d_root, (int)m->n, s->d_loglik,
+                                  s->d_status, s->d_partial, (long)s->nsites, (long)s->nblocks);
+        else
+            hipLaunchKernelGGL(ckern, dim3(grid), dim3(WAVES * 64), 0, m->ctx->stream,
+                               chalf, (const double *)s->d_obs, (int)s->nobs, (KS + 1) / 2,
+                               s->half_kroot, (const double *)m->d_root, (int)m->n, s->d_loglik,
+                               s->d_status, s->d_partial, (long)s->nsites, (long)s->nblocks);
+        rt_time_extra_end(m->ctx, RT_K_COMBINE, ca, cb);
+        return RT_OK;
+    }
     RT_LAUNCH_TIMED(m->ctx, kern, dim3(grid), dim3(WAVES * 64), lds,
                        m->d_Pfrag, (const int4_t *)s->d_lane_ops, (int)s->ops.size(),
                        s->d_obs, (int)s->nobs, m->d_root, (int)m->n, lds_slots,
                        s->d_loglik, s->d_status, s->d_partial, (long)s->nsites,
-                       (long)s->nblocks, s->d_Lout, s->d_Mout);
+                       (long)s->nblocks, s->d_Lout, s->d_Mout, hv);
     return RT_OK;
 }
 
 static int launch_mfma(rt_model *m, rt_sites *s, const char **name)
 {
     const int ks = ks_of(m->n);
-    snprintf(s->kernel_name, sizeof(s->kernel_name), "prune_mfma%s<%d,%d>",
-             s->mfma_solo ? "_solo" : "", nt_of(m->n), ks);
+    snprintf(s->kernel_name, sizeof(s->kernel_name), "prune_mfma%s<%d,%d%s>",
+             s->mfma_solo ? "_solo" : "", nt_of(m->n), ks,
+             s->interp_halves && !s->mfma_solo && !s->d_Lout ? ",halves" : "");
     *name = s->kernel_name;
     switch (ks) {
     case 2: return launch_mfma_inst<1, 2>(m, s);
