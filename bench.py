@@ -47,6 +47,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F64_MFMA_DATASHEET_TFLOPS = 78.6    # MI355X datasheet dense FP64 matrix
 ROOFLINE_LAUNCHES = 32         # event-timed launches per kernel after the timed region
+SPINUP_SECONDS = 0.3        # untimed load before the warm-up steps (clock ramp of an idle box)
 
 
 def f64_mfma_peak():
@@ -243,6 +244,18 @@ def run_workload(name, ctx, ctl, rank, world, reduce_kind, steps, warmup, args,
                 model.allreduce_group(batches[grp[0]:grp[1]])
         return b
 
+    # spin-up, untimed and before the W warm-up steps: a fresh box idles at its floor clock and
+    # takes tens of milliseconds of sustained load to reach the clock it then holds -- a run of
+    # 20 steps of 0.2 ms after 5 warm-up steps measured the ramp (0.231 ms per step, kernel 181 us),
+    # not the path (0.210 ms, 171 us with --steps 200).  The same device step, without the
+    # collectives of the N > 1 loop (each rank spins by its own clock).
+    t_spin = time.perf_counter()
+    j = 0
+    while time.perf_counter() - t_spin < SPINUP_SECONDS:
+        for _ in range(25):
+            model.step(batches[j % len(batches)])
+            j += 1
+        ctx.sync()
     for j in range(warmup):
         step(j)
     ctx.sync()
@@ -393,6 +406,7 @@ def run_workload(name, ctx, ctl, rank, world, reduce_kind, steps, warmup, args,
                    # (tree, observed nodes) and context, in rt_sites_create, OUTSIDE the
                    # timed region; `interpreter_kernel` is what the same batch runs at
                    # until / without it (an MCMC over topologies lives there)
+                   'spinup_s': SPINUP_SECONDS,
                    'jit_compile_s': jit_compile_s,
                    'upload_and_pack_s': upload_s,
                    'interpreter_kernel': interp},
