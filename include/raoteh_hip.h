@@ -37,7 +37,12 @@ extern "C" {
 #define RT_ERR_SINGULAR     -6   /* expm: non-finite Q t / singular Pade den. */
 #define RT_ERR_ZERO_PROB    -7   /* a chain's observations have likelihood 0 */
 
-#define RT_MAX_STATES       64   /* n <= 64 for the pruning kernels          */
+#define RT_MAX_STATES      128   /* pruning kernels and the reference-format passes
+                                    (pset / set / pmap / distn / joint): n <= 128 --
+                                    examples/p53/liwen.py:599-621 runs _mcy_dense on
+                                    2 x 61 = 122 compound states                */
+#define RT_MAX_EXPECT_STATES 64  /* expectation path (rt_mjp_*), Rao-Teh forest /
+                                    chains, spectral reconstruction: n <= 64    */
 #define RT_MAX_EXPM_STATES 128   /* expm: n <= 64 LDS-resident, <= 128 through
                                     L2-resident scratch (the Frechet blocks of the
                                     61-state codon model have order 122)        */
@@ -56,8 +61,9 @@ extern "C" {
                                     one-hot vectors are special cases)       */
 #define RT_OBS_STATE         1   /* uint8 [nsites][nobs] observed state,
                                     255 = unobserved (type x, _mcx.py:12-23) */
-#define RT_OBS_MASK          2   /* uint64 [nsites][nobs] bit s = state s
-                                    allowed (type y, _mcy.py:12-16)          */
+#define RT_OBS_MASK          2   /* uint64 [nsites][nobs][ceil(n/64)]: bit s % 64
+                                    of word s / 64 = state s allowed (type y,
+                                    _mcy.py:12-16); one word per node for n <= 64 */
 
 /* kernel ids for rt_ctx_kernel_time                                         */
 #define RT_K_EXPM            0

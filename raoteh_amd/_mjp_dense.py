@@ -78,16 +78,19 @@ def get_likelihood(T, node_to_allowed_states, root, nstates,
         root_distn=root_distn, P_default=None)
 
 
-def allowed_states_to_masks(sites, obs_nodes):
-    """list of node->set dicts -> uint64[nsites, nobs] bit masks."""
-    out = np.zeros((len(sites), len(obs_nodes)), dtype=np.uint64)
+def allowed_states_to_masks(sites, obs_nodes, nstates=None):
+    """list of node->set dicts -> uint64[nsites, nobs] bit masks; with nstates > 64
+    uint64[nsites, nobs, ceil(nstates / 64)] (bit s % 64 of word s // 64)."""
+    words = 1 if nstates is None else max(1, (int(nstates) + 63) // 64)
+    out = np.zeros((len(sites), len(obs_nodes), words), dtype=np.uint64)
     for i, d in enumerate(sites):
         for k, v in enumerate(obs_nodes):
             m = 0
             for s in d[v]:
                 m |= 1 << int(s)
-            out[i, k] = m
-    return out
+            for w in range(words):
+                out[i, k, w] = (m >> (64 * w)) & (2 ** 64 - 1)
+    return out[:, :, 0] if words == 1 else out
 
 
 def _build(T, root, nstates, obs_nodes, data, kind, root_distn, Q_default,

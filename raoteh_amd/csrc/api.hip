@@ -904,7 +904,7 @@ static int sites_alloc(rt_sites *s, bool generic)
         s->obs_bytes = s->nblocks * K * kp * 128 * 8;
         padded = s->nblocks * 16;
         const int64_t nt = (n + 15) / 16;
-        const int64_t waves = nt == 3 ? 3 : 4;
+        const int64_t waves = nt == 3 ? 3 : std::max<int64_t>(4, nt);
         const int64_t tiles = waves / nt;
         s->npartials = s->mfma_solo ? (s->nblocks + 3) / 4 * 4
                                     : (s->nblocks + tiles - 1) / tiles * waves;
@@ -963,7 +963,7 @@ static int sites_alloc(rt_sites *s, bool generic)
         // cut and the same policy as the specialised kernel's (want_root_halves).
         // RAOTEH_INTERP_HALVES=0 / 1 overrides.
         std::vector<rt_op> opsA, opsB;
-        bool ih = e == hipSuccess && s->layout == RT_LAYOUT_MFMA && !s->mfma_solo && n <= 64 &&
+        bool ih = e == hipSuccess && s->layout == RT_LAYOUT_MFMA && !s->mfma_solo &&
                   rt_split_at_root(s->ops, &opsA, &opsB);
         if (ih) {
             if (const char *v = getenv("RAOTEH_INTERP_HALVES")) ih = atoi(v) != 0;
@@ -1383,7 +1383,11 @@ static int sites_create_impl(rt_model *m, int64_t nsites, int kind, int64_t nobs
             src_of_k.push_back(j);
         }
     }
-    const bool generic = opt_force_generic(m->ctx) || m->max_depth > RT_FAST_MAX_DEPTH;
+    // the split-M kernels keep NT * 2 KB of LDS per accumulator slot: above 64 states a tree
+    // that needs more slots than the CU's 160 KB hold runs the generic kernel
+    const int64_t nt_waves = std::max<int64_t>(4, (m->n + 15) / 16);
+    const bool generic = opt_force_generic(m->ctx) || m->max_depth > RT_FAST_MAX_DEPTH ||
+                         (m->n > 64 && nt_waves * m->max_depth * 2048 + 20 * 1024 > 160 * 1024);
     s->layout = (generic || m->n <= 4) ? RT_LAYOUT_LANE : RT_LAYOUT_MFMA;
     // tuning knobs of the lane family (A/B measurements)
     // Default: leaf vectors through the LDS-DMA ring (3 slots) when two 4-wave

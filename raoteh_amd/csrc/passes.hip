@@ -16,8 +16,8 @@
 
 namespace {
 
-// One 64-lane workgroup holds 64 / n sites (n <= 32; one site above): lane =
-// (site slot, state).  The sites of a workgroup never exchange anything, so the
+// One 64-lane workgroup holds 64 / n sites (n <= 32; one site above, in a workgroup of
+// 128 lanes for 64 < n <= 128): lane = (site slot, state).  The sites of a workgroup never exchange anything, so the
 // arithmetic of a site is the same in every packing; at n = 4 a wave carries 16
 // sites instead of one with 60 idle lanes.
 struct site_lane {
@@ -42,8 +42,9 @@ inline unsigned pass_grid(int64_t nsites, int64_t n)
     const int64_t per = n <= 32 ? 64 / n : 1;
     return (unsigned)((nsites + per - 1) / per);
 }
+inline unsigned pass_block(int64_t n) { return n > 64 ? 128u : 64u; }
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(128)
 pset_kernel(int nnodes, int n, long nsites, const long *__restrict__ idx,
             const long *__restrict__ ptr, const double *__restrict__ esd,
             long *__restrict__ mask)
@@ -69,7 +70,7 @@ pset_kernel(int nnodes, int n, long nsites, const long *__restrict__ idx,
     }
 }
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(128)
 set_kernel(int nnodes, int n, long nsites, const long *__restrict__ idx,
            const long *__restrict__ ptr, const double *__restrict__ esd,
            long *__restrict__ mask)
@@ -93,7 +94,7 @@ set_kernel(int nnodes, int n, long nsites, const long *__restrict__ idx,
     }
 }
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(128)
 pmap_kernel(int nnodes, int n, long nsites, const long *__restrict__ idx,
             const long *__restrict__ ptr, const double *__restrict__ esd,
             const long *__restrict__ mask, const double *__restrict__ obs,
@@ -212,10 +213,10 @@ int mask_pass(rt_ctx *ctx, bool forward, int64_t nnodes, int64_t n, int64_t nsit
                                   ctx->stream);
     if (e == hipSuccess) {
         if (forward)
-            hipLaunchKernelGGL(set_kernel, dim3(pass_grid(nsites, n)), dim3(64), 0, ctx->stream, (int)nnodes, (int)n,
+            hipLaunchKernelGGL(set_kernel, dim3(pass_grid(nsites, n)), dim3(pass_block(n)), 0, ctx->stream, (int)nnodes, (int)n,
                        (long)nsites, d.idx, d.ptr, d.esd, dm);
         else
-            hipLaunchKernelGGL(pset_kernel, dim3(pass_grid(nsites, n)), dim3(64), 0, ctx->stream, (int)nnodes, (int)n,
+            hipLaunchKernelGGL(pset_kernel, dim3(pass_grid(nsites, n)), dim3(pass_block(n)), 0, ctx->stream, (int)nnodes, (int)n,
                        (long)nsites, d.idx, d.ptr, d.esd, dm);
         e = hipGetLastError();
     }
@@ -267,11 +268,11 @@ extern "C" int rt_mcy_esd_passes(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t
     RT_HIP(hipMemcpyAsync(d_esd, esd, (size_t)nnodes * n * n * 8, hipMemcpyHostToDevice, st));
     RT_HIP(hipMemcpyAsync(d_mask, state_mask, bytes, hipMemcpyHostToDevice, st));
     if (d_obs) RT_HIP(hipMemcpyAsync(d_obs, obs_likelihood, bytes, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(pset_kernel, dim3(pass_grid(nsites, n)), dim3(64), 0, st, (int)nnodes, (int)n,
+    hipLaunchKernelGGL(pset_kernel, dim3(pass_grid(nsites, n)), dim3(pass_block(n)), 0, st, (int)nnodes, (int)n,
                        (long)nsites, d_idx, d_ptr, d_esd, d_mask);
-    hipLaunchKernelGGL(set_kernel, dim3(pass_grid(nsites, n)), dim3(64), 0, st, (int)nnodes, (int)n,
+    hipLaunchKernelGGL(set_kernel, dim3(pass_grid(nsites, n)), dim3(pass_block(n)), 0, st, (int)nnodes, (int)n,
                        (long)nsites, d_idx, d_ptr, d_esd, d_mask);
-    hipLaunchKernelGGL(pmap_kernel, dim3(pass_grid(nsites, n)), dim3(64), 0, st, (int)nnodes, (int)n,
+    hipLaunchKernelGGL(pmap_kernel, dim3(pass_grid(nsites, n)), dim3(pass_block(n)), 0, st, (int)nnodes, (int)n,
                        (long)nsites, d_idx, d_ptr, d_esd, d_mask, d_obs, d_out);
     RT_HIP(hipGetLastError());
     RT_HIP(hipMemcpyAsync(state_mask, d_mask, bytes, hipMemcpyDeviceToHost, st));
@@ -316,7 +317,7 @@ extern "C" int rt_mcy_esd_get_node_to_pmap(rt_ctx *ctx, int64_t nnodes, int64_t 
         e = hipMemcpyAsync(dobs, obs_likelihood, bytes, hipMemcpyHostToDevice,
                            ctx->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(pmap_kernel, dim3(pass_grid(nsites, n)), dim3(64), 0, ctx->stream, (int)nnodes, (int)n,
+        hipLaunchKernelGGL(pmap_kernel, dim3(pass_grid(nsites, n)), dim3(pass_block(n)), 0, ctx->stream, (int)nnodes, (int)n,
                        (long)nsites, d.idx, d.ptr, d.esd, dm, dobs, dout);
         e = hipGetLastError();
     }
@@ -350,14 +351,14 @@ extern "C" int rt_mcy_esd_get_node_to_pmap(rt_ctx *ctx, int64_t nnodes, int64_t 
 namespace {
 
 template <bool JOINT>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(128)
 distn_kernel(int nnodes, int n, long nsites, const long *__restrict__ idx,
              const long *__restrict__ ptr, const double *__restrict__ esd,
              const double *__restrict__ root_distn, const double *__restrict__ pmap_all,
              double *__restrict__ distn_all, double *__restrict__ joint_all,
              int *__restrict__ status)
 {
-    __shared__ double wbuf[64];
+    __shared__ double wbuf[128];
     __shared__ int bad[64];
     const site_lane L = lane_site(n, nsites);
     const int s = L.s, lane0 = L.slot * n;         // first lane of this site
@@ -449,11 +450,11 @@ int distn_pass(rt_ctx *ctx, bool joint, int64_t nnodes, int64_t n, int64_t nsite
         e = hipMemcpyAsync(dr, root_distn, n * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
         if (joint)
-            hipLaunchKernelGGL(distn_kernel<true>, dim3(pass_grid(nsites, n)), dim3(64), 0, ctx->stream, (int)nnodes, (int)n,
+            hipLaunchKernelGGL(distn_kernel<true>, dim3(pass_grid(nsites, n)), dim3(pass_block(n)), 0, ctx->stream, (int)nnodes, (int)n,
                        (long)nsites, d.idx, d.ptr, d.esd, dr, dp,
                                dd, dj, ds);
         else
-            hipLaunchKernelGGL(distn_kernel<false>, dim3(pass_grid(nsites, n)), dim3(64), 0, ctx->stream, (int)nnodes, (int)n,
+            hipLaunchKernelGGL(distn_kernel<false>, dim3(pass_grid(nsites, n)), dim3(pass_block(n)), 0, ctx->stream, (int)nnodes, (int)n,
                        (long)nsites, d.idx, d.ptr, d.esd, dr, dp,
                                dd, dj, ds);
         e = hipGetLastError();
@@ -515,11 +516,11 @@ ratio_sum_kernel(int nnodes, int n, int nsites, const int *__restrict__ parent,
                  const double *__restrict__ distn_all, const double *__restrict__ weights,
                  double *__restrict__ part)
 {
-    __shared__ double Ps[RT_MAX_STATES * RT_MAX_STATES];
-    __shared__ double p[RT_MAX_STATES], u[RT_MAX_STATES];
+    __shared__ double Ps[RT_MAX_EXPECT_STATES * RT_MAX_EXPECT_STATES];
+    __shared__ double p[RT_MAX_EXPECT_STATES], u[RT_MAX_EXPECT_STATES];
     const int c = blockIdx.x, g = blockIdx.y, G = gridDim.y, t = threadIdx.x;
     const int nn = n * n;
-    constexpr int PER = RT_MAX_STATES * RT_MAX_STATES / 256;
+    constexpr int PER = RT_MAX_EXPECT_STATES * RT_MAX_EXPECT_STATES / 256;
     double acc[PER];
     int ea[PER], eb[PER];
 #pragma unroll
@@ -1365,6 +1366,10 @@ int expectation_weights_impl(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t nsi
 {
     RT_REQUIRE(ctx, "null context");
     RT_TRY(check_tree(nnodes, n, nsites, idx, ptr, esd));
+    if (n > RT_MAX_EXPECT_STATES) {
+        rt_set_error("expectation path: n=%lld > %d", (long long)n, RT_MAX_EXPECT_STATES);
+        return RT_ERR_UNSUPPORTED;
+    }
     RT_REQUIRE(edge_weights && (state_mask || data || nobs == 0 || nsites == 0), "null array");
     std::vector<int> obs_idx;
     if (!state_mask) {
@@ -1448,13 +1453,13 @@ int expectation_weights_impl(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t nsi
     }
     if (d_root) RT_HIP(hipMemcpyAsync(d_root, root_distn, (size_t)n * 8, hipMemcpyHostToDevice, st));
     if (d_w) RT_HIP(hipMemcpyAsync(d_w, site_weights, (size_t)nsites * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(pset_kernel, dim3(pass_grid(nsites, n)), dim3(64), 0, st, (int)nnodes, (int)n,
+    hipLaunchKernelGGL(pset_kernel, dim3(pass_grid(nsites, n)), dim3(pass_block(n)), 0, st, (int)nnodes, (int)n,
                        (long)nsites, d_idx, d_ptr, d_esd, d_mask);
-    hipLaunchKernelGGL(set_kernel, dim3(pass_grid(nsites, n)), dim3(64), 0, st, (int)nnodes, (int)n,
+    hipLaunchKernelGGL(set_kernel, dim3(pass_grid(nsites, n)), dim3(pass_block(n)), 0, st, (int)nnodes, (int)n,
                        (long)nsites, d_idx, d_ptr, d_esd, d_mask);
-    hipLaunchKernelGGL(pmap_kernel, dim3(pass_grid(nsites, n)), dim3(64), 0, st, (int)nnodes, (int)n,
+    hipLaunchKernelGGL(pmap_kernel, dim3(pass_grid(nsites, n)), dim3(pass_block(n)), 0, st, (int)nnodes, (int)n,
                        (long)nsites, d_idx, d_ptr, d_esd, d_mask, (const double *)nullptr, d_pmap);
-    hipLaunchKernelGGL(distn_kernel<false>, dim3(pass_grid(nsites, n)), dim3(64), 0, st, (int)nnodes, (int)n,
+    hipLaunchKernelGGL(distn_kernel<false>, dim3(pass_grid(nsites, n)), dim3(pass_block(n)), 0, st, (int)nnodes, (int)n,
                        (long)nsites, d_idx, d_ptr, d_esd, d_root, d_pmap, d_distn,
                        (double *)nullptr, d_st);
     if (nn <= 128)

@@ -16,14 +16,14 @@
 //                       P_e comes through the scalar cache as FMA operands,
 //                       pending accumulators live in a register stack.
 //                       HBM-bound (config 2).
-//   prune_mfma_kernel   4 < n <= 64   one wave = 16 sites, one workgroup = 64
-//                       sites.  t = P_e * L as v_mfma_f64_16x16x4_f64 tiles:
+//   prune_mfma_kernel   4 < n <= 128  one wave = 16 sites, one workgroup = 64
+//                       sites (n <= 64; above that NT = 5..8 waves share ONE tile).  t = P_e * L as v_mfma_f64_16x16x4_f64 tiles:
 //                       the D tile of one edge IS the B operand of the next
 //                       edge (same lane/register map), so messages never leave
 //                       registers.  P_e is staged once per workgroup in LDS
 //                       (LDS-DMA, double buffered), leaf vectors are loaded in
 //                       B-operand order straight from HBM one step ahead.
-//   prune_generic_kernel  any n <= 64, any stack depth: one lane = one site,
+//   prune_generic_kernel  any n <= 128, any stack depth: one lane = one site,
 //                       accumulators in a global scratch stack.  Fallback only.
 #include "common.h"
 #include "reduce.h"
@@ -577,7 +577,7 @@ prune_lanedma_kernel(const double *__restrict__ Pord,   // [nrec][N][N]
 }
 
 // ---------------------------------------------------------------------------
-// 4 < n <= 64: v_mfma_f64_16x16x4_f64
+// 4 < n <= 128: v_mfma_f64_16x16x4_f64
 // ---------------------------------------------------------------------------
 //
 // Register maps (guide: f64 MFMA 16x16x4): A lane l holds A[l&15][l>>4], B lane
@@ -608,8 +608,12 @@ struct rt_interp_halves {
     double *halfbuf = nullptr;       // null: the whole tree in one program
 };
 
+// waves of a split-M workgroup: whole tiles of NT row-tile waves (NT <= 4: up to four
+// waves; 4 < NT <= 8, i.e. 64 < n <= 128 states: one tile of NT waves)
+__host__ __device__ constexpr int rt_split_waves(int NT) { return NT == 3 ? 3 : (NT < 4 ? 4 : NT); }
+
 template <int NT, int KS, bool STORE>
-__global__ void __launch_bounds__((NT == 3 ? 3 : 4) * 64)
+__global__ void __launch_bounds__(rt_split_waves(NT) * 64)
 prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
                   const int4_t *__restrict__ prog, int nops,   // LOP_* program
                   const double *__restrict__ obs, int K,  // [blk16][K][KP][64][2]
@@ -621,7 +625,7 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
     // Lout / Mout (optional): own rows of L_v and of the message M_v = P_v L_v of every step,
     // [step][tile][m][r][lane] -- what the downward pass and the site sums of the expectation
     // path read back (csrc/expect_mfma.hip)
-    constexpr int WAVES = (NT == 3) ? 3 : 4;
+    constexpr int WAVES = rt_split_waves(NT);
     constexpr int TILES = WAVES / NT;
     constexpr int KP = (KS + 1) / 2;           // k-step pairs
     constexpr int XB = NT * 4 * 64;            // doubles of one x exchange buffer
@@ -829,13 +833,13 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
 // observation if it has one (stream position kroot), then the root step and the site epilogue
 // of prune_mfma_kernel unchanged -- same workgroup shape, same partial sums per wave.
 template <int NT>
-__global__ void __launch_bounds__((NT == 3 ? 3 : 4) * 64)
+__global__ void __launch_bounds__(rt_split_waves(NT) * 64)
 prune_mfma_combine_kernel(const double *__restrict__ halfbuf, const double *__restrict__ obs,
                           int K, int KP, int kroot, const double *__restrict__ root_w, int n,
                           double *__restrict__ loglik, int *__restrict__ status,
                           double *__restrict__ partial, long nsites, long nblocks16)
 {
-    constexpr int WAVES = (NT == 3) ? 3 : 4;
+    constexpr int WAVES = rt_split_waves(NT);
     constexpr int TILES = WAVES / NT;
     __shared__ double red[TILES * NT * 16];
     const int lane = threadIdx.x & 63;
@@ -1214,8 +1218,11 @@ __device__ __forceinline__ double obs_value(int kind, const void *data, long sit
         const unsigned char st = ((const unsigned char *)data)[(size_t)site * nobs + j];
         return (st == 255 || st == s) ? 1.0 : 0.0;
     }
-    const unsigned long long m = ((const unsigned long long *)data)[(size_t)site * nobs + j];
-    return ((m >> s) & 1ull) ? 1.0 : 0.0;
+    // allowed-set masks: ceil(n / 64) words per (site, node), bit s % 64 of word s / 64
+    const int words = (n + 63) >> 6;
+    const unsigned long long m =
+        ((const unsigned long long *)data)[((size_t)site * nobs + j) * words + (s >> 6)];
+    return ((m >> (s & 63)) & 1ull) ? 1.0 : 0.0;
 }
 
 // lane family: [blk][k][pair][lane][2] with S sites per block (64 unless the batch
@@ -1349,7 +1356,7 @@ int rt_sites_pack(rt_sites *s, int kind, const int64_t *src_of_k, const void *da
     size_t in_bytes;
     if (kind == RT_OBS_DENSE) in_bytes = (size_t)s->nsites * K * n * 8;
     else if (kind == RT_OBS_STATE) in_bytes = (size_t)s->nsites * K;
-    else in_bytes = (size_t)s->nsites * K * 8;
+    else in_bytes = (size_t)s->nsites * K * 8 * (size_t)((n + 63) / 64);
     void *d_in = nullptr;
     int *d_src = nullptr;
     std::vector<int> src(K);
@@ -1522,7 +1529,7 @@ static int launch_mfma_inst(rt_model *m, rt_sites *s)
             return RT_OK;
         }
     }
-    constexpr int WAVES = (NT == 3) ? 3 : 4;
+    constexpr int WAVES = rt_split_waves(NT);
     constexpr int TILES = WAVES / NT;
     const int lds = (TILES * NT * 4 * 64 + TILES * NT * 16) * 8 + WAVES * lds_slots * 2048;
     const unsigned grid = (unsigned)((s->nblocks + TILES - 1) / TILES);
@@ -1592,6 +1599,23 @@ static int launch_mfma(rt_model *m, rt_sites *s, const char **name)
     case 14: return launch_mfma_inst<4, 14>(m, s);
     case 15: return launch_mfma_inst<4, 15>(m, s);
     case 16: return launch_mfma_inst<4, 16>(m, s);
+    // 64 < n <= 128: one tile of NT = 5..8 waves per workgroup
+    case 17: return launch_mfma_inst<5, 17>(m, s);
+    case 18: return launch_mfma_inst<5, 18>(m, s);
+    case 19: return launch_mfma_inst<5, 19>(m, s);
+    case 20: return launch_mfma_inst<5, 20>(m, s);
+    case 21: return launch_mfma_inst<6, 21>(m, s);
+    case 22: return launch_mfma_inst<6, 22>(m, s);
+    case 23: return launch_mfma_inst<6, 23>(m, s);
+    case 24: return launch_mfma_inst<6, 24>(m, s);
+    case 25: return launch_mfma_inst<7, 25>(m, s);
+    case 26: return launch_mfma_inst<7, 26>(m, s);
+    case 27: return launch_mfma_inst<7, 27>(m, s);
+    case 28: return launch_mfma_inst<7, 28>(m, s);
+    case 29: return launch_mfma_inst<8, 29>(m, s);
+    case 30: return launch_mfma_inst<8, 30>(m, s);
+    case 31: return launch_mfma_inst<8, 31>(m, s);
+    case 32: return launch_mfma_inst<8, 32>(m, s);
     default: break;
     }
     rt_set_error("no MFMA pruning kernel for n=%lld", (long long)m->n);
@@ -1612,7 +1636,8 @@ static int launch_generic(rt_model *m, rt_sites *s, const char **name)
     if (n <= 8) { *name = "prune_generic<8>"; RT_GEN(8); }
     else if (n <= 16) { *name = "prune_generic<16>"; RT_GEN(16); }
     else if (n <= 32) { *name = "prune_generic<32>"; RT_GEN(32); }
-    else { *name = "prune_generic<64>"; RT_GEN(64); }
+    else if (n <= 64) { *name = "prune_generic<64>"; RT_GEN(64); }
+    else { *name = "prune_generic<128>"; RT_GEN(128); }
 #undef RT_GEN
     return RT_OK;
 }

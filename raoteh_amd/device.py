@@ -523,7 +523,8 @@ class TreeModel(object):
     def upload_sites(self, obs_nodes, data, kind='dense'):
         """obs_nodes: tree nodes (nx ids) carrying per-site data, in the order
         of the data's second axis.  data: dense f64[nsites,nobs,n] | state
-        uint8[nsites,nobs] (255 = unobserved) | mask uint64[nsites,nobs]."""
+        uint8[nsites,nobs] (255 = unobserved) | mask uint64[nsites,nobs] (nstates
+        <= 64) or uint64[nsites,nobs,ceil(nstates/64)] (bit s % 64 of word s // 64)."""
         code = _KINDS[kind]
         idx = _i64([self.tree.node_to_index[v] for v in obs_nodes])
         if kind == 'dense':
@@ -533,8 +534,10 @@ class TreeModel(object):
             data = _as_uint8_states(data, self.nstates)
             ok = data.ndim == 2
         else:
+            # one 64-bit word per node for nstates <= 64, ceil(nstates / 64) words above
             data = np.ascontiguousarray(data, dtype=np.uint64)
-            ok = data.ndim == 2
+            words = (self.nstates + 63) // 64
+            ok = (data.ndim == 2 and words == 1) or (data.ndim == 3 and data.shape[2] == words)
         if not ok or data.shape[1] != len(idx):
             raise ValueError('observation array has the wrong shape')
         nsites = data.shape[0]

@@ -209,6 +209,44 @@ def blinking_allowed_states(primary_state, nprimary, primary_to_part):
     return out
 
 
+def switching_model(Q_default, primary_distn, benign_states, rho):
+    """Compound "switching" process of reference examples/p53/liwen.py:599-621 over
+    2 n states: states 0..n-1 are the reference process (only moves INTO benign
+    states are allowed: edge sa -> sb is kept when sb is benign, :612-615), states
+    n..2n-1 the default process (all of Q_default, :606-608), and every reference
+    state s switches to its default twin n + s at rate rho (:619-620); never back.
+    The diagonal is minus the row sum (_density.rate_matrix_to_numpy_array, :46-48).
+    The prior puts the primary distribution, renormalised, on the benign reference
+    states (:623-627).  Returns (Q f64[2n,2n], distn f64[2n])."""
+    Q_default = np.asarray(Q_default, dtype=float)
+    n = Q_default.shape[0]
+    benign = np.zeros(n, dtype=bool)
+    benign[list(benign_states)] = True
+    off = Q_default - np.diag(np.diag(Q_default))
+    Q = np.zeros((2 * n, 2 * n))
+    Q[n:, n:] = off
+    Q[:n, :n] = off * benign[None, :]
+    Q[np.arange(n), n + np.arange(n)] = rho
+    Q -= np.diag(Q.sum(axis=1))
+    # the reference normalises a dict with Python's sum() in ascending state order
+    # (_util.py:104-109): a plain left-to-right sum, spelled out so that it does not
+    # depend on the interpreter's sum() (compensated from Python 3.12 on)
+    p = np.asarray(primary_distn, dtype=float)
+    total = 0.0
+    for s in range(n):
+        if benign[s]:
+            total += float(p[s])
+    distn = np.zeros(2 * n)
+    distn[:n] = np.where(benign, p, 0.0) / total
+    return Q, distn
+
+
+def switching_allowed_states(codon_state, nstates):
+    """Allowed compound states of a leaf whose codon is observed: the codon in either
+    process (examples/p53/liwen.py:682)."""
+    return [int(codon_state), int(nstates) + int(codon_state)]
+
+
 # ---------------------------------------------------------------------------
 # data
 # ---------------------------------------------------------------------------

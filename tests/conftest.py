@@ -87,6 +87,36 @@ def expectation_cases():
     return out
 
 
+def switching_cases():
+    """tests/golden/switching.json (the 122-state model of examples/p53/liwen.py:599-621)
+    rebuilt from the p53 data files with this repository's builders.  -> (fixture, list of
+    dict(T, root, original_root, nstates, ncompound, Q_default, primary_distn, Q_compound,
+    compound_distn, allowed, want)) where want is the reference's record of the site."""
+    from raoteh_amd import io as rio, synth
+    fx = load_golden('switching')
+    here = os.path.join(GOLDEN, 'p53')
+    code = rio.read_genetic_code(os.path.join(here, 'universal.code.txt'))
+    codon_to_state = dict((c, s) for s, _, c in code)
+    n = fx['nstates']
+    Q_default, primary = rio.mg94_from_code(code, fx['kappa'], fx['omega'], fx['nt'])
+    with open(os.path.join(here, 'p53S.const.tree')) as f:
+        T, original_root, leaf_name_pairs = rio.read_newick(f.read())
+    name_to_leaf = dict((name, leaf) for leaf, name in leaf_name_pairs)
+    root = name_to_leaf['Has']
+    assert (root, original_root) == (fx['root'], fx['original_root'])
+    cases = []
+    for rec in fx['sites']:
+        Qc, dc = synth.switching_model(Q_default, primary, rec['benign_states'], fx['rho'])
+        allowed = dict((v, set(range(2 * n))) for v in T)
+        for name, codon in zip(fx['names'], rec['column']):
+            allowed[name_to_leaf[name]] = set(
+                synth.switching_allowed_states(codon_to_state[codon], n))
+        cases.append(dict(T=T, root=root, original_root=original_root, nstates=n,
+                          ncompound=2 * n, Q_default=Q_default, primary_distn=primary,
+                          Q_compound=Qc, compound_distn=dc, allowed=allowed, want=rec))
+    return fx, cases
+
+
 @pytest.fixture(scope='session')
 def golden():
     return load_golden

@@ -17,7 +17,8 @@ import networkx as nx
 import numpy as np
 import pytest
 
-from conftest import expectation_cases, load_golden, tree_from_edges, config_from_golden
+from conftest import (expectation_cases, load_golden, tree_from_edges, config_from_golden,
+                      switching_cases)
 from oracle import oracle_numpy as orc
 
 pytestmark = pytest.mark.gpu
@@ -491,7 +492,8 @@ def _random_case(ra, rng, n, nnodes, nsites, internal_obs=True, sparse=False):
     return T, root, obs_nodes, w
 
 
-@pytest.mark.parametrize('n', [1, 2, 3, 4, 5, 8, 13, 16, 20, 33, 48, 61, 64])
+@pytest.mark.parametrize('n', [1, 2, 3, 4, 5, 8, 13, 16, 20, 33, 48, 61, 64,
+                               65, 77, 96, 100, 113, 122, 128])
 def test_fast_kernels_random_trees(ra, n):
     rng = np.random.RandomState(100 + n)
     for nnodes, nsites in ((2, 1), (7, 65), (30, 257), (41, 1000)):
@@ -523,11 +525,19 @@ def test_fast_kernels_random_trees(ra, n):
             masks = bits.astype(np.uint64)
             dm = ((masks[..., None] >> np.arange(n, dtype=np.uint64)) & 1
                   ).astype(np.float64)
-            want, wst = orc.batch_log_likelihoods(idx, ptr, esd, oidx, dm, w)
-            ll, st = model.log_likelihoods(
-                model.upload_sites(obs_nodes, masks, kind='mask'))
-            np.testing.assert_array_equal(st & 1, wst)
-            np.testing.assert_allclose(ll[wst == 0], want[wst == 0], rtol=RTOL_LL)
+        else:
+            # ceil(n / 64) words per node: bit s % 64 of word s // 64
+            dm = (rng.uniform(size=(nsites, len(obs_nodes), n)) < 0.3).astype(np.float64)
+            dm[..., rng.randint(n)] = 1.0
+            masks = np.zeros((nsites, len(obs_nodes), (n + 63) // 64), dtype=np.uint64)
+            for sidx in range(n):
+                masks[..., sidx // 64] |= (dm[..., sidx].astype(np.uint64)
+                                           << np.uint64(sidx % 64))
+        want, wst = orc.batch_log_likelihoods(idx, ptr, esd, oidx, dm, w)
+        ll, st = model.log_likelihoods(
+            model.upload_sites(obs_nodes, masks, kind='mask'))
+        np.testing.assert_array_equal(st & 1, wst)
+        np.testing.assert_allclose(ll[wst == 0], want[wst == 0], rtol=RTOL_LL)
         # type x: states with some unobserved
         states = rng.randint(0, n, size=(nsites, len(obs_nodes))).astype(np.uint8)
         states[rng.uniform(size=states.shape) < 0.15] = 255
@@ -543,7 +553,7 @@ def test_fast_kernels_random_trees(ra, n):
         np.testing.assert_allclose(ll[wst == 0], want[wst == 0], rtol=RTOL_LL)
 
 
-@pytest.mark.parametrize('n', [4, 20, 61])
+@pytest.mark.parametrize('n', [4, 20, 61, 122])
 def test_generic_kernel_agrees(ra, n):
     rng = np.random.RandomState(n)
     T, root, obs_nodes, w = _random_case(ra, rng, n, 25, 300)
@@ -710,6 +720,123 @@ def test_tree_specialised_kernel_is_bit_identical(ra, n):
         out[1] = out[1, 64]
         np.testing.assert_array_equal(out[1][1] & 1, wst)
         np.testing.assert_allclose(out[1][0][wst == 0], want[wst == 0], rtol=RTOL_LL)
+
+
+def test_switching_model_122_states(ra):
+    """The 122-state switching model of examples/p53/liwen.py:599-621 on the p53 tree rooted
+    at the leaf 'Has': _mcy_dense.get_likelihood as liwen.py:150-158 calls it, the node
+    marginals of :138-148, StructuralZeroProb, and the batched path -- against the
+    reference's own numbers (tests/golden/switching.json, unaccelerated _mcy / _mc0 twins
+    on scipy's expm) and the oracle."""
+    from raoteh_amd import _mc0_dense
+    from raoteh_amd._util import StructuralZeroProb
+    fx, cases = switching_cases()
+    n2 = fx['ncompound']
+    seen_zero = False
+    for c in cases:
+        want = c['want']
+        T_aug = ra.mjp.get_expm_augmented_tree(c['T'], c['root'], Q_default=c['Q_compound'])
+        if want['log_likelihood'] is None:
+            with pytest.raises(StructuralZeroProb):
+                ra.mcy.get_likelihood(T_aug, c['root'], n2, node_to_allowed_states=c['allowed'],
+                                      root_distn=c['compound_distn'], P_default=None)
+            seen_zero = True
+            continue
+        lk = ra.mcy.get_likelihood(T_aug, c['root'], n2, node_to_allowed_states=c['allowed'],
+                                   root_distn=c['compound_distn'], P_default=None)
+        assert np.log(lk) == pytest.approx(want['log_likelihood'], rel=RTOL_LL)
+        lk2 = ra.mjp.get_likelihood(c['T'], c['allowed'], c['root'], n2,
+                                    root_distn=c['compound_distn'], Q_default=c['Q_compound'])
+        assert lk2 == lk
+        node_to_pmap = ra.mcy.get_node_to_pmap(T_aug, c['root'], n2,
+                                               node_to_allowed_states=c['allowed'])
+        np.testing.assert_allclose(node_to_pmap[c['root']], want['root_pmap'], rtol=1e-10,
+                                   atol=1e-300)
+        node_to_distn = _mc0_dense.get_node_to_distn_esd(
+            T_aug, c['root'], node_to_pmap, n2, root_distn=c['compound_distn'])
+        d0 = node_to_distn[c['original_root']]
+        np.testing.assert_allclose(d0, want['original_root_distn'], rtol=1e-9, atol=1e-18)
+        assert d0[:fx['nstates']].sum() == pytest.approx(want['p_reference'], rel=RTOL_LL)
+        if 'P_scipy' in want:
+            nb = want['P_scipy_node']
+            P = T_aug[dict(nx.bfs_predecessors(T_aug, c['root']))[nb]][nb]['P']
+            np.testing.assert_allclose(P[want['P_scipy_rows']], want['P_scipy'], rtol=1e-11,
+                                       atol=1e-18)
+    assert seen_zero
+    # batched: the sites that share a rate matrix cannot be one batch here (a matrix per
+    # column), so each column is replicated with its leaf sets perturbed: masks of two
+    # words per node against the oracle, interpreter and generic kernels
+    c = cases[0]
+    leaves = [v for v in c['T'] if c['T'].degree(v) == 1]
+    rng = np.random.RandomState(5)
+    nsites = 300
+    dm = np.zeros((nsites, len(leaves), n2))
+    for i in range(nsites):
+        for k, v in enumerate(leaves):
+            cod = rng.randint(fx['nstates']) if rng.uniform() < 0.2 else min(c['allowed'][v])
+            dm[i, k, [cod, fx['nstates'] + cod]] = 1.0
+    masks = np.zeros((nsites, len(leaves), 2), dtype=np.uint64)
+    for sidx in range(n2):
+        masks[..., sidx // 64] |= dm[..., sidx].astype(np.uint64) << np.uint64(sidx % 64)
+    sites = [dict((v, set(np.nonzero(dm[i, k])[0])) for k, v in enumerate(leaves))
+             for i in range(4)]
+    np.testing.assert_array_equal(ra.mjp.allowed_states_to_masks(sites, leaves, n2), masks[:4])
+    model = ra.device.TreeModel(c['T'], c['root'], n2)
+    model.set_rates(Q_default=c['Q_compound'])
+    model.set_root_distn(c['compound_distn'])
+    pre, idx, ptr, esd = orc.get_expm_augmented_transitions(c['T'], c['root'], n2,
+                                                            Q_default=c['Q_compound'])
+    np.testing.assert_allclose(model.get_transitions()[1:], esd[1:], rtol=1e-10, atol=1e-16)
+    oidx = [pre.index(v) for v in leaves]
+    wl, wst = orc.batch_log_likelihoods(idx, ptr, esd, oidx, dm, c['compound_distn'])
+    assert 0 < wst.sum() < nsites
+    for kind, data in (('mask', masks), ('dense', dm)):
+        batch = model.upload_sites(leaves, data, kind=kind)
+        ll, st = model.log_likelihoods(batch)
+        assert batch.kernel_name.startswith('prune_mfma<8,31'), batch.kernel_name
+        np.testing.assert_array_equal(st & 1, wst)
+        np.testing.assert_allclose(ll[wst == 0], wl[wst == 0], rtol=RTOL_LL)
+        assert np.all(np.isneginf(ll[wst != 0]))
+
+
+@pytest.mark.parametrize('n', [65, 100, 128])
+def test_reference_format_passes_above_64_states(ra, n):
+    """pset / set / pmap / distn / joint on the reference's arrays at 64 < n <= 128 (one
+    128-lane workgroup per site) against the oracle's restatement of the pyfelscore twins."""
+    rng = np.random.RandomState(n)
+    T, root, obs_nodes, w = _random_case(ra, rng, n, 19, 3, sparse=True)
+    pre, idx, ptr, esd = orc.get_esd_transitions(T, root, n)
+    nsites = 3
+    mask = (rng.uniform(size=(nsites, len(pre), n)) < 0.5).astype(np.int64)
+    mask[:, :, rng.randint(n)] = 1
+    want_mask, want_pmap, want_distn, want_joint = [], [], [], []
+    for i in range(nsites):
+        m = mask[i].copy()
+        orc.mcy_esd_get_node_to_pset(idx, ptr, esd, m)
+        orc.esd_get_node_to_set(idx, ptr, esd, m)
+        pm = orc.mcy_esd_get_node_to_pmap(idx, ptr, esd, m)
+        dn = orc.mc0_esd_get_node_to_distn(idx, ptr, esd, w, pm)
+        want_mask.append(m)
+        want_pmap.append(pm)
+        want_distn.append(dn)
+        want_joint.append(orc.mc0_esd_get_joint_endpoint_distn(idx, ptr, esd, pm, dn))
+    got_mask = mask.copy()
+    ra.ctx.node_to_pset(idx, ptr, esd, got_mask)
+    ra.ctx.node_to_set(idx, ptr, esd, got_mask)
+    np.testing.assert_array_equal(got_mask, np.array(want_mask))
+    pmap = np.empty(mask.shape)
+    ra.ctx.node_to_pmap(idx, ptr, esd, got_mask, pmap)
+    np.testing.assert_allclose(pmap, np.array(want_pmap), rtol=1e-12, atol=1e-300)
+    both = mask.copy()
+    pmap2 = np.empty(mask.shape)
+    ra.ctx.passes(idx, ptr, esd, both, pmap2)
+    np.testing.assert_array_equal(both, got_mask)
+    np.testing.assert_array_equal(pmap2, pmap)
+    distn, status = ra.ctx.node_to_distn(idx, ptr, esd, w, pmap)
+    assert not status.any()
+    np.testing.assert_allclose(distn, np.array(want_distn), rtol=1e-11, atol=1e-300)
+    J = ra.ctx.joint_endpoint_distn(idx, ptr, esd, pmap, distn)
+    np.testing.assert_allclose(J, np.array(want_joint), rtol=1e-11, atol=1e-300)
 
 
 def test_deep_caterpillar_and_wide_star(ra):

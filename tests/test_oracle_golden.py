@@ -10,7 +10,8 @@ import networkx as nx
 import numpy as np
 import pytest
 
-from conftest import load_golden, tree_from_edges, config_from_golden, expectation_cases
+from conftest import (load_golden, tree_from_edges, config_from_golden, expectation_cases,
+                      switching_cases)
 from oracle import oracle_numpy as orc
 
 RTOL = 1e-12
@@ -336,3 +337,54 @@ def test_spectral_restatement_matches_the_reference_qtop():
                 np.testing.assert_allclose(orc.spectral_getp_v2(D, A2, lam2, B2, t),
                                            orc.spectral_getp_v2(D, A, lam, B, t),
                                            rtol=1e-10, atol=1e-13)
+
+
+def test_switching_model_builder_matches_liwen():
+    # examples/p53/liwen.py:599-627 run by tools/gen_golden.py with the reference's own
+    # helpers: the compound rate matrix and prior of synth.switching_model are those
+    fx, cases = switching_cases()
+    assert fx['ncompound'] == 122
+    for c in cases:
+        want = c['want']
+        np.testing.assert_allclose(c['compound_distn'], want['compound_distn'],
+                                   rtol=1e-15, atol=0)
+        if 'Q_compound_nonzero' in want:
+            Q = np.zeros((122, 122))
+            for a, b, v in want['Q_compound_nonzero']:
+                Q[a, b] = v
+            # io.mg94_from_code vs create_mg94: the same numbers to rounding
+            np.testing.assert_allclose(c['Q_compound'], Q, rtol=1e-13, atol=0)
+            assert ((c['Q_compound'] != 0) == (Q != 0)).all()
+
+
+def test_switching_oracle_matches_reference():
+    # 122 states: likelihood, StructuralZeroProb and the posterior probability that the
+    # original root is in the reference process (liwen.py:367-415)
+    fx, cases = switching_cases()
+    seen_zero = False
+    for c in cases:
+        want = c['want']
+        args = (c['T'], c['allowed'], c['root'], c['ncompound'])
+        if want['log_likelihood'] is None:
+            with pytest.raises(orc.StructuralZeroProb):
+                orc.mjp_dense_get_likelihood(*args, root_distn=c['compound_distn'],
+                                             Q_default=c['Q_compound'])
+            seen_zero = True
+            continue
+        lk = orc.mjp_dense_get_likelihood(*args, root_distn=c['compound_distn'],
+                                          Q_default=c['Q_compound'])
+        assert np.log(lk) == pytest.approx(want['log_likelihood'], rel=1e-11)
+        preorder, indices, indptr, esd = orc.get_expm_augmented_transitions(
+            c['T'], c['root'], c['ncompound'], Q_default=c['Q_compound'])
+        if 'P_scipy' in want:
+            k = preorder.index(want['P_scipy_node'])
+            np.testing.assert_allclose(esd[k][want['P_scipy_rows']], want['P_scipy'],
+                                       rtol=1e-12, atol=1e-300)
+        mask = orc.define_state_mask(c['allowed'], preorder, c['ncompound'])
+        _, pmap = orc.esd_get_node_to_pmap(indices, indptr, esd, mask)
+        np.testing.assert_allclose(pmap[0], want['root_pmap'], rtol=1e-10, atol=1e-300)
+        distn = orc.mc0_esd_get_node_to_distn(indices, indptr, esd, c['compound_distn'], pmap)
+        d0 = distn[preorder.index(c['original_root'])]
+        np.testing.assert_allclose(d0, want['original_root_distn'], rtol=1e-9, atol=1e-18)
+        assert d0[:61].sum() == pytest.approx(want['p_reference'], rel=1e-11)
+    assert seen_zero

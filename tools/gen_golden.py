@@ -24,6 +24,7 @@ Reference functions exercised:
   examples/code2x3/run.py do_blinking_process  :329-475 (builder of the config-5 model)
   _graph_transform.get_chunk_tree_type_b       raoteh/sampler/_graph_transform.py:298-375
   _mc0.get_node_to_distn                       raoteh/sampler/_mc0.py:382-462
+  examples/p53/liwen.py:566-636,677-682        the 122-state switching model (fixture_switching)
 expm per edge is ``scipy.linalg.expm(Q*t)`` exactly as ``_mjp_dense.py:24-25``.
 
 usage: python tools/gen_golden.py [--out tests/golden]
@@ -963,6 +964,126 @@ def fixture_spectral(mods):
     return dict(cases=cases)
 
 
+def fixture_switching(mods, nsites=5):
+    """The 122-state "switching" model of examples/p53/liwen.py: MG94 codon process
+    (create_mg94, parameters of get_jeff_params_e :273-300) x {reference, default},
+    built step by step as liwen.py:566-636 builds it (the same reference helpers:
+    create_mg94.create_mg94, _density.rate_matrix_to_numpy_array / dict_to_numpy_array,
+    _util.get_normalized_dict_distn), on the p53 tree re-rooted at the leaf 'Has'
+    (:476-477), leaf sets {c, 61 + c} (:682).  The disease table liwen.py reads is not
+    in the reference tree, so each column gets a seeded benign set of amino acids (the
+    residues seen in the column plus a random half of the others).  Likelihoods and the
+    posterior probability that the ORIGINAL root is in the reference process
+    (:403-415) come from the reference's unaccelerated type-y functions
+    (_mcy.py:396-470,611-682, _mc0.py:89-138,202-252,382-462) with P = scipy expm."""
+    sys.path.insert(0, REF + '/examples/p53')
+    if not hasattr(nx, 'to_numpy_matrix'):
+        nx.to_numpy_matrix = lambda G, **kw: np.asmatrix(nx.to_numpy_array(G, **kw))
+    import create_mg94
+    from raoteh_amd import io as rio
+    _util, _density, _mc0 = mods['_util'], mods['_density'], mods['_mc0']
+    here = os.path.join(os.path.dirname(HERE), 'tests', 'golden', 'p53')
+    genetic_code = rio.read_genetic_code(os.path.join(here, 'universal.code.txt'))
+    codon_to_state = dict((c, s) for s, r, c in genetic_code)
+    nstates = len(genetic_code)
+    states = list(range(nstates))
+    # get_jeff_params_e (liwen.py:273-300) on the tree shipped with the p53 example
+    rho = 0.61610
+    AG = 0.50862
+    CT = 1 - AG
+    A = AG * 0.49373
+    G = AG - A
+    T = CT * 0.38884
+    C = CT - T
+    kappa = 3.38714
+    omega = 0.37767
+    Q, primary_distn, state_to_residue, residue_to_part = create_mg94.create_mg94(
+        A, C, G, T, kappa, omega, genetic_code, target_expected_rate=1.0)
+    Q_dense = _density.rate_matrix_to_numpy_array(Q, nodelist=states)
+    with open(os.path.join(here, 'p53S.const.tree')) as f:
+        tree, original_root, leaf_name_pairs = rio.read_newick(f.read())
+    name_to_leaf = dict((name, leaf) for leaf, name in leaf_name_pairs)
+    root = name_to_leaf['Has']
+    name_codons = rio.read_phylip(os.path.join(here, 'alignment.for.codeml.phylip'))
+    names = [nm for nm, _ in name_codons]
+    columns = list(zip(*[cod for _, cod in name_codons]))
+    residues = sorted(set(r for s, r, c in genetic_code))
+    rng = np.random.RandomState(20131205)
+    ncompound = 2 * nstates
+    compound_states = list(range(ncompound))
+    sites = []
+    t0 = time.time()
+    for i in range(nsites):
+        column = [c.upper() for c in columns[i]]
+        seen = set(state_to_residue[codon_to_state[c]] for c in column)
+        others = [r for r in residues if r not in seen]
+        extra = [r for r in others if rng.random_sample() < 0.5]
+        benign_residues = seen | set(extra)
+        if i == 1:                     # a column whose observed residue may be lethal somewhere
+            benign_residues = set(extra) | set(sorted(seen)[:1])
+        benign_states = set(s for s, r, c in genetic_code if r in benign_residues)
+        # liwen.py:599-627
+        Q_compound = nx.DiGraph()
+        for sa, sb in Q.edges():
+            weight = Q[sa][sb]['weight']
+            Q_compound.add_edge(nstates + sa, nstates + sb, weight=weight)
+        for sa, sb in Q.edges():
+            weight = Q[sa][sb]['weight']
+            if sb in benign_states:
+                Q_compound.add_edge(sa, sb, weight=weight)
+        for s in range(nstates):
+            Q_compound.add_edge(s, nstates + s, weight=rho)
+        compound_weights = {}
+        for s in range(ncompound):
+            if (s in primary_distn) and (s in benign_states):
+                compound_weights[s] = primary_distn[s]
+        compound_distn = _util.get_normalized_dict_distn(compound_weights)
+        Q_compound_dense = _density.rate_matrix_to_numpy_array(
+            Q_compound, nodelist=compound_states)
+        compound_distn_dense = _density.dict_to_numpy_array(
+            compound_distn, nodelist=compound_states)
+        # liwen.py:677-682
+        node_to_allowed_states = dict((n, set(compound_states)) for n in tree)
+        for name, codon in zip(names, column):
+            leaf = name_to_leaf[name]
+            codon_state = codon_to_state[codon]
+            node_to_allowed_states[leaf] = {codon_state, nstates + codon_state}
+        # get_codon_site_inferences (:367-415), compound process, unaccelerated functions
+        tmp = nx.Graph()
+        for a, b, d in tree.edges(data=True):
+            tmp.add_edge(a, b, weight=d['weight'])
+        T_aug, dense = augmented(tmp, root, Q_compound_dense)
+        rec = dict(column=column, benign_residues=sorted(benign_residues),
+                   benign_states=sorted(int(s) for s in benign_states),
+                   compound_distn=compound_distn_dense.tolist())
+        try:
+            pset, nset, pmap = ref_type_y(mods, T_aug, root, node_to_allowed_states)
+            lik = _mc0.get_likelihood(pmap[root], root_distn=compound_distn)
+            node_to_distn = _mc0.get_node_to_distn(T_aug, root, pmap, root_distn=compound_distn)
+            d0 = node_to_distn[original_root]
+            rec.update(likelihood=float(lik), log_likelihood=float(np.log(lik)),
+                       p_reference=float(sum(p for s, p in d0.items() if s < nstates)),
+                       root_pmap=[float(pmap[root].get(s, 0.0)) for s in compound_states],
+                       original_root_distn=[float(d0.get(s, 0.0)) for s in compound_states])
+        except _util.StructuralZeroProb:
+            rec.update(likelihood=0.0, log_likelihood=None, p_reference=None)
+        if i < 2:                      # the compound rate matrix itself, sparse
+            nz = np.nonzero(Q_compound_dense)
+            rec['Q_compound_nonzero'] = [[int(a), int(b), float(Q_compound_dense[a, b])]
+                                         for a, b in zip(*nz)]
+        if i == 0:
+            nb0 = sorted(dense)[0]
+            rec['P_scipy_node'] = int(nb0)
+            rec['P_scipy_rows'] = [0, 60, 61, 121]
+            rec['P_scipy'] = [dense[nb0][r].tolist() for r in (0, 60, 61, 121)]
+        sites.append(rec)
+    return dict(nstates=nstates, ncompound=ncompound, rho=rho, kappa=kappa, omega=omega,
+                nt=dict(A=A, C=C, G=G, T=T), root=int(root), original_root=int(original_root),
+                names=names, Q_default_offdiagonal_checksum=float(np.abs(Q_dense).sum()),
+                primary_distn=[float(primary_distn[s]) for s in states],
+                sites=sites, reference_seconds=time.time() - t0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(os.path.dirname(HERE),
@@ -994,6 +1115,7 @@ def main():
         forest=lambda: fixture_forest(mods),
         chunk_trees=lambda: fixture_chunk_trees(mods),
         spectral=lambda: fixture_spectral(mods),
+        switching=lambda: fixture_switching(mods),
     )
     only = args.only.split(',') if args.only else list(makers)
     fixtures = dict((name, makers[name]()) for name in only)
