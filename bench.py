@@ -9,7 +9,7 @@ the device) -> fragment repack -> Felsenstein upward pass + root reduce + log
 HBM before the timed region starts.  Batches rotate through several HBM copies
 so the 256 MiB Infinity Cache cannot hold the working set.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c5|c4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c5|c4|c6]
                     [--also c2,c5,c4]
 
 The headline (`value`, `roofline`, `cpu_baseline` at the top level) is the
@@ -73,6 +73,11 @@ WORKLOADS = {
                     'vectors', bound='mfma', scaling='strong'),
     'c5': dict(desc='20-state blinking compound process, 32-leaf tree, per-edge Q, '
                     '50000 sites/GPU, dense f64 0/1 leaf masks', bound='hbm', scaling='weak'),
+    # not a BASELINE.json configuration: the 122-state space of examples/p53/liwen.py:599-621
+    # (the caller SURVEY 8b lists that needs more than 64 states) at the shape of C3
+    'c6': dict(desc='122-state switching model (MG94 x {reference, default}, '
+                    'examples/p53/liwen.py:599-621), 64-leaf balanced tree, 10000 sites/GPU, '
+                    'dense f64 0/1 leaf masks {c, 61+c}', bound='mfma', scaling='weak'),
 }
 
 
@@ -182,7 +187,7 @@ def shard_config(name, rank, world, sites):
         total = synth.C4_NSITES if sites is None else sites
         lo, hi = shard_range(total, rank, world)
         return synth.make_config('c4', site_range=(lo, hi)), total
-    per = {'c2': 100000, 'c3': 10000, 'c5': 50000}[name] if sites is None else sites
+    per = {'c2': 100000, 'c3': 10000, 'c5': 50000, 'c6': 10000}[name] if sites is None else sites
     total = per * world
     cfg = synth.make_config(name, nsites=total)
     lo, hi = shard_range(total, rank, world)
@@ -554,7 +559,7 @@ def main():
     ctx = device.Context(0 if os.environ.get('RAOTEH_BENCH_ONE_DEVICE') else local_rank)
 
     if args.also is None:
-        also = [w for w in ('c2', 'c5', 'c4') if w != args.workload]
+        also = [w for w in ('c2', 'c5', 'c6', 'c4') if w != args.workload]
         if args.workload != 'c3':
             also.insert(0, 'c3')
     else:
@@ -589,7 +594,7 @@ def main():
         # the carried workloads use their own short fixed step counts (c4: a step is
         # ~20 ms per million sites) so that the default run still finishes in minutes
         ksteps, kwarm = {'c2': (200, 20), 'c3': (100, 10), 'c5': (100, 10),
-                         'c4': (10, 2)}[w]
+                         'c4': (10, 2), 'c6': (50, 5)}[w]
         extra[w] = run_workload(w, ctx, ctl, rank, world, reduce_kind, ksteps, kwarm, args,
                                 min(cpu_s, 8.0))
     if rank != 0:

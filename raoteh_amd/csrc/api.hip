@@ -1102,7 +1102,7 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
             // split-M family: NT waves share T tiles.  T = 2 halves the A-fragment
             // traffic and the barriers per MFMA but needs the whole register file
             // (one workgroup per CU): worth it once the batch is several rounds deep
-            if (s->model->n > 64) return RT_OK;
+            const bool wide = s->model->n > 64;     // NT = 5..8 waves: one tile per workgroup
             const int64_t ntiles = (s->nsites + 15) / 16;
             // tiles per workgroup: T = 2 (one A fetch and one barrier per two chains, two
             // workgroups per CU) once the batch is several rounds deep; below that one tile
@@ -1110,7 +1110,7 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
             // generator: config 3 (625 tiles) 205 us at T = 1, 211 us at T = 3 (209
             // workgroups, one per CU), 253 us at T = 2; a config-4 shard (7 813 tiles)
             // 1 984 us at T = 2, 2 040 us at T = 1, 2 303 us at T = 3.
-            int T = (ntiles >= 2048 && s->ops.size() <= 300) ? 2 : 1;
+            int T = (ntiles >= 2048 && s->ops.size() <= 300 && !wide) ? 2 : 1;
             bool halves = T == 1 && want_root_halves(s, ntiles);
             // Root halves with as many half-tiles per workgroup as make the launch ONE round
             // of at most one workgroup per CU (3..5 independent chains per SIMD keep the pipe
@@ -1119,10 +1119,10 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
             if (halves && !getenv("RAOTEH_JIT_HALVES_T1")) {
                 const int64_t cus = std::max(1, s->model->ctx->num_cus);
                 const int64_t th = (2 * ntiles + cus - 1) / cus;
-                if (th >= 3 && th <= 5 && s->ops.size() <= 300) T = (int)th;
+                if (th >= 3 && th <= 5 && s->ops.size() <= 300 && !wide) T = (int)th;
             }
             if (const char *v = getenv("RAOTEH_JIT_TILES"))
-                T = std::min(halves ? 5 : 3, std::max(1, atoi(v)));
+                T = std::min(wide ? 2 : halves ? 5 : 3, std::max(1, atoi(v)));
             int D = 2, LA = 1;     // leaves fetched ahead (the pipelined generator needs >= 2)
             if (const char *v = getenv("RAOTEH_JIT_PREFETCH")) D = std::max(1, atoi(v));
             if (const char *v = getenv("RAOTEH_JIT_LOOKAHEAD")) LA = std::max(1, atoi(v));
@@ -1310,7 +1310,8 @@ extern "C" int rt_jit_source(int64_t nnodes, const int64_t *idx, const int64_t *
 {
     RT_REQUIRE(nnodes >= 1 && ptr && (idx || nnodes == 1) && buf && capacity > 0,
                "bad arguments");
-    RT_REQUIRE(n >= 1 && n <= 64, "tree-specialised kernels exist for n <= 64");
+    RT_REQUIRE(n >= 1 && n <= RT_MAX_STATES, "tree-specialised kernels exist for n <= %d",
+               RT_MAX_STATES);
     rt_model m;
     m.nnodes = nnodes;
     if (nnodes > 1) m.indices.assign(idx, idx + (nnodes - 1));

@@ -1090,8 +1090,8 @@ std::string rt_jit_mfma_split_source(const std::vector<rt_op> &ops, int n, int K
           << " + " << i << ") * 3 + " << which << "] = __builtin_readcyclecounter();\n";
     };
     o << "extern \"C\" __global__ void __launch_bounds__(" << 64 * NT
-      << ") __attribute__((amdgpu_waves_per_eu(" << (T == 1 ? "3, 3" : T == 2 ? "2, 2" : "1, 1")
-      << ")))\n"
+      << ") __attribute__((amdgpu_waves_per_eu("
+      << (NT > 4 ? "2, 2" : T == 1 ? "3, 3" : T == 2 ? "2, 2" : "1, 1") << ")))\n"
          "rt_jit_prune(const double *__restrict__ Pfrag, const rt_d2 *__restrict__ obs,\n"
          "             const double *__restrict__ root_w, double *__restrict__ loglik,\n"
          "             int *__restrict__ status, double *__restrict__ partial,\n"
@@ -1488,8 +1488,12 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
         o << "    if (blockIdx.x == " << trace_wg << " && lane == 0) rt_trace[(m * " << (nrec_max + 1)
           << " + " << i << ") * 3 + " << which << "] = __builtin_readcyclecounter();\n";
     };
+    // NT <= 4 waves: one wave per SIMD and workgroup, three / two / one workgroups per CU at
+    // T = 1 / 2 / more tiles.  NT = 5..8 (64 < n <= 128): two waves on some or all SIMDs and
+    // the A fragments of two steps alone are up to 128 registers: one workgroup per CU
     o << "extern \"C\" __global__ void __launch_bounds__(" << 64 * NT
-      << ") __attribute__((amdgpu_waves_per_eu(" << (T == 1 ? "3, 3" : T == 2 ? "2, 2" : "1, 1")
+      << ") __attribute__((amdgpu_waves_per_eu("
+      << (NT > 4 ? "2, 2" : T == 1 ? "3, 3" : T == 2 ? "2, 2" : "1, 1")
       << ")))\n"
          "rt_jit_prune(const double *__restrict__ Pfrag, const rt_d2 *__restrict__ obs,\n"
          "             const double *__restrict__ root_w, double *__restrict__ loglik,\n"

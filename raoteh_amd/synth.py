@@ -368,6 +368,8 @@ def make_config(name, nsites=None, site_range=None):
         seed = 2
     elif name == 'c5':
         return _make_c5(50000 if nsites is None else nsites)
+    elif name == 'c6':
+        return _make_c6(10000 if nsites is None else nsites)
     else:
         raise ValueError('unknown config %r' % (name,))
     node_to_P = dict((nb, _expm(Q, T[na][nb]['weight']))
@@ -413,6 +415,29 @@ def _make_c5(nsites):
                 leaf_states=leaf_primary, obs_kind='mask',
                 leaf_allowed=allowed, nprimary=nprimary,
                 primary_to_part=primary_to_part)
+
+
+def _make_c6(nsites):
+    """Not a BASELINE.json configuration: the state space of examples/p53/liwen.py:599-621
+    (MG94 x {reference, default} = 122 compound states, switching_model above) at the shape
+    of config 3 -- 64-leaf balanced tree, leaf sets {c, 61 + c} (liwen.py:682) for codons
+    simulated from the default process, a seeded half of the amino acids benign."""
+    T, root, leaves = balanced_tree(64, seed=0)
+    Q, distn = mg94()
+    code = genetic_code()
+    rng = np.random.RandomState(6)
+    residues = sorted(set(aa for _, aa in code))
+    benign_res = set(r for r in residues if rng.uniform() < 0.5)
+    benign = [s for s, (_, aa) in enumerate(code) if aa in benign_res]
+    Qc, dc = switching_model(Q, distn, benign, 0.61610)
+    node_to_P = dict((nb, _expm(Q, T[na][nb]['weight']))
+                     for na, nb in nx.bfs_edges(T, root))
+    states = simulate_states(T, root, node_to_P, distn, nsites, 6)
+    leaf_states = np.stack([states[v] for v in leaves], axis=1)
+    n = len(distn)
+    return dict(name='c6', T=T, root=root, leaves=leaves, nstates=2 * n, Q_default=Qc,
+                root_distn=dc, leaf_states=leaf_states, obs_kind='mask',
+                leaf_allowed=[switching_allowed_states(c, n) for c in range(n)])
 
 
 def leaf_likelihoods(cfg, dtype=np.float64):

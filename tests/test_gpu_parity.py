@@ -659,7 +659,7 @@ def test_sparse_api_matches_reference_golden(ra):
         _mjp.get_likelihood(nx.Graph([(0, 1, dict(weight=1.0))]), {}, 5)
 
 
-@pytest.mark.parametrize('n', [1, 2, 3, 4, 5, 13, 16, 20, 32, 33, 48, 61, 64])
+@pytest.mark.parametrize('n', [1, 2, 3, 4, 5, 13, 16, 20, 32, 33, 48, 61, 64, 65, 90, 122, 128])
 def test_tree_specialised_kernel_is_bit_identical(ra, n):
     """jit.hip: the hiprtc-compiled straight-line kernel for one tree performs
     the interpreter kernel's arithmetic in the interpreter's order."""
@@ -685,7 +685,9 @@ def test_tree_specialised_kernel_is_bit_identical(ra, n):
         # ('h5': five half-tiles per workgroup)
         variants = (((0, 0), (1, 64), (1, 49), (1, 7)) if n <= 4 else
                     ((0, 0), (1, 64), (1, 2), (1, 3), (1, 4)) if n <= 32 else
-                    ((0, 0), (1, 64), (1, 2), (1, 3), (1, 'h'), (1, 'h5')))
+                    ((0, 0), (1, 64), (1, 2), (1, 3), (1, 'h'), (1, 'h5')) if n <= 64 else
+                    # 64 < n <= 128: NT = 5..8 waves share one or two tiles
+                    ((0, 0), (1, 64), (1, 2), (1, 'h')))
         for jit, bs in variants:
             ra.lib.check(set_option(b'jit', jit))
             if n <= 4:
@@ -716,7 +718,10 @@ def test_tree_specialised_kernel_is_bit_identical(ra, n):
             np.testing.assert_array_equal(out[0, 0][1], out[key][1])
             assert out[key][2][1] == out[0, 0][2][1] and out[key][2][2] == nsites
             assert out[key][2][0] == pytest.approx(out[0, 0][2][0], rel=1e-13)
-        np.testing.assert_array_equal(out[0, 0][2], out[1, 64][2])
+        # (the batch sum adds the per-wave partial sums in a fixed order that depends on where
+        # a kernel leaves them: the same places up to 64 states, eight waves apart above)
+        if n <= 64:
+            np.testing.assert_array_equal(out[0, 0][2], out[1, 64][2])
         out[1] = out[1, 64]
         np.testing.assert_array_equal(out[1][1] & 1, wst)
         np.testing.assert_allclose(out[1][0][wst == 0], want[wst == 0], rtol=RTOL_LL)
