@@ -110,6 +110,28 @@ int rt_expm(rt_ctx *ctx, int64_t n, int64_t count,
 int rt_expm_spectral(rt_ctx *ctx, int64_t n, int64_t count, const double *A,
             const double *lam, const double *B, const double *D, const double *t, double *P);
 
+/* pyfelscore.get_lb_transition_matrix(t, Q, P) (examples/p53/liwen.py:45; pure-Python twin
+ * getp_lb, liwen.py:47-82) at `count` interval lengths in one launch: the lower bound of
+ * expm(Q t) that keeps the histories with no change (diagonal: exp(t Q[a][a])) or exactly one
+ * change a -> b (rab (exp(-ra t) - exp(-rb t)) / (rb - ra), or rab t exp(-rb t) when ra == rb;
+ * ra = -Q[a][a]).  Q f64[n][n] with diagonal = minus the row sum, t f64[count],
+ * P f64[count][n][n] out.  Any n.                                                       */
+int rt_lb_transition_matrix(rt_ctx *ctx, int64_t n, int64_t count, const double *Q,
+            const double *t, double *P);
+/* pyfelscore.tmjp_get_inhomogeneous_mjp (_tmjp_dense.py:1039-1054; sparse twin
+ * _tmjp.get_inhomogeneous_mjp, _tmjp.py:863-900), same argument order: the tree CSR, the
+ * primary state of the edge above every node (int64[nnodes], entry 0 ignored),
+ * primary_to_part int64[nprimary], Q_primary f64[nprimary][nprimary], the two tolerance
+ * rates and the class under consideration; node_to_allowed_tolerances int64[nnodes][2]
+ * (ones on entry; column 0 cleared where the class of an adjacent edge's state is the class
+ * under consideration) and tol_rate_matrices f64[nnodes][3][3] (keyed by the child index,
+ * diagonal = minus the row sum; the root's slot zero) are filled.  Host only: no context. */
+int rt_tmjp_get_inhomogeneous_mjp(int64_t nnodes, const int64_t *tree_csr_indices,
+            const int64_t *tree_csr_indptr, const int64_t *edge_to_primary_state,
+            int64_t nprimary, const int64_t *primary_to_part, const double *Q_primary,
+            double rate_on, double rate_off, int64_t tolerance_class,
+            int64_t *node_to_allowed_tolerances, double *tol_rate_matrices);
+
 /* The three pyfelscore passes of _mcy_dense.py:261-291, batched over
  * `nsites` independent sites that share the tree and the transitions:
  *   tree_csr_indices int64[nnodes-1], tree_csr_indptr int64[nnodes+1]:
@@ -361,6 +383,21 @@ int rt_forest_passes(rt_ctx *ctx, int64_t n, int64_t ntrees,
             const int64_t *tree_node_offset, const int64_t *tree_csr_indices,
             const int64_t *tree_csr_indptr, const double *P,
             uint64_t *allowed_sets, double *subtree_probability);
+/* pyfelscore.mcy_get_node_to_pset (_mcy.py:158,259; un-accelerated twin _mcy.py:396-470)
+ * and pyfelscore.get_node_to_set (_mcy.py:168; twin _mc0.py:89-138) with the reference's own
+ * arguments: ONE tree (children CSR in preorder index space), the transition matrix as a
+ * boolean CSR shared by every edge (trans_csr_indptr int64[n + 1], trans_csr_indices the
+ * column indices of the nonzero entries of each row, _mcy.py:148-149), state_mask
+ * int64[nnodes][n] 0/1 updated in place.  tmp_state_mask int64[n] is the scratch row
+ * pyfelscore asks for (may be NULL).  n <= 64.                                        */
+int rt_mcy_get_node_to_pset(rt_ctx *ctx, int64_t nnodes, int64_t n,
+            const int64_t *tree_csr_indices, const int64_t *tree_csr_indptr,
+            const int64_t *trans_csr_indices, const int64_t *trans_csr_indptr,
+            int64_t *state_mask);
+int rt_get_node_to_set(rt_ctx *ctx, int64_t nnodes, int64_t n,
+            const int64_t *tree_csr_indices, const int64_t *tree_csr_indptr,
+            const int64_t *trans_csr_indices, const int64_t *trans_csr_indptr,
+            int64_t *state_mask, int64_t *tmp_state_mask);
 /* The same passes followed by _sample_mc0_dense.resample_states (:53-98) for every
  * tree: root ~ root_distn * L[root] (root_distn NULL = weights of one), child ~
  * P[parent's state] * L[child].  Draws come from Philox-4x32-10 keyed by `seed` with

@@ -663,3 +663,38 @@ def reference_faithful_site_loglik(T, root, nstates, node_to_allowed_states,
     lik = mjp_dense_get_likelihood(T, node_to_allowed_states, root, nstates,
                                    root_distn=root_distn, Q_default=Q_default)
     return np.log(lik)
+
+
+# ---------------------------------------------------------------------------
+# pyfelscore.get_lb_transition_matrix (examples/p53/liwen.py:45)
+# ---------------------------------------------------------------------------
+
+def getp_lb(Q, t):
+    """examples/p53/liwen.py:47-82 (``getp_lb``, the pure-Python twin of
+    ``pyfelscore.get_lb_transition_matrix``): entry (a, a) = exp(t Q[a, a]), the probability
+    of no change; entry (a, b) = the probability of exactly one change, of type a -> b:
+    the integral over its time x of exp(-ra x) rab exp(-rb (t - x)).
+
+    Parity status of THIS function: restated from the text of liwen.py, which cannot be
+    imported here (it needs ``dendropy``, absent) -- "parity unpinned" against the reference's
+    own output; tests/test_oracle_golden.py pins it to the integral the reference's comment
+    states (numerical quadrature) and to expm(Q t) as an upper bound."""
+    Q = np.asarray(Q, dtype=float)
+    n = Q.shape[0]
+    P = np.zeros_like(Q)
+    for sa in range(n):
+        for sb in range(n):
+            if sa == sb:
+                p = np.exp(t * Q[sa, sb])
+            else:
+                rab = Q[sa, sb]
+                if rab:
+                    ra, rb = -Q[sa, sa], -Q[sb, sb]
+                    if ra == rb:
+                        p = rab * t * np.exp(-rb * t)
+                    else:
+                        p = rab * ((np.exp(-ra * t) - np.exp(-rb * t)) / (rb - ra))
+                else:
+                    p = 0.0
+            P[sa, sb] = p
+    return P

@@ -62,6 +62,14 @@ SIGNATURES = {
                                    POINTER(c_int64), POINTER(c_char_p)]),
     'rt_expm': (c_int, [c_void_p, c_int64, c_int64, _p_f64, c_int64, _p_i64,
                         _p_f64, _p_f64, _p_i32]),
+    'rt_lb_transition_matrix': (c_int, [c_void_p, c_int64, c_int64, _p_f64, _p_f64, _p_f64]),
+    'rt_tmjp_get_inhomogeneous_mjp': (c_int, [c_int64, _p_i64, _p_i64, _p_i64, c_int64, _p_i64,
+                                              _p_f64, c_double, c_double, c_int64, _p_i64,
+                                              _p_f64]),
+    'rt_mcy_get_node_to_pset': (c_int, [c_void_p, c_int64, c_int64, _p_i64, _p_i64, _p_i64,
+                                        _p_i64, _p_i64]),
+    'rt_get_node_to_set': (c_int, [c_void_p, c_int64, c_int64, _p_i64, _p_i64, _p_i64, _p_i64,
+                                   _p_i64, _p_i64]),
     'rt_mcy_esd_get_node_to_pset': (c_int, [c_void_p, c_int64, c_int64, c_int64,
                                             _p_i64, _p_i64, _p_f64, _p_i64]),
     'rt_esd_get_node_to_set': (c_int, [c_void_p, c_int64, c_int64, c_int64,

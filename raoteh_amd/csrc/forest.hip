@@ -120,7 +120,8 @@ forest_sets_kernel(int n, long ntrees, const long *__restrict__ off,
         wave_lds_order();
     }
     // backward: a state stays at v only if it has a transition into every child's set
-    for (long v = hi - 1; v > lo; --v) {
+    // (forward: 0 = this pass only, 1 = both, 2 = the forward pass only)
+    for (long v = hi - 1; forward != 2 && v > lo; --v) {
         const unsigned long long cset = fits ? lset[w][v - lo] : coherent_load(&allowed[v]);
         const unsigned long long keep = __ballot((rb & cset) != 0ull);
         const long p = lo + parent[v];
@@ -289,7 +290,7 @@ forest_sets_grouped_kernel(int n, long ntrees, const long *__restrict__ off,
         for (long i = lane; i < whi - wlo; i += 64) lset[w][i] = allowed[wlo + i];
         wave_lds_order();
     }
-    for (long step = 0;; ++step) {
+    for (long step = 0; forward != 2; ++step) {
         const long v = hi - 1 - step;
         const bool valid = active && v > lo;
         if (!__any(valid)) break;
@@ -661,6 +662,66 @@ extern "C" int rt_forest_passes(rt_ctx *ctx, int64_t n, int64_t ntrees,
     RT_HIP(hipMemcpyAsync(allowed_sets, f.d_allowed, total * 8, hipMemcpyDeviceToHost, st));
     RT_HIP(hipStreamSynchronize(st));
     return RT_OK;
+}
+
+// pyfelscore.mcy_get_node_to_pset (_mcy.py:158,259; twin _mcy.py:396-470) and
+// pyfelscore.get_node_to_set (_mcy.py:168; twin _mc0.py:89-138) on the reference's own arrays:
+// ONE tree, the transition matrix as a boolean CSR shared by every edge, the int64 0/1 state
+// mask updated in place.  The forest kernels above on a forest of one tree.
+static int shared_matrix_mask_pass(rt_ctx *ctx, int mode, int64_t nnodes, int64_t n,
+                                   const int64_t *idx, const int64_t *ptr, const int64_t *tidx,
+                                   const int64_t *tptr, int64_t *state_mask)
+{
+    RT_REQUIRE(ctx, "null context");
+    RT_REQUIRE(nnodes >= 1 && n >= 1 && ptr && tptr && state_mask, "bad arguments");
+    RT_REQUIRE(n <= 64, "the forest passes hold a state per lane: n <= 64");
+    RT_REQUIRE(tptr[0] == 0 && tptr[n] >= 0 && (tidx || tptr[n] == 0), "bad transition CSR");
+    std::vector<double> P((size_t)n * n, 0.0);
+    for (int64_t a = 0; a < n; ++a) {
+        RT_REQUIRE(tptr[a + 1] >= tptr[a], "trans_csr_indptr not monotone");
+        for (int64_t e = tptr[a]; e < tptr[a + 1]; ++e) {
+            RT_REQUIRE(tidx[e] >= 0 && tidx[e] < n, "trans_csr_indices out of range");
+            P[(size_t)(a * n + tidx[e])] = 1.0;
+        }
+    }
+    const int64_t off[2] = {0, nnodes};
+    forest_dev f;
+    RT_TRY(forest_upload(ctx, n, 1, off, idx, ptr, P.data(), f));
+    std::vector<unsigned long long> sets((size_t)nnodes, 0ull);
+    for (int64_t v = 0; v < nnodes; ++v)
+        for (int64_t a = 0; a < n; ++a)
+            if (state_mask[v * n + a]) sets[(size_t)v] |= 1ull << a;
+    hipStream_t st = ctx->stream;
+    RT_HIP(hipMalloc((void **)&f.d_allowed, nnodes * 8));
+    RT_HIP(hipMemcpyAsync(f.d_allowed, sets.data(), nnodes * 8, hipMemcpyHostToDevice, st));
+    launch_forest_sets((int)n, 1, f.d_off, f.d_parent, f.P.d_rowbits, f.P.d_colbits,
+                       (unsigned long long *)f.d_allowed, mode, st);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipMemcpyAsync(sets.data(), f.d_allowed, nnodes * 8, hipMemcpyDeviceToHost, st));
+    RT_HIP(hipStreamSynchronize(st));
+    for (int64_t v = 0; v < nnodes; ++v)
+        for (int64_t a = 0; a < n; ++a) state_mask[v * n + a] = (int64_t)((sets[(size_t)v] >> a) & 1ull);
+    return RT_OK;
+}
+
+extern "C" int rt_mcy_get_node_to_pset(rt_ctx *ctx, int64_t nnodes, int64_t n,
+        const int64_t *tree_csr_indices, const int64_t *tree_csr_indptr,
+        const int64_t *trans_csr_indices, const int64_t *trans_csr_indptr, int64_t *state_mask)
+{
+    return shared_matrix_mask_pass(ctx, 0, nnodes, n, tree_csr_indices, tree_csr_indptr,
+                                   trans_csr_indices, trans_csr_indptr, state_mask);
+}
+
+extern "C" int rt_get_node_to_set(rt_ctx *ctx, int64_t nnodes, int64_t n,
+        const int64_t *tree_csr_indices, const int64_t *tree_csr_indptr,
+        const int64_t *trans_csr_indices, const int64_t *trans_csr_indptr, int64_t *state_mask,
+        int64_t *tmp_state_mask)
+{
+    // tmp_state_mask int64[n]: the scratch row pyfelscore asks its caller for (_mcy.py:166-174);
+    // left zeroed, as the caller hands it over
+    if (tmp_state_mask) memset(tmp_state_mask, 0, (size_t)n * 8);
+    return shared_matrix_mask_pass(ctx, 2, nnodes, n, tree_csr_indices, tree_csr_indptr,
+                                   trans_csr_indices, trans_csr_indptr, state_mask);
 }
 
 static int forest_resample_impl(rt_ctx *ctx, int64_t n, int64_t ntrees,

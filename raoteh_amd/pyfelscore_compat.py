@@ -14,12 +14,100 @@ import numpy as np
 
 from .device import get_context
 
-__all__ = ['mcy_esd_get_node_to_pset', 'esd_get_node_to_set',
+__all__ = ['mcy_get_node_to_pset', 'get_node_to_set', 'tmjp_get_inhomogeneous_mjp',
+           'get_lb_transition_matrix',
+           'mcy_esd_get_node_to_pset', 'esd_get_node_to_set',
            'mcy_esd_get_node_to_pmap', 'mc0_esd_get_node_to_distn',
            'mc0_esd_get_joint_endpoint_distn', 'get_tolerance_rate_matrix',
            'get_mmpp_block', 'get_mmpp_block_zero_off_rate',
            'get_mmpp_frechet_all_positive', 'get_mmpp_frechet_diagonalizable_w_zero',
            'get_mmpp_frechet_defective_w_zero', 'get_tolerance_expectations']
+
+
+def _i64c(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _check_mask(state_mask):
+    if state_mask.dtype != np.int64 or not state_mask.flags['C_CONTIGUOUS']:
+        raise ValueError('state_mask must be a C-contiguous int64 array')
+
+
+def mcy_get_node_to_pset(tree_csr_indices, tree_csr_indptr, trans_csr_indices,
+                         trans_csr_indptr, state_mask):
+    """call sites: _mcy.py:158,259 -- ONE transition matrix, given as a boolean CSR, on
+    every edge (the uniformized P of a Rao-Teh sweep); state_mask int[nnodes, nstates]
+    is updated in place (backward pass)."""
+    import ctypes
+    from . import _lib
+    _check_mask(state_mask)
+    idx, ptr = _i64c(tree_csr_indices), _i64c(tree_csr_indptr)
+    tidx, tptr = _i64c(trans_csr_indices), _i64c(trans_csr_indptr)
+    p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+    _lib.check(_lib.lib().rt_mcy_get_node_to_pset(
+        get_context()._h, state_mask.shape[0], state_mask.shape[1], p(idx), p(ptr), p(tidx),
+        p(tptr), p(state_mask)))
+
+
+def get_node_to_set(tree_csr_indices, tree_csr_indptr, trans_csr_indices, trans_csr_indptr,
+                    state_mask, tmp_state_mask):
+    """call site: _mcy.py:168 -- the forward pass with the same shared matrix;
+    tmp_state_mask int[nstates] is the scratch row pyfelscore asks for."""
+    import ctypes
+    from . import _lib
+    _check_mask(state_mask)
+    idx, ptr = _i64c(tree_csr_indices), _i64c(tree_csr_indptr)
+    tidx, tptr = _i64c(trans_csr_indices), _i64c(trans_csr_indptr)
+    tmp = np.zeros(state_mask.shape[1], dtype=np.int64)
+    p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+    _lib.check(_lib.lib().rt_get_node_to_set(
+        get_context()._h, state_mask.shape[0], state_mask.shape[1], p(idx), p(ptr), p(tidx),
+        p(tptr), p(state_mask), p(tmp)))
+    if tmp_state_mask is not None:
+        tmp_state_mask[...] = tmp
+
+
+def tmjp_get_inhomogeneous_mjp(tree_csr_indices, tree_csr_indptr, edge_to_primary_state,
+                               primary_to_part_array, Q_primary, rate_on, rate_off,
+                               tolerance_class, node_to_allowed_tolerances_array,
+                               tol_rate_matrices):
+    """call site: _tmjp_dense.py:1039-1054 (sparse twin _tmjp.py:863-900): fills the 3 x 3
+    tolerance rate matrix of every edge and clears tolerance state 0 at the endpoints of
+    edges whose primary state belongs to ``tolerance_class``."""
+    import ctypes
+    from . import _lib
+    out_a, out_m = node_to_allowed_tolerances_array, tol_rate_matrices
+    if out_a.dtype != np.int64 or not out_a.flags['C_CONTIGUOUS'] or \
+            out_m.dtype != np.float64 or not out_m.flags['C_CONTIGUOUS']:
+        raise ValueError('the output arrays must be C-contiguous int64 / float64')
+    idx, ptr = _i64c(tree_csr_indices), _i64c(tree_csr_indptr)
+    es, part = _i64c(edge_to_primary_state), _i64c(primary_to_part_array)
+    Q = np.ascontiguousarray(Q_primary, dtype=np.float64)
+    nnodes = out_a.shape[0]
+    if out_a.shape != (nnodes, 2) or out_m.shape != (nnodes, 3, 3) or \
+            Q.shape != (part.shape[0], part.shape[0]) or es.shape != (nnodes,):
+        raise ValueError('shape mismatch')
+    pi = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+    pf = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    _lib.check(_lib.lib().rt_tmjp_get_inhomogeneous_mjp(
+        nnodes, pi(idx), pi(ptr), pi(es), part.shape[0], pi(part), pf(Q), float(rate_on),
+        float(rate_off), int(tolerance_class), pi(out_a), pf(out_m)))
+
+
+def get_lb_transition_matrix(t, Q, P):
+    """call site: examples/p53/liwen.py:45 (twin getp_lb, :47-82): P <- the lower bound of
+    expm(Q t) that keeps the histories with at most one change."""
+    import ctypes
+    from . import _lib
+    Q = np.ascontiguousarray(Q, dtype=np.float64)
+    if Q.ndim != 2 or Q.shape[0] != Q.shape[1]:
+        raise ValueError('expected the array to be square')
+    tt = np.array([t], dtype=np.float64)
+    out = np.empty((1,) + Q.shape)
+    pf = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    _lib.check(_lib.lib().rt_lb_transition_matrix(get_context()._h, Q.shape[0], 1, pf(Q), pf(tt),
+                                                  pf(out)))
+    P[...] = out[0]
 
 
 def mcy_esd_get_node_to_pset(tree_csr_indices, tree_csr_indptr,

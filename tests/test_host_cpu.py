@@ -574,3 +574,60 @@ def test_root_halves_source_covers_every_step_once(monkeypatch):
         assert ('ob_0' in combine) == (ta.node_to_index[root] in obs)
         assert 'loglik[site]' in combine and 'loglik[site]' not in main
     assert seen_cut >= 4
+
+
+def test_pyfelscore_compat_exports_every_name_the_reference_calls():
+    """Container only (the reference tree is not on the GPU box): every ``pyfelscore.<name>``
+    the reference's sampler modules and its p53 example call is exported by the shim."""
+    import ast
+    import glob
+    ref = '/root/reference'
+    if not os.path.isdir(ref):
+        pytest.skip('the reference tree is only present in the build container')
+    called = set()
+    for pattern in ('raoteh/sampler/*.py', 'examples/p53/*.py'):
+        for path in glob.glob(os.path.join(ref, pattern)):
+            with open(path, errors='replace') as f:
+                called.update(re.findall(r'pyfelscore\.(\w+)', f.read()))
+    assert {'mcy_get_node_to_pset', 'get_node_to_set', 'tmjp_get_inhomogeneous_mjp',
+            'get_lb_transition_matrix', 'mcy_esd_get_node_to_pmap'} <= called
+    tree = ast.parse(open(os.path.join(ROOT, 'raoteh_amd', 'pyfelscore_compat.py')).read())
+    exported, defined = set(), set()
+    for node in tree.body:
+        if isinstance(node, ast.Assign) and getattr(node.targets[0], 'id', '') == '__all__':
+            exported = set(ast.literal_eval(node.value))
+        if isinstance(node, ast.FunctionDef):
+            defined.add(node.name)
+    assert called <= exported, sorted(called - exported)
+    assert exported <= defined, sorted(exported - defined)
+
+
+def test_tmjp_get_inhomogeneous_mjp_matches_the_reference_twin():
+    """pyfelscore.tmjp_get_inhomogeneous_mjp (_tmjp_dense.py:1039-1054): host-side entry
+    point of the library, against what the reference's sparse twin (_tmjp.py:803-903)
+    returns for the same trajectories (tests/golden/tmjp_inhomogeneous.json)."""
+    from raoteh_amd import pyfelscore_compat as pyf
+    fx = load_golden('tmjp_inhomogeneous')
+    assert len(fx['cases']) >= 10
+    for c in fx['cases']:
+        n = c['nprimary']
+        Q = np.array(c['Q_primary_offdiagonal'])
+        Q = Q - np.diag(Q.sum(axis=1))
+        nnodes = len(c['edge_to_primary_state'])
+        for cl in c['classes']:
+            allowed = np.ones((nnodes, 2), dtype=np.int64)
+            mats = np.full((nnodes, 3, 3), np.nan)
+            pyf.tmjp_get_inhomogeneous_mjp(
+                np.array(c['tree_csr_indices'], dtype=np.int64),
+                np.array(c['tree_csr_indptr'], dtype=np.int64),
+                np.array(c['edge_to_primary_state'], dtype=np.int64),
+                np.array(c['primary_to_part'], dtype=np.int64), Q, c['rate_on'], c['rate_off'],
+                cl['tolerance_class'], allowed, mats)
+            np.testing.assert_array_equal(allowed, np.array(cl['node_to_allowed_tolerances']))
+            np.testing.assert_allclose(mats, np.array(cl['tol_rate_matrices']), rtol=1e-14,
+                                       atol=0)
+    with pytest.raises(ValueError):
+        pyf.tmjp_get_inhomogeneous_mjp(
+            np.array([1], dtype=np.int64), np.array([0, 1, 1], dtype=np.int64),
+            np.array([0, 7], dtype=np.int64), np.array([0, 0], dtype=np.int64), np.zeros((2, 2)),
+            1.0, 1.0, 0, np.ones((2, 2), dtype=np.int64), np.zeros((2, 3, 3)))

@@ -388,3 +388,29 @@ def test_switching_oracle_matches_reference():
         np.testing.assert_allclose(d0, want['original_root_distn'], rtol=1e-9, atol=1e-18)
         assert d0[:61].sum() == pytest.approx(want['p_reference'], rel=1e-11)
     assert seen_zero
+
+
+def test_lower_bound_transition_matrix_is_the_stated_integral():
+    # liwen.py:59-77 states what an off-diagonal entry is: the integral over the time x of the
+    # one change of exp(-ra x) rab exp(-rb (t - x)); the bound never exceeds expm(Q t)
+    from scipy.integrate import quad
+    rng = np.random.RandomState(3)
+    for n in (2, 5):
+        Q = rng.exponential(size=(n, n)) * (rng.uniform(size=(n, n)) < 0.7)
+        np.fill_diagonal(Q, 0.0)
+        Q[0, 1] = 0.5
+        Q -= np.diag(Q.sum(axis=1))
+        if n == 5:
+            Q[1, 1] = Q[0, 0]                        # the ra == rb branch (:69-70)
+        for t in (0.05, 0.7):
+            P = orc.getp_lb(Q, t)
+            for a in range(n):
+                for b in range(n):
+                    if a == b:
+                        want = np.exp(t * Q[a, a])
+                    else:
+                        want = quad(lambda x: np.exp(Q[a, a] * x) * Q[a, b] *
+                                    np.exp(Q[b, b] * (t - x)), 0.0, t, epsabs=0, epsrel=1e-13)[0]
+                    assert P[a, b] == pytest.approx(want, rel=1e-11, abs=1e-300)
+            if n == 2:
+                assert (P <= orc.custom_expm(Q, t) + 1e-15).all()

@@ -25,6 +25,8 @@ Reference functions exercised:
   _graph_transform.get_chunk_tree_type_b       raoteh/sampler/_graph_transform.py:298-375
   _mc0.get_node_to_distn                       raoteh/sampler/_mc0.py:382-462
   examples/p53/liwen.py:566-636,677-682        the 122-state switching model (fixture_switching)
+  _tmjp.get_inhomogeneous_mjp                  raoteh/sampler/_tmjp.py:803-903 (the sparse twin of
+                                               pyfelscore.tmjp_get_inhomogeneous_mjp)
 expm per edge is ``scipy.linalg.expm(Q*t)`` exactly as ``_mjp_dense.py:24-25``.
 
 usage: python tools/gen_golden.py [--out tests/golden]
@@ -964,6 +966,71 @@ def fixture_spectral(mods):
     return dict(cases=cases)
 
 
+def fixture_tmjp_inhomogeneous(mods, ncases=12):
+    """pyfelscore.tmjp_get_inhomogeneous_mjp (_tmjp_dense.py:1039-1054) through its sparse
+    twin _tmjp.get_inhomogeneous_mjp (_tmjp.py:803-903): random primary trajectories (trees
+    whose edges carry a primary state), random sparse primary rate matrices, every tolerance
+    class.  Recorded per case: the tree in the reference's preorder CSR, the primary state of
+    the edge above every node, and per class the 3 x 3 rate matrix of every edge (dense,
+    diagonal = minus the row sum, keyed by the child's preorder index) and the allowed
+    tolerance states of every node."""
+    _tmjp = importlib.import_module('raoteh.sampler._tmjp')
+    _density = mods['_density']
+    if not hasattr(nx, 'to_numpy_matrix'):      # networkx >= 3 (as in fixture_p53_mg94)
+        nx.to_numpy_matrix = lambda G, **kw: np.asmatrix(nx.to_numpy_array(G, **kw))
+    rng = np.random.RandomState(77)
+    cases = []
+    for case in range(ncases):
+        nprimary = int(rng.choice([2, 3, 5, 6]))
+        nparts = int(rng.randint(1, min(3, nprimary) + 1))
+        primary_to_part = dict((i, int(rng.randint(nparts))) for i in range(nprimary))
+        Qd = rng.exponential(size=(nprimary, nprimary)) * (rng.uniform(size=(nprimary, nprimary)) < 0.6)
+        np.fill_diagonal(Qd, 0.0)
+        Q_nx = nx.DiGraph()
+        Q_nx.add_nodes_from(range(nprimary))
+        for a in range(nprimary):
+            for b in range(nprimary):
+                if Qd[a, b]:
+                    Q_nx.add_edge(a, b, weight=float(Qd[a, b]))
+        nnodes = int(rng.randint(2, 15))
+        T = nx.Graph()
+        T.add_node(0)
+        for k in range(1, nnodes):
+            T.add_edge(int(rng.randint(k)), k, weight=float(0.1 + rng.exponential()),
+                       state=int(rng.randint(nprimary)))
+        root = 0
+        rate_on, rate_off = float(0.2 + rng.exponential()), float(0.2 + rng.exponential())
+        preorder = list(nx.dfs_preorder_nodes(T, root))
+        T_bfs = nx.DiGraph()
+        T_bfs.add_node(root)
+        for na, nb in nx.bfs_edges(T, root):
+            T_bfs.add_edge(na, nb)
+        idx, ptr = _density.digraph_to_bool_csr(T_bfs, preorder)
+        index = dict((v, i) for i, v in enumerate(preorder))
+        pred = dict((b, a) for a, b in nx.bfs_edges(T, root))
+        edge_state = [0] * nnodes
+        for b, a in pred.items():
+            edge_state[index[b]] = T[a][b]['state']
+        per_class = []
+        for tol in range(nparts):
+            T_tol, allowed = _tmjp.get_inhomogeneous_mjp(
+                primary_to_part, rate_on, rate_off, Q_nx, T, root, tol)
+            mats = np.zeros((nnodes, 3, 3))
+            for b, a in pred.items():
+                M = np.zeros((3, 3))            # (the graph may lack a state: no nodelist)
+                for sa, sb, d in T_tol[a][b]['Q'].edges(data=True):
+                    M[sa, sb] = d['weight']
+                mats[index[b]] = M - np.diag(M.sum(axis=1))
+            arr = [[1 if t in allowed[v] else 0 for t in (0, 1)] for v in preorder]
+            per_class.append(dict(tolerance_class=tol, tol_rate_matrices=mats.tolist(),
+                                  node_to_allowed_tolerances=arr))
+        cases.append(dict(nprimary=nprimary, primary_to_part=[primary_to_part[i] for i in range(nprimary)],
+                          Q_primary_offdiagonal=Qd.tolist(), rate_on=rate_on, rate_off=rate_off,
+                          tree_csr_indices=[int(x) for x in idx], tree_csr_indptr=[int(x) for x in ptr],
+                          edge_to_primary_state=[int(x) for x in edge_state], classes=per_class))
+    return dict(cases=cases)
+
+
 def fixture_switching(mods, nsites=5):
     """The 122-state "switching" model of examples/p53/liwen.py: MG94 codon process
     (create_mg94, parameters of get_jeff_params_e :273-300) x {reference, default},
@@ -1116,6 +1183,7 @@ def main():
         chunk_trees=lambda: fixture_chunk_trees(mods),
         spectral=lambda: fixture_spectral(mods),
         switching=lambda: fixture_switching(mods),
+        tmjp_inhomogeneous=lambda: fixture_tmjp_inhomogeneous(mods),
     )
     only = args.only.split(',') if args.only else list(makers)
     fixtures = dict((name, makers[name]()) for name in only)
