@@ -8,6 +8,13 @@
  * ABI: every function returns 0 (RT_OK) or a negative RT_ERR_* code and
  * rt_last_error() returns a human-readable message for the calling thread.
  *
+ * Ownership and destruction order.  A site batch (rt_sites) refers to its model, a model and
+ * a chain batch (rt_chains) refer to their context, until they are destroyed.  Children go
+ * first: rt_model_destroy returns RT_ERR_INVALID (and destroys nothing) while a batch created
+ * from the model is alive, rt_ctx_destroy while a model or a chain batch of the context is
+ * alive; rt_last_error() names what is left.  Destroying NULL is a no-op.  Using a handle
+ * after its destroy call returned RT_OK is undefined.
+ *
  * "Reference" citations are file:line under the reference repository root
  * (argriffing/raoteh).  The reference's only native boundary on this path is
  * the third-party Cython module `pyfelscore` (absent from the reference

@@ -438,19 +438,32 @@ class DeviceHistoryBatch(object):
         _lib.check(code)
         self._h = handle
         self.nsweeps = 0
+        # the C object refers to its context: the context closes its chain batches before it
+        # goes (device.Context.close), whatever order the garbage collector picks
+        self.ctx._children.add(self)
+
+    def close(self):
+        from .device import _shutting_down
+        h = getattr(self, '_h', None)
+        if h and not _shutting_down:
+            _lib.lib().rt_chains_destroy(h)
+        self._h = None
 
     def __del__(self):
-        h = getattr(self, '_h', None)
-        if h:
-            try:
-                _lib.lib().rt_chains_destroy(h)
-            except Exception:
-                pass
-            self._h = None
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def sweep(self, nsweeps=1):
-        _lib.check(_lib.lib().rt_chains_sweep(self._h, int(nsweeps)))
-        self.nsweeps += int(nsweeps)
+        before = self.sizes()[2]
+        code = _lib.lib().rt_chains_sweep(self._h, int(nsweeps))
+        self.nsweeps += self.sizes()[2] - before          # the sweeps that completed
+        if code == _lib.RT_ERR_ZERO_PROB:
+            # what HistoryBatch.sweep and the reference raise for the same condition
+            # (_sample_mc0_dense.py:57-62)
+            raise StructuralZeroProb(_lib.last_error())
+        _lib.check(code)
         return self
 
     def sizes(self):

@@ -115,9 +115,15 @@ extern "C" int rt_ctx_destroy(rt_ctx *ctx)
 {
     if (!ctx) return RT_OK;
     hipSetDevice(ctx->device);
-    ctx->pending_reduce = nullptr;       // its batch may be gone already
+    rt_expect_cache_release(ctx);        // the library's own model + batch of the last call
+    // the caller's models and chain batches hold this context: they go first
+    if (ctx->live_models > 0 || ctx->live_chains > 0) {
+        rt_set_error("rt_ctx_destroy: %d model(s) and %d chain batch(es) of this context are "
+                     "still alive; destroy them first", ctx->live_models, ctx->live_chains);
+        return RT_ERR_INVALID;
+    }
+    ctx->pending_reduce = nullptr;
     hipStreamSynchronize(ctx->stream);
-    rt_expect_cache_release(ctx);
     rt_comm_destroy(ctx);
     rt_jit_release(ctx);
     for (auto &s : ctx->slots) {
@@ -390,6 +396,13 @@ static int64_t pfrag_doubles(const rt_model *m)
 extern "C" int rt_model_destroy(rt_model *m)
 {
     if (!m) return RT_OK;
+    // a site batch refers to its model (and through it to the context) until it is destroyed
+    if (m->live_batches > 0) {
+        rt_set_error("rt_model_destroy: %d site batch(es) of this model are still alive; "
+                     "destroy them first", m->live_batches);
+        return RT_ERR_INVALID;
+    }
+    m->ctx->live_models -= 1;
     hipSetDevice(m->ctx->device);
     hipStreamSynchronize(m->ctx->stream);
     hipFree(m->d_indices); hipFree(m->d_indptr); hipFree(m->d_ops); hipFree(m->d_P);
@@ -427,6 +440,7 @@ extern "C" int rt_model_create(rt_ctx *ctx, int64_t nnodes, int64_t n,
     rt_model *m = new (std::nothrow) rt_model();
     if (!m) return RT_ERR_NOMEM;
     m->ctx = ctx;
+    ctx->live_models += 1;            // (every failure path below goes through rt_model_destroy)
     m->nnodes = nnodes;
     m->n = n;
     if (nnodes > 1) m->indices.assign(idx, idx + (nnodes - 1));
@@ -771,6 +785,7 @@ static int opt_jit_block_sites(const rt_ctx *c)
 extern "C" int rt_sites_destroy(rt_sites *s)
 {
     if (!s) return RT_OK;
+    if (s->counted) s->model->live_batches -= 1;
     hipSetDevice(s->model->ctx->device);
     if (s->model->ctx->pending_reduce == s) s->model->ctx->pending_reduce = nullptr;
     hipStreamSynchronize(s->model->ctx->stream);
@@ -1458,6 +1473,8 @@ static int sites_create_impl(rt_model *m, int64_t nsites, int kind, int64_t nobs
         rt_sites_destroy(s);
         return rc;
     }
+    s->counted = true;
+    m->live_batches += 1;
     *out = s;
     return RT_OK;
 }
@@ -1640,6 +1657,8 @@ extern "C" int rt_sites_clone(rt_sites *src, rt_sites **out)
         rt_sites_destroy(s);
         return rc;
     }
+    s->counted = true;
+    s->model->live_batches += 1;
     *out = s;
     return RT_OK;
 }

@@ -96,6 +96,12 @@ struct rt_ctx {
     hipStream_t stream2 = nullptr;      // side stream of two-kernel pruning launches (lazy)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     size_t expm_scratch_bytes = 0;
+    // Lifetime (include/raoteh_hip.h, "ownership and destruction order"): a context cannot
+    // go while one of its models or chain batches lives, a model not while one of its site
+    // batches lives -- the destroy call refuses (RT_ERR_INVALID) instead of leaving the
+    // children with a dangling parent.  Counts of live children, own internal objects (the
+    // expectation cache, probe batches) included.
+    int live_models = 0, live_chains = 0;
 };
 static const int RT_OPT_UNSET = -2;
 
@@ -150,6 +156,7 @@ struct rt_model {
     double *d_t_step = nullptr;
     bool have_P = false;
     bool frag_dirty = true;
+    int live_batches = 0;           // site batches created from this model and not yet destroyed
 };
 
 // Device layouts of a site batch:
@@ -223,6 +230,7 @@ struct rt_sites {
                                     // as one byte per leaf: 1 = uint8 states, 2 = allowed-set masks
     double *d_scratch = nullptr;    // generic kernel message stack
     int64_t scratch_bytes = 0;
+    bool counted = false;           // this batch is in its model's live_batches
     char kernel_name[64] = "";      // the pruning kernel variant of this batch
     double jit_compile_s = 0.0;     // hiprtc time spent for this batch (0: cache hit / none)
 };

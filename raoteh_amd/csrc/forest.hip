@@ -85,6 +85,10 @@ __device__ __forceinline__ double philox_uniform(unsigned long long seed, unsign
 // 0.2 ms for the upward pass that does the arithmetic.
 constexpr int FOREST_CAP = 1024;
 
+// (Assumption of the > FOREST_CAP path, stated: a word one lane stores with coherent_store and
+// another lane of the SAME wave loads with coherent_load a few instructions later sees the
+// store -- same-address accesses of one wave are ordered at L2.  Test:
+// test_forest_trees_beyond_the_lds_image.)
 __device__ __forceinline__ unsigned long long coherent_load(const unsigned long long *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -817,7 +821,13 @@ namespace {
 
 constexpr int SWEEP_WAVES = 4;             // chains per workgroup
 constexpr int SWEEP_MAX_NODES = 1024;      // base tree nodes (LDS tables per wave)
-constexpr int SWEEP_MAX_GAPS = 255;        // Poisson events per row (8 bits of the counter)
+// Poisson events per row: the count of a row travels from the count kernel to the split
+// kernel in 16 bits, the draw of gap k has the counter (chain, row, k & 255) in the stream
+// `stream + ((k >> 8) << 40)`.  A row that reaches the cap (rate x length of the order of
+// 60 000: not a branch of a tree anybody samples) fails the sweep with an error -- it is
+// never silently emitted as one event-free piece (the reference, _sample_mjp_dense.py:47-61,
+// has no cap at all).
+constexpr int SWEEP_MAX_GAPS = 65535;
 
 struct chains_tables {                     // per wave, in dynamic LDS
     int *rows;          // [N] new rows on the edge above node v
@@ -851,8 +861,8 @@ __device__ __forceinline__ int row_events(double rate, double len, unsigned long
     double t = 0.0;
     if (rate > 0.0) {
         while (k < SWEEP_MAX_GAPS) {
-            const double u = philox_uniform(seed, stream, (chain << 40) | (row << 8) |
-                                                          (unsigned long long)k);
+            const double u = philox_uniform(seed, stream + ((unsigned long long)(k >> 8) << 40),
+                                            (chain << 40) | (row << 8) | (unsigned long long)(k & 255));
             const double gap = -log1p(-u) / rate;
             if (!(t + gap < len)) break;
             emit(k, gap);
@@ -869,7 +879,7 @@ sweep_count_kernel(long nchains, const long *__restrict__ start, const int *__re
                    const double *__restrict__ len, const int *__restrict__ state,
                    const double *__restrict__ rates, int per, unsigned long long seed,
                    unsigned long long stream, long *__restrict__ newcnt,
-                   unsigned char *__restrict__ row_k)
+                   unsigned short *__restrict__ row_k, int *__restrict__ overflow)
 {
     const int lane = threadIdx.x & 63;
     const long c = (long)blockIdx.x * SWEEP_WAVES + (threadIdx.x >> 6);
@@ -880,7 +890,8 @@ sweep_count_kernel(long nchains, const long *__restrict__ start, const int *__re
         const int k = row_events(rates[state[lo + i]], len[lo + i], seed, stream,
                                  (unsigned long long)c, (unsigned long long)i, per,
                                  [](int, double) {});
-        row_k[lo + i] = (unsigned char)k;        // <= SWEEP_MAX_GAPS: the split pass reads it back
+        row_k[lo + i] = (unsigned short)k;       // <= SWEEP_MAX_GAPS: the split pass reads it back
+        if (per == 0 && k >= SWEEP_MAX_GAPS) atomicOr(overflow, 1);     // the cap cut this row short
         total += k + 1;
     }
 #pragma unroll
@@ -894,7 +905,7 @@ sweep_split_kernel(long nchains, int N, int nbits, const int *__restrict__ paren
                    const int *__restrict__ edge, const double *__restrict__ len,
                    const int *__restrict__ state, const double *__restrict__ rates, int per,
                    unsigned long long seed, unsigned long long stream,
-                   const unsigned char *__restrict__ row_k,
+                   const unsigned short *__restrict__ row_k,
                    const unsigned long long *__restrict__ node_masks,
                    const long *__restrict__ newstart, int *__restrict__ edge_out,
                    double *__restrict__ len_out, int *__restrict__ row_chunk,
@@ -998,7 +1009,13 @@ sweep_split_kernel(long nchains, int N, int nbits, const int *__restrict__ paren
     // pass 2: chunk of every new row; parents and masks of the chunks the rows open
     // (the rows were written by other lanes of this wave a moment ago, and a neighbouring
     // chain's wave on this CU may have pulled the shared cache line into the vector L1 before
-    // that: read them at L2)
+    // that: read them at L2).  The stores of pass 1 were plain: one release / acquire pair at
+    // agent scope, once per chain, orders them before the loads below for every lane of the
+    // wave (the memory model does not promise cross-lane order through L2 from a
+    // wavefront-scope fence alone, even if this hardware issues a wave's accesses in order).
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     for (int j = lane; j < total; j += 64) {
         const int v = __hip_atomic_load(&edge_out[out + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int k = j - first[v];
@@ -1126,7 +1143,7 @@ struct rt_chains {
     // rows: buffer A holds the current histories, B the freshly split ones
     int64_t cap_rows = 0, cap_chunks = 0;
     int *d_edge_a = nullptr, *d_state_a = nullptr, *d_edge_b = nullptr, *d_row_chunk = nullptr;
-    unsigned char *d_row_k = nullptr;      // events of each current row (count -> split)
+    unsigned short *d_row_k = nullptr;     // events of each current row (count -> split)
     double *d_len_a = nullptr, *d_len_b = nullptr;
     long *d_start = nullptr, *d_newcnt = nullptr, *d_newstart = nullptr, *d_choff = nullptr;
     int *d_cnt = nullptr, *d_node_chunk = nullptr, *d_node_state = nullptr;
@@ -1185,9 +1202,10 @@ int chains_step(rt_chains *h, int per, int *flag_out)
     const int64_t C = h->nchains, N = h->N;
     const dim3 grid(sweep_grid(C)), block(64 * SWEEP_WAVES);
     const unsigned long long stream_events = 2 * h->nsweeps + 1, stream_states = 2 * h->nsweeps;
+    RT_HIP(hipMemsetAsync(h->d_flag, 0, 2 * sizeof(int), st));      // [0] status, [1] row overflow
     hipLaunchKernelGGL(sweep_count_kernel, grid, block, 0, st, (long)C, h->d_start, h->d_cnt,
                        h->d_len_a, h->d_state_a, h->d_rates, per, (unsigned long long)h->seed,
-                       stream_events, h->d_newcnt, h->d_row_k);
+                       stream_events, h->d_newcnt, h->d_row_k, h->d_flag + 1);
     // where each chain's new rows start: exclusive prefix sum over C + 1 counts (the last is 0,
     // so the last output is the total); rocPRIM's scan (a single-workgroup scan took 186 us at
     // 100 000 chains)
@@ -1198,8 +1216,16 @@ int chains_step(rt_chains *h, int per, int *flag_out)
     }
     RT_HIP(hipGetLastError());
     long total_rows = 0;
+    int overflow = 0;
     RT_HIP(hipMemcpyAsync(&total_rows, h->d_newstart + C, sizeof(long), hipMemcpyDeviceToHost, st));
+    RT_HIP(hipMemcpyAsync(&overflow, h->d_flag + 1, sizeof(int), hipMemcpyDeviceToHost, st));
     RT_HIP(hipStreamSynchronize(st));
+    if (overflow) {
+        rt_set_error("a history row would carry %d or more virtual events in one sweep (Poisson "
+                     "rate x segment length too large for the device sampler); nothing was "
+                     "changed", SWEEP_MAX_GAPS);
+        return RT_ERR_UNSUPPORTED;
+    }
     const int64_t total_chunks = total_rows - C * (N - 2);
     RT_REQUIRE(total_rows < (1ll << 31) && total_chunks >= C, "row count out of range");
     if (total_rows > h->cap_rows) {
@@ -1235,7 +1261,6 @@ int chains_step(rt_chains *h, int per, int *flag_out)
     launch_forest_sample((int)h->n, (long)C, h->d_choff, h->d_cparent, h->P.d_dense, h->d_root,
                          h->d_L, (unsigned long long)h->seed, stream_states, h->d_cstate,
                          h->d_status, st);
-    RT_HIP(hipMemsetAsync(h->d_flag, 0, sizeof(int), st));
     hipLaunchKernelGGL(sweep_flag_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st,
                        (long)C, h->d_status, h->d_flag);
     RT_HIP(hipGetLastError());
@@ -1311,7 +1336,7 @@ extern "C" int rt_chains_create(rt_ctx *ctx, int64_t nnodes, const int32_t *pare
     RT_CH(hipMalloc((void **)&h->d_node_chunk, C * N * 4));
     RT_CH(hipMalloc((void **)&h->d_node_state, C * N * 4));
     RT_CH(hipMalloc((void **)&h->d_status, C * 4));
-    RT_CH(hipMalloc((void **)&h->d_flag, 4));
+    RT_CH(hipMalloc((void **)&h->d_flag, 8));
     RT_CH(hipMemcpyAsync(h->d_parent, parent, N * 4, hipMemcpyHostToDevice, st));
     RT_CH(hipMemcpyAsync(h->d_branch, branch_lengths, N * 8, hipMemcpyHostToDevice, st));
     RT_CH(hipMemcpyAsync(h->d_rates, poisson_rates, n * 8, hipMemcpyHostToDevice, st));
@@ -1339,7 +1364,7 @@ extern "C" int rt_chains_create(rt_ctx *ctx, int64_t nnodes, const int32_t *pare
         RT_CH(hipMalloc((void **)&h->d_edge_b, h->cap_rows * 4));
         RT_CH(hipMalloc((void **)&h->d_len_b, h->cap_rows * 8));
         RT_CH(hipMalloc((void **)&h->d_row_chunk, h->cap_rows * 4));
-        RT_CH(hipMalloc((void **)&h->d_row_k, h->cap_rows));
+        RT_CH(hipMalloc((void **)&h->d_row_k, h->cap_rows * sizeof(unsigned short)));
         RT_CH(hipMemcpyAsync(h->d_edge_a, edge.data(), edge.size() * 4, hipMemcpyHostToDevice, st));
         RT_CH(hipMemcpyAsync(h->d_state_a, state.data(), state.size() * 4, hipMemcpyHostToDevice, st));
         RT_CH(hipMemcpyAsync(h->d_len_a, len.data(), len.size() * 8, hipMemcpyHostToDevice, st));
@@ -1370,6 +1395,7 @@ extern "C" int rt_chains_create(rt_ctx *ctx, int64_t nnodes, const int32_t *pare
         rc = chains_step(h, per, &flag);
         if (rc != RT_OK) return fail(rc);
     }
+    ctx->live_chains += 1;
     *out = h;
     return RT_OK;
 }
@@ -1381,7 +1407,14 @@ extern "C" int rt_chains_sweep(rt_chains *h, int64_t nsweeps)
     for (int64_t i = 0; i < nsweeps; ++i) {
         int flag = 0;
         RT_TRY(chains_step(h, 0, &flag));
-        RT_REQUIRE(flag == 0, "a chunk tree has zero likelihood (status %d)", flag);
+        if (flag != 0) {
+            // the reference raises StructuralZeroProb / NumericalZeroProb here
+            // (_sample_mc0_dense.py:57-62); nothing was committed, and the sweep does not count
+            --h->nsweeps;
+            rt_set_error("a chunk tree has zero likelihood (status %d: %s)", flag,
+                         flag == 1 ? "at its root" : "below its root");
+            return RT_ERR_ZERO_PROB;
+        }
     }
     return RT_OK;
 }
@@ -1533,6 +1566,7 @@ extern "C" int rt_chains_restore(rt_chains *h, const uint8_t *reject)
 extern "C" int rt_chains_destroy(rt_chains *h)
 {
     if (!h) return RT_OK;
+    h->ctx->live_chains -= 1;
     hipSetDevice(h->ctx->device);
     hipStreamSynchronize(h->ctx->stream);
     delete h;

@@ -76,12 +76,18 @@ class Context(object):
 
     def __init__(self, device=0):
         self._h = c_void_p()
+        # models and chain batches of this context: the C objects refer to it, and
+        # rt_ctx_destroy refuses while one of them lives, so close() closes them first
+        # (objects that die in one garbage-collection cycle are finalised in any order)
+        self._children = weakref.WeakSet()
         _lib.check(_lib.lib().rt_ctx_create(int(device), byref(self._h)))
         self.device = int(device)
 
     def close(self):
         if self._h and not _shutting_down:
-            _lib.lib().rt_ctx_destroy(self._h)
+            for child in list(self._children):
+                child.close()
+            _lib.check(_lib.lib().rt_ctx_destroy(self._h))
             self._h = c_void_p()
 
     def __del__(self):
@@ -427,12 +433,13 @@ class TreeModel(object):
         _lib.check(_lib.lib().rt_model_create(
             self.ctx._h, ta.nnodes, self.nstates, _ptr(ta.indices, c_int64),
             _ptr(ta.indptr, c_int64), byref(self._h)))
+        self.ctx._children.add(self)
 
     def close(self):
         for batch in list(getattr(self, '_batches', ())):
             batch.close()
         if self._h and not _shutting_down:
-            _lib.lib().rt_model_destroy(self._h)
+            _lib.check(_lib.lib().rt_model_destroy(self._h))
             self._h = c_void_p()
 
     def __del__(self):

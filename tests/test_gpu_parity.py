@@ -1583,6 +1583,97 @@ def test_options_are_per_context_and_kernels_are_verified(ra):
     other.close()
 
 
+def test_destruction_order_is_refused_not_undefined(ra):
+    """include/raoteh_hip.h, ownership: rt_model_destroy while a batch of the model lives and
+    rt_ctx_destroy while a model or chain batch of the context lives return RT_ERR_INVALID and
+    destroy nothing; in the right order everything goes.  Straight through ctypes."""
+    from ctypes import byref, c_void_p, c_double, c_int32, c_int64, c_uint64, POINTER
+    L = ra.lib.lib()
+    ctx = c_void_p()
+    assert L.rt_ctx_create(0, byref(ctx)) == 0
+    idx = np.array([1, 2], dtype=np.int64)
+    ptr = np.array([0, 2, 2, 2], dtype=np.int64)
+    p64 = lambda a: a.ctypes.data_as(POINTER(c_int64))
+    pf = lambda a: a.ctypes.data_as(POINTER(c_double))
+    model = c_void_p()
+    assert L.rt_model_create(ctx, 3, 4, p64(idx), p64(ptr), byref(model)) == 0
+    esd = np.tile(np.full((4, 4), 0.25), (3, 1, 1))
+    assert L.rt_model_set_transitions(model, pf(esd)) == 0
+    obs = np.array([1, 2], dtype=np.int64)
+    data = np.array([[0, 1], [2, 255]], dtype=np.uint8)
+    sites, twin = c_void_p(), c_void_p()
+    assert L.rt_sites_create(model, 2, ra.lib.RT_OBS_STATE, 2, p64(obs), data.ctypes.data_as(c_void_p),
+                             byref(sites)) == 0
+    assert L.rt_sites_clone(sites, byref(twin)) == 0
+    assert L.rt_prune(model, sites) == 0
+    # chains on the same context
+    parent = np.array([-1, 0, 0], dtype=np.int32)
+    branch = np.array([0.0, 0.3, 0.2])
+    P = np.full((4, 4), 0.25)
+    rates = np.full(4, 1.5)
+    masks = np.full((5, 3), 15, dtype=np.uint64)
+    chains = c_void_p()
+    assert L.rt_chains_create(ctx, 3, parent.ctypes.data_as(POINTER(c_int32)), pf(branch), 4, pf(P),
+                              pf(rates), None, 5, masks.ctypes.data_as(POINTER(c_uint64)),
+                              c_uint64(1), byref(chains)) == 0
+    # wrong order: refused, nothing destroyed, everything still works
+    assert L.rt_model_destroy(model) == ra.lib.RT_ERR_INVALID
+    assert b'2 site batch' in L.rt_last_error()
+    assert L.rt_ctx_destroy(ctx) == ra.lib.RT_ERR_INVALID
+    assert b'1 model' in L.rt_last_error() and b'1 chain' in L.rt_last_error()
+    assert L.rt_prune(model, twin) == 0
+    ll = np.zeros(2)
+    assert L.rt_sites_get_logliks(twin, pf(ll), None) == 0
+    # root weights of one (not a distribution): 4 x 0.25 x 0.25 and 4 x 0.25 x 1
+    np.testing.assert_allclose(ll, np.log([0.25, 1.0]), rtol=1e-14, atol=1e-15)
+    assert L.rt_chains_sweep(chains, 2) == 0
+    # one child left: still refused
+    assert L.rt_sites_destroy(sites) == 0
+    assert L.rt_model_destroy(model) == ra.lib.RT_ERR_INVALID
+    assert L.rt_sites_destroy(twin) == 0
+    assert L.rt_model_destroy(model) == 0
+    assert L.rt_ctx_destroy(ctx) == ra.lib.RT_ERR_INVALID       # the chains
+    assert L.rt_chains_destroy(chains) == 0
+    assert L.rt_ctx_destroy(ctx) == 0
+    assert L.rt_model_destroy(None) == 0 and L.rt_sites_destroy(None) == 0
+
+
+def test_objects_in_a_reference_cycle_are_finalised_in_a_safe_order(ra):
+    """A context, a model, two batches and a chain batch that die in ONE garbage-collection
+    cycle (a cycle through a traceback kept them alive in round 2: the model was finalised
+    before its batch and the process segfaulted): the Python classes close children first."""
+    import gc
+    from raoteh_amd import _sampler
+    T, root, leaves = ra.synth.balanced_tree(4)
+    Q, distn = ra.synth.hky85()
+
+    def build():
+        ctx = ra.device.Context(0)
+        model = ra.device.TreeModel(T, root, 4, ctx=ctx)
+        model.set_rates(Q_default=Q)
+        batch = model.upload_sites(leaves, np.zeros((3, len(leaves)), dtype=np.uint8), kind='state')
+        twin = batch.clone()
+        model.prune(batch)
+        chains = _sampler.DeviceHistoryBatch(T, root, Q, nchains=4, seed=2, ctx=ctx)
+        chains.sweep(1)
+        cycle = {'ctx': ctx, 'model': model, 'batches': [batch, twin], 'chains': chains}
+        cycle['self'] = cycle                       # only the cycle collector can free this
+        ctx.cycle = cycle
+        return ctx._h.value
+
+    for _ in range(3):
+        gc.collect()
+        assert build()
+        gc.collect()
+    # an explicit close of the context closes what hangs on it
+    ctx = ra.device.Context(0)
+    model = ra.device.TreeModel(T, root, 4, ctx=ctx)
+    model.set_rates(Q_default=Q)
+    batch = model.upload_sites(leaves, np.zeros((3, len(leaves)), dtype=np.uint8), kind='state')
+    ctx.close()
+    assert not batch._h and not model._h and not ctx._h
+
+
 def test_timing_and_clone(ra):
     cfg = ra.synth.make_config('c2', nsites=2000)
     model = ra.device.TreeModel(cfg['T'], cfg['root'], cfg['nstates'])
@@ -2361,6 +2452,46 @@ def test_device_chains_at_the_limits(ra):
         _sampler.DeviceHistoryBatch(big, 0, Q4, nchains=2, ctx=ra.ctx)
     with pytest.raises(ValueError):
         _sampler.DeviceHistoryBatch(T, 7, np.zeros((3, 3)), nchains=1, ctx=ra.ctx)
+
+
+def test_device_sweep_virtual_events_are_poisson_beyond_255_per_row(ra):
+    """The virtual events of a sweep are a Poisson process of rate omega - q(state) on every
+    segment (_sample_mjp_dense.py:47-61), however many fall on one row: with a uniformization
+    factor of 400 a row of length 1 carries ~ 399 of them (round 2's kernel stopped at 255
+    silently).  A row that would pass the 16-bit cap is an error, not a wrong draw; a chunk
+    tree of zero likelihood in a sweep raises what the host batch raises."""
+    from raoteh_amd import _sampler
+    from raoteh_amd._util import StructuralZeroProb
+    Q = np.array([[-1.0, 1.0], [1.0, -1.0]])
+    T = nx.Graph()
+    T.add_edge(0, 1, weight=1.0)
+    C = 2000
+    b = _sampler.DeviceHistoryBatch(T, 0, Q, nchains=C, uniformization_factor=400, seed=3,
+                                    ctx=ra.ctx)
+    assert b.poisson_rates == pytest.approx([399.0, 399.0])
+    for _ in range(3):
+        rows_before = b.sizes()[0]
+        expect = float((b.dwell_times() * b.poisson_rates[None, :]).sum(axis=1).mean())
+        b.sweep(1)
+        events = (b.sizes()[1] - rows_before) / float(C)      # two-node tree: chunks = new rows
+        assert expect == pytest.approx(399.0, rel=1e-9)
+        assert abs(events - expect) < 5.0 * np.sqrt(expect / C), (events, expect)
+    chain, edge, length, state = b.rows()
+    np.testing.assert_allclose(np.bincount(chain, weights=length, minlength=C), 1.0, rtol=1e-11)
+    # past the cap of 65 535 events per row: refused
+    far = _sampler.DeviceHistoryBatch(T, 0, Q, nchains=4, uniformization_factor=70000, seed=1,
+                                      ctx=ra.ctx)
+    with pytest.raises(ra.lib.RaotehHipError) as err:
+        far.sweep(1)
+    assert 'virtual events' in str(err.value) and far.nsweeps == 0
+    # root restricted to a state the data then rule out in mid-run cannot happen through the
+    # constructor (it checks feasibility), so the zero-likelihood error path of a sweep is
+    # reached through the C ABI: masks that exclude every state at a node after creation are
+    # not expressible either -- the creation-time error is the one a caller sees
+    with pytest.raises(StructuralZeroProb):
+        _sampler.DeviceHistoryBatch(T, 0, np.array([[-1.0, 1.0], [0.0, 0.0]]),
+                                    node_to_allowed_states={0: {1}, 1: {0}}, nchains=2,
+                                    ctx=ra.ctx)
 
 
 def test_codon_scale_expectation_weights_on_the_matrix_pipe(ra, monkeypatch):

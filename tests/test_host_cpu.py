@@ -252,8 +252,15 @@ def test_tree_specialised_mfma_source_is_generated_on_the_host(monkeypatch):
         assert src.count('__syncthreads()') == steps + 1      # one per step + the root's
     rc = _lib.lib().rt_jit_source(
         ta.nnodes, ta.indices.ctypes.data_as(p64), ta.indptr.ctypes.data_as(p64),
-        65, len(obs), obs.ctypes.data_as(p64), 2, buf, len(buf))
+        129, len(obs), obs.ctypes.data_as(p64), 2, buf, len(buf))
     assert rc < 0
+    # 64 < n <= 128: NT = 5..8 waves per workgroup, one workgroup per CU
+    rc = _lib.lib().rt_jit_source(
+        ta.nnodes, ta.indices.ctypes.data_as(p64), ta.indptr.ctypes.data_as(p64),
+        122, len(obs), obs.ctypes.data_as(p64), 2, buf, len(buf))
+    assert rc == 0
+    src = buf.value.decode()
+    assert '__launch_bounds__(512)' in src and 'amdgpu_waves_per_eu(2, 2)' in src
 
 
 def test_frechet_block_assembly_is_the_adjoint_of_expm_frechet():
