@@ -68,6 +68,35 @@ def test_expm_matches_scipy_fixture(ra):
             assert tuple(info[k]) == (m, s)
 
 
+def test_pade_expm_kernels_match_scipy_fixture(ra, monkeypatch):
+    """RAOTEH_EXPM=pade: the [m/m] Pade scaling-and-squaring kernels (what north_star names;
+    the default is the Taylor / Paterson-Stockmeyer scheme) against the same
+    stored scipy matrices, plus a codon-model likelihood through rt_model_set_rates."""
+    monkeypatch.setenv('RAOTEH_EXPM', 'pade')
+    fx = load_golden('expm')
+    by_n = {}
+    for row in fx['rows']:
+        by_n.setdefault(len(row['Q']), []).append(row)
+    for n, rows in by_n.items():
+        if n > 64:
+            continue                      # the Pade kernel keeps its matrices in LDS: n <= 64
+        Q = np.array([r['Q'] for r in rows])
+        t = np.array([r['t'] for r in rows])
+        P, info = ra.ctx.expm(Q, t, return_info=True)
+        for k, r in enumerate(rows):
+            want = np.array(r['P'])
+            np.testing.assert_allclose(P[k], want, rtol=1e-10,
+                                       atol=1e-14 * max(1.0, np.abs(want).max()),
+                                       err_msg='pade %s t=%g' % (r['form'], r['t']))
+            m, s = orc.pade_order_and_squarings(np.abs(np.array(r['Q']) * r['t']).sum(axis=0).max())
+            assert tuple(info[k]) == (m, s)
+    fx = load_golden('config_c3')
+    T, root, n, Q_default, distn, sites = config_from_golden(fx)
+    for site, want in zip(sites, fx['log_likelihoods']):
+        lk = ra.mjp.get_likelihood(T, site, root, n, root_distn=distn, Q_default=Q_default)
+        assert np.log(lk) == pytest.approx(want, rel=RTOL_LL)
+
+
 def test_spectral_reconstruction_matches_the_reference_qtop(ra):
     """csrc/spectral.hip through rt_expm_spectral and rt_model_set_rates_spectral against
     examples/p53/qtop.py's own getp_spectral_v2 outputs (tests/golden/spectral.json), and
