@@ -304,6 +304,12 @@ int rt_build_schedule(int64_t nnodes, const int64_t *tree_csr_indices,
  * 64); automatic = batches of at least 65 536 / n sites.  Results are
  * bit-identical with and without it.  "jit_block_sites" (0 automatic, 1..64):
  * sites per wave of those kernels (automatic balances the waves over the CUs). */
+/* "jit_async" (1 default / 0): for n > 4, rt_sites_create does not wait for hiprtc -- a host
+ * thread of this process compiles the kernel (or loads its code object from the persistent
+ * cache directory: RAOTEH_JIT_CACHE_DIR, default ~/.cache/raoteh_amd/jit; RAOTEH_JIT_CACHE=0
+ * disables it) while the batch runs the interpreter kernel; a later rt_prune / rt_step swaps
+ * the kernel in once it is there and has passed the probe verification.  rt_sites_jit_wait
+ * blocks until that has happened (or failed: the batch then stays on the interpreter).   */
 int rt_set_option(const char *key, int64_t value);
 /* The same options for ONE context (they take precedence over the process-wide
  * defaults above; value -2 = back to the default): two contexts on two threads can
@@ -323,6 +329,9 @@ int rt_sites_create(rt_model *model, int64_t nsites, int kind, int64_t nobs,
  * the benchmark to rotate batches so the 256 MiB Infinity Cache cannot hold
  * the working set).                                                         */
 int rt_sites_clone(rt_sites *sites, rt_sites **clone);
+/* Wait for the background compile of this batch's tree-specialised kernel, if one is
+ * pending, and switch the batch to it (see "jit_async").                              */
+int rt_sites_jit_wait(rt_sites *sites);
 int rt_sites_destroy(rt_sites *sites);
 int64_t rt_sites_device_bytes(const rt_sites *sites);
 /* Seconds rt_sites_create spent in hiprtc for this batch's tree-specialised kernel

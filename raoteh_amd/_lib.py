@@ -121,6 +121,7 @@ SIGNATURES = {
     'rt_sites_create': (c_int, [c_void_p, c_int64, c_int, c_int64, _p_i64,
                                 c_void_p, POINTER(c_void_p)]),
     'rt_sites_clone': (c_int, [c_void_p, POINTER(c_void_p)]),
+    'rt_sites_jit_wait': (c_int, [c_void_p]),
     'rt_sites_destroy': (c_int, [c_void_p]),
     'rt_sites_device_bytes': (c_int64, [c_void_p]),
     'rt_prune': (c_int, [c_void_p, c_void_p]),

@@ -125,6 +125,7 @@ extern "C" int rt_ctx_destroy(rt_ctx *ctx)
     ctx->pending_reduce = nullptr;
     hipStreamSynchronize(ctx->stream);
     rt_comm_destroy(ctx);
+    rt_jit_join_all(ctx);                // no compile thread of this context outlives it
     rt_jit_release(ctx);
     for (auto &s : ctx->slots) {
         drain_slot(s, true);
@@ -734,6 +735,9 @@ static std::atomic<int> g_force_generic{0};
 static std::atomic<int> g_jit{-1};
 static const int64_t RT_JIT_MIN_WORK = 65536;
 static std::atomic<int> g_jit_block_sites{0};    // 0 = automatic (see sites_jit)
+// 1: rt_sites_create does not wait for hiprtc (MFMA family): the batch runs the interpreter
+// kernel until the background job is done; 0: compile inside rt_sites_create
+static std::atomic<int> g_jit_async{1};
 
 static int parse_option(const char *key, int64_t value, int *which, int *out)
 {
@@ -746,6 +750,7 @@ static int parse_option(const char *key, int64_t value, int *which, int *out)
         *out = (int)value;
         return RT_OK;
     }
+    if (strcmp(key, "jit_async") == 0) { *which = 3; *out = value != 0; return RT_OK; }
     rt_set_error("unknown option %s", key);
     return RT_ERR_INVALID;
 }
@@ -754,7 +759,8 @@ extern "C" int rt_set_option(const char *key, int64_t value)
 {
     int which = 0, v = 0;
     RT_TRY(parse_option(key, value, &which, &v));
-    (which == 0 ? g_force_generic : which == 1 ? g_jit : g_jit_block_sites).store(v);
+    (which == 0 ? g_force_generic : which == 1 ? g_jit : which == 2 ? g_jit_block_sites
+                                                                     : g_jit_async).store(v);
     return RT_OK;
 }
 
@@ -768,7 +774,8 @@ extern "C" int rt_ctx_set_option(rt_ctx *ctx, const char *key, int64_t value)
     } else {
         RT_TRY(parse_option(key, value, &which, &v));
     }
-    (which == 0 ? ctx->opt_force_generic : which == 1 ? ctx->opt_jit : ctx->opt_jit_block_sites) = v;
+    (which == 0 ? ctx->opt_force_generic : which == 1 ? ctx->opt_jit
+     : which == 2 ? ctx->opt_jit_block_sites : ctx->opt_jit_async) = v;
     return RT_OK;
 }
 
@@ -777,6 +784,11 @@ static int opt_force_generic(const rt_ctx *c)
     return c->opt_force_generic != RT_OPT_UNSET ? c->opt_force_generic : g_force_generic.load();
 }
 static int opt_jit(const rt_ctx *c) { return c->opt_jit != RT_OPT_UNSET ? c->opt_jit : g_jit.load(); }
+static int opt_jit_async(const rt_ctx *c)
+{
+    if (const char *v = getenv("RAOTEH_JIT_ASYNC")) return atoi(v) != 0;
+    return c->opt_jit_async != RT_OPT_UNSET ? c->opt_jit_async : g_jit_async.load();
+}
 static int opt_jit_block_sites(const rt_ctx *c)
 {
     return c->opt_jit_block_sites != RT_OPT_UNSET ? c->opt_jit_block_sites : g_jit_block_sites.load();
@@ -1071,6 +1083,30 @@ struct jit_override {
     bool no_solo = false;     // n <= 32: the split-M interpreter kernel, not the one-wave one
 };
 
+// Background compile for an MFMA-family batch: candidates the cache already knows as
+// rejected are skipped; if the first one left is usable the caller's synchronous path takes
+// it from the cache (fast), else a job compiles the remaining ones in order (-> true).
+template <class MakeSource>
+static bool sites_jit_start_async(rt_sites *s, const std::vector<rt_sites::jit_cand> &cands,
+                                  MakeSource make)
+{
+    std::vector<rt_sites::jit_cand> todo;
+    std::vector<std::string> srcs;
+    for (const auto &c : cands) {
+        std::string src = make(c);
+        const int known = rt_jit_cached(s->model->ctx, src);
+        if (known < 0 && todo.empty()) continue;      // spilled or failed verification earlier
+        if (known > 0 && todo.empty()) return false;  // in the cache: no job needed
+        todo.push_back(c);
+        srcs.push_back(std::move(src));
+    }
+    if (todo.empty()) return false;
+    s->jit_cands = todo;
+    s->jit_srcs = srcs;
+    s->jit_job = rt_jit_start(s->model->ctx, std::move(srcs), true);
+    return true;
+}
+
 static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov)
 {
     if (ov && ov->mode == 1) return RT_OK;
@@ -1144,7 +1180,23 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
             s->jit_prefetch = D;
             s->jit_lookahead = LA;
             int rc = RT_ERR_UNSUPPORTED;
-            // fewer tiles if it spills: halves at T, halves at one tile, then the whole tree
+            // fewer tiles if it spills: halves at T, halves at one tile, then the whole tree.
+            // Unless the kernel is already in this context's cache, a background job works
+            // through that list while the batch runs the interpreter kernel.
+            if (!forced && opt_jit_async(s->model->ctx)) {
+                std::vector<rt_sites::jit_cand> cands;
+                for (int t = T, h = halves;;) {
+                    cands.push_back({t, h != 0, false});
+                    if (h && t > 1) t = 1;
+                    else if (h) h = 0;
+                    else if (t > 1) --t;
+                    else break;
+                }
+                if (sites_jit_start_async(s, cands, [&](const rt_sites::jit_cand &c) {
+                        return split_source(s->ops, (int)s->model->n, (int)s->nobs, c.T, D, LA, c.halves);
+                    }))
+                    return RT_OK;
+            }
             while (rc == RT_ERR_UNSUPPORTED) {
                 const std::string src =
                     split_source(s->ops, (int)s->model->n, (int)s->nobs, T, D, LA, halves);
@@ -1231,6 +1283,14 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
                     return RT_OK;
                 }
             }
+        }
+        if (!forced && opt_jit_async(s->model->ctx)) {
+            std::vector<rt_sites::jit_cand> cands;
+            for (int t = T; t >= 1; --t) cands.push_back({t, false, quad});
+            if (sites_jit_start_async(s, cands, [&](const rt_sites::jit_cand &c) {
+                    return rt_jit_mfma_source(s->ops, (int)s->model->n, (int)s->nobs, c.T, D, LA, c.quad);
+                }))
+                return RT_OK;
         }
         for (; T >= 1 && rc == RT_ERR_UNSUPPORTED; --T) {         // fewer tiles if it spills
             const std::string src =
@@ -1378,6 +1438,7 @@ static int sites_create_impl(rt_model *m, int64_t nsites, int kind, int64_t nobs
     s->model = m;
     s->nsites = nsites;
     s->nobs = nobs;
+    s->jit_kind = kind;
     s->node_obs.assign((size_t)m->nnodes, -1);
     for (int64_t j = 0; j < nobs; ++j) {
         const int64_t v = obs_nodes[j];
@@ -1608,6 +1669,70 @@ static int verify_jit_kernel(rt_sites *s, int kind)
     return rc;
 }
 
+// The background job of this batch is done (or `wait`: join it): take the kernel it left in
+// the context's cache, verify it on a probe batch if nobody has yet, and from the next launch
+// on the batch runs it.  Any failure leaves the batch on the interpreter kernel.
+int rt_sites_jit_poll(rt_sites *s, bool wait)
+{
+    if (!s->jit_job) return RT_OK;
+    if (!rt_jit_job_done(s->jit_job.get(), wait)) return RT_OK;
+    std::shared_ptr<rt_jit_job> job;
+    job.swap(s->jit_job);
+    int rc = RT_OK, chosen = -1;
+    double seconds = 0.0;
+    std::string err;
+    rt_jit_job_result(job.get(), &rc, &chosen, &seconds, &err);
+    s->jit_compile_s = seconds;
+    std::vector<rt_sites::jit_cand> cands;
+    std::vector<std::string> srcs;
+    cands.swap(s->jit_cands);
+    srcs.swap(s->jit_srcs);
+    if (rc != RT_OK || chosen < 0 || chosen >= (int)cands.size()) {
+        rt_set_error("background compile: %s", err.c_str());
+        return RT_OK;
+    }
+    rt_model *m = s->model;
+    RT_HIP(hipSetDevice(m->ctx->device));
+    void *fn = nullptr;
+    if (rt_jit_get(m->ctx, srcs[(size_t)chosen], &fn, true, nullptr) != RT_OK) return RT_OK;
+    const rt_sites::jit_cand c = cands[(size_t)chosen];
+    const bool split = m->n > 32 || !s->mfma_solo;
+    s->jit_fn = fn;
+    s->jit_tiles = c.T;
+    s->jit_quad = !split && c.quad;
+    if (split) s->jit_waves = (int)((m->n + 15) / 16);
+    int src = RT_OK;
+    if (split && c.halves) src = sites_halves_setup(s);
+    if (src == RT_OK && s->jit_halves && !s->d_half &&
+        hipMalloc((void **)&s->d_half,
+                  (size_t)(s->nblocks + 8) * 2 * ((m->n + 15) / 16) * 4 * 64 * 8) != hipSuccess)
+        src = RT_ERR_NOMEM;
+    if (src == RT_OK && !rt_jit_verified(m->ctx, fn) && !getenv("RAOTEH_JIT_NO_VERIFY")) {
+        src = verify_jit_kernel(s, s->jit_kind);
+        rt_jit_set_verified(m->ctx, fn, src == RT_OK);
+    }
+    if (src != RT_OK) {
+        rt_jit_ref(m->ctx, fn, -1);
+        s->jit_fn = nullptr;
+        s->jit_tiles = 1;
+        s->jit_quad = false;
+        s->jit_halves = false;
+        s->jit_combine = nullptr;
+        return RT_OK;
+    }
+    // the interpreter kernel and the specialised one leave their per-wave partial sums in
+    // different places of d_partial: what the other one wrote must read as zero
+    if (m->ctx->pending_reduce == s) RT_TRY(rt_flush_reduce(m->ctx));
+    RT_HIP(hipMemsetAsync(s->d_partial, 0, (size_t)s->npartials * 16, m->ctx->stream));
+    return RT_OK;
+}
+
+extern "C" int rt_sites_jit_wait(rt_sites *s)
+{
+    RT_REQUIRE(s, "null pointer");
+    return rt_sites_jit_poll(s, true);
+}
+
 extern "C" int rt_sites_clone(rt_sites *src, rt_sites **out)
 {
     RT_REQUIRE(src && out, "null pointer");
@@ -1640,6 +1765,11 @@ extern "C" int rt_sites_clone(rt_sites *src, rt_sites **out)
     s->compact_states = src->compact_states;
     s->node_obs = src->node_obs;
     s->ops = src->ops;
+    s->jit_job = src->jit_job;              // a pending background compile serves both
+    s->jit_cands = src->jit_cands;
+    s->jit_srcs = src->jit_srcs;
+    s->jit_kind = src->jit_kind;
+    s->jit_compile_s = src->jit_compile_s;
     int rc = sites_alloc(s, src->d_scratch != nullptr);
     if (rc == RT_OK && s->obs_bytes > 0) {
         // on the library's stream: a device-to-device hipMemcpy returns before the copy
@@ -1694,6 +1824,7 @@ extern "C" int rt_prune(rt_model *m, rt_sites *s)
     RT_REQUIRE(s->model == m, "the site batch belongs to another model");
     RT_REQUIRE(m->have_P, "the model has no transition matrices yet");
     RT_HIP(hipSetDevice(m->ctx->device));
+    if (s->jit_job) RT_TRY(rt_sites_jit_poll(s, false));
     return rt_launch_prune(m, s);
 }
 
@@ -1710,6 +1841,7 @@ extern "C" int rt_step(rt_model *m, rt_sites *s, int recompute_transitions)
     RT_REQUIRE(recompute_transitions || m->have_P,
                "the model has no transition matrices yet");
     RT_HIP(hipSetDevice(m->ctx->device));
+    if (s->jit_job) RT_TRY(rt_sites_jit_poll(s, false));
     // n <= 4 and a tree-specialised kernel: the pruning launch computes the transitions from
     // the resident rates itself (and carries the previous step's batch sum): ONE launch
     const bool fuse = recompute_transitions && s->jit_fused && s->jit_fn && !m->spectral &&

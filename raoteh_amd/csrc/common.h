@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -41,6 +42,8 @@ void rt_set_error(const char *fmt, ...);
         int rc_ = (call);                                                     \
         if (rc_ != RT_OK) return rc_;                                         \
     } while (0)
+
+struct rt_jit_job;      // a background compile (jit.hip)
 
 // ---- handles ------------------------------------------------------------------
 
@@ -83,6 +86,7 @@ struct rt_ctx {
     int opt_force_generic = -2;
     int opt_jit = -2;
     int opt_jit_block_sites = -2;
+    int opt_jit_async = -2;
     // The batch whose per-wave partial sums still await their fixed-order reduction.
     // rt_step defers it: the reduction of step j rides as one extra workgroup of step
     // j + 1's expm launch (two launches per step instead of three: on config 2 the two
@@ -230,6 +234,13 @@ struct rt_sites {
                                     // as one byte per leaf: 1 = uint8 states, 2 = allowed-set masks
     double *d_scratch = nullptr;    // generic kernel message stack
     int64_t scratch_bytes = 0;
+    // background compile of the tree-specialised kernel (MFMA family): the batch runs the
+    // interpreter kernel until the job is done and rt_sites_jit_poll swaps the kernel in
+    std::shared_ptr<rt_jit_job> jit_job;
+    struct jit_cand { int T; bool halves; bool quad; };
+    std::vector<jit_cand> jit_cands;        // what each candidate source of the job was built with
+    std::vector<std::string> jit_srcs;
+    int jit_kind = 0;                       // observation kind of the batch (probe batches)
     bool counted = false;           // this batch is in its model's live_batches
     char kernel_name[64] = "";      // the pruning kernel variant of this batch
     double jit_compile_s = 0.0;     // hiprtc time spent for this batch (0: cache hit / none)
@@ -304,6 +315,17 @@ bool rt_split_at_root(const std::vector<rt_op> &ops, std::vector<rt_op> *A, std:
 int rt_jit_companion(const rt_ctx *ctx, void *fn, const char *name, void **out);
 int rt_jit_get(rt_ctx *ctx, const std::string &src, void **fn, bool mfma = false,
                double *compile_s = nullptr);
+// background compilation (jit.hip): a host thread of this process works through candidate
+// sources (the first that compiles without scratch wins) and leaves the kernel in the
+// per-context cache; rt_jit_job_done polls (or joins), rt_jit_join_all before the context goes
+std::shared_ptr<rt_jit_job> rt_jit_start(rt_ctx *ctx, std::vector<std::string> sources, bool mfma);
+bool rt_jit_job_done(rt_jit_job *job, bool wait);
+void rt_jit_job_result(rt_jit_job *job, int *rc, int *chosen, double *seconds, std::string *error);
+void rt_jit_join_all(const rt_ctx *ctx);
+// (ctx, src): 1 compiled and usable, -1 compiled and rejected, 0 unknown (no reference taken)
+int rt_jit_cached(const rt_ctx *ctx, const std::string &src);
+// api.hip: swap the finished background kernel of a batch in (wait: join the job first)
+int rt_sites_jit_poll(rt_sites *s, bool wait);
 void rt_jit_ref(const rt_ctx *ctx, void *fn, int delta);
 // every freshly compiled kernel is run once against the interpreter kernel on a probe
 // batch before a user batch may launch it (api.hip verify_jit_kernel): 0 = not yet,

@@ -27,11 +27,17 @@
 
 #include <hip/hiprtc.h>
 
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
 #include <chrono>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <sstream>
 #include <string>
+#include <thread>
 
 namespace {
 
@@ -1847,55 +1853,108 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
     return o.str();
 }
 
-// compile (or fetch from the per-device cache) and return the function
-int rt_jit_get(rt_ctx *ctx, const std::string &src, void **fn, bool mfma, double *compile_s)
+namespace {
+
+// ---- persistent code-object cache -----------------------------------------------------------
+// A tree-specialised kernel costs 0.4-3.5 s of hiprtc on a cold process (61 states, five
+// half-tiles per workgroup: 3.4 s).  The code object of every kernel that compiled is kept
+// in a user cache directory, keyed by a hash of everything that decides it -- the source
+// text, the compiler options, the hiprtc version and the target -- and a later process (or
+// another context of this one) loads it with hipModuleLoadData in a few milliseconds.
+//   RAOTEH_JIT_CACHE_DIR   the directory (default $XDG_CACHE_HOME/raoteh_amd/jit or
+//                          ~/.cache/raoteh_amd/jit; created on demand)
+//   RAOTEH_JIT_CACHE=0     neither read nor written
+// A cached object is data this library wrote for itself; it is still checked like a fresh
+// one (scratch attribute, probe verification against the interpreter kernel) before use.
+std::string jit_cache_dir()
 {
-    const auto t_begin = std::chrono::steady_clock::now();
-    std::lock_guard<std::mutex> lock(g_jit_mutex);
-    const auto key = std::make_pair((const rt_ctx *)ctx, src);
-    auto it = g_jit_cache.find(key);
-    if (it != g_jit_cache.end()) {
-        if (!it->second.fn || it->second.rejected) {
-            rt_set_error(it->second.rejected
-                             ? "tree-specialised kernel rejected earlier (differs from the "
-                               "interpreter kernel on the probe batch: miscompiled)"
-                             : "tree-specialised kernel rejected earlier (register spills)");
-            return RT_ERR_UNSUPPORTED;
+    const char *off = getenv("RAOTEH_JIT_CACHE");
+    if (off && atoi(off) == 0 && off[0] != '\0') return std::string();
+    if (const char *d = getenv("RAOTEH_JIT_CACHE_DIR")) return d;
+    if (const char *x = getenv("XDG_CACHE_HOME")) return std::string(x) + "/raoteh_amd/jit";
+    if (const char *h = getenv("HOME")) return std::string(h) + "/.cache/raoteh_amd/jit";
+    return std::string();
+}
+
+void make_dirs(const std::string &path)
+{
+    for (size_t i = 1; i <= path.size(); ++i)
+        if (i == path.size() || path[i] == '/') mkdir(path.substr(0, i).c_str(), 0700);
+}
+
+// 128 bits of FNV-1a over (source, options, hiprtc version, target)
+std::string jit_cache_key(const std::string &src, bool vgpr_form)
+{
+    int major = 0, minor = 0;
+    hiprtcVersion(&major, &minor);
+    char tail[96];
+    snprintf(tail, sizeof(tail), "|gfx950|-O3|c++17|vgpr-form=%d|hiprtc %d.%d|layout 1", (int)vgpr_form,
+             major, minor);
+    unsigned long long h1 = 0xcbf29ce484222325ull, h2 = 0x84222325cbf29ce4ull;
+    auto feed = [&](const char *p, size_t n) {
+        for (size_t i = 0; i < n; ++i) {
+            h1 = (h1 ^ (unsigned char)p[i]) * 0x100000001b3ull;
+            h2 = (h2 ^ (unsigned char)p[i]) * 0x100000001b3ull + 0x9E3779B97F4A7C15ull;
         }
-        it->second.refs += 1;
-        *fn = (void *)it->second.fn;
-        return RT_OK;
+    };
+    feed(src.data(), src.size());
+    feed(tail, strlen(tail));
+    char out[40];
+    snprintf(out, sizeof(out), "%016llx%016llx", h1, h2);
+    return out;
+}
+
+bool disk_cache_load(const std::string &key, std::vector<char> &code)
+{
+    const std::string dir = jit_cache_dir();
+    if (dir.empty()) return false;
+    FILE *f = fopen((dir + "/" + key + ".hsaco").c_str(), "rb");
+    if (!f) return false;
+    bool ok = false;
+    if (fseek(f, 0, SEEK_END) == 0) {
+        const long sz = ftell(f);
+        if (sz > 64 && sz < (256l << 20) && fseek(f, 0, SEEK_SET) == 0) {
+            code.resize((size_t)sz);
+            ok = fread(code.data(), 1, (size_t)sz, f) == (size_t)sz &&
+                 memcmp(code.data(), "\x7f" "ELF", 4) == 0;
+        }
     }
-    // A module stays loaded while a batch may still launch it (refs).  When the cache
-    // is full, the kernels no batch refers to any more are dropped (a program that
-    // keeps changing its tree, e.g. MCMC over topologies); if every one is in use the
-    // new batch runs the interpreter kernels.
-    if (g_jit_cache.size() >= 256) {
-        for (auto e = g_jit_cache.begin(); e != g_jit_cache.end();) {
-            if (e->second.refs == 0) {
-                if (e->second.module) hipModuleUnload(e->second.module);
-                e = g_jit_cache.erase(e);
-            } else {
-                ++e;
-            }
-        }
-        if (g_jit_cache.size() >= 256) {
-            rt_set_error("tree-specialised kernel cache is full (256 kernels in use)");
-            return RT_ERR_UNSUPPORTED;
-        }
-    }
+    fclose(f);
+    return ok;
+}
+
+void disk_cache_store(const std::string &key, const std::vector<char> &code)
+{
+    const std::string dir = jit_cache_dir();
+    if (dir.empty()) return;
+    make_dirs(dir);
+    char tmp[64];
+    snprintf(tmp, sizeof(tmp), "/.%s.%ld.tmp", key.substr(0, 16).c_str(), (long)getpid());
+    const std::string tpath = dir + tmp, fpath = dir + "/" + key + ".hsaco";
+    FILE *f = fopen(tpath.c_str(), "wb");
+    if (!f) return;
+    const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+    if (fclose(f) != 0 || !ok || rename(tpath.c_str(), fpath.c_str()) != 0) remove(tpath.c_str());
+}
+
+// source -> code object: the disk cache, else hiprtc (no lock held: a compile takes seconds)
+int jit_compile(const std::string &src, bool mfma, std::vector<char> &code, bool *from_disk)
+{
+    // MFMA family: results straight into VGPRs (the default picks AGPRs and reads
+    // every result back with two v_accvgpr_read_b32: 1 300 moves for 1 240 MFMAs)
+    const bool vgpr_form = mfma && !getenv("RAOTEH_JIT_NO_VGPR_FORM");
+    const std::string key = jit_cache_key(src, vgpr_form);
+    *from_disk = disk_cache_load(key, code);
+    if (*from_disk) return RT_OK;
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "rt_jit_prune.hip", 0, nullptr, nullptr) !=
         HIPRTC_SUCCESS) {
         rt_set_error("hiprtcCreateProgram failed");
         return RT_ERR_HIP;
     }
-    // MFMA family: results straight into VGPRs (the default picks AGPRs and reads
-    // every result back with two v_accvgpr_read_b32: 1 300 moves for 1 240 MFMAs)
     const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm",
                           "-amdgpu-mfma-vgpr-form=1"};
-    const hiprtcResult cr =
-        hiprtcCompileProgram(prog, (mfma && !getenv("RAOTEH_JIT_NO_VGPR_FORM")) ? 5 : 3, opts);
+    const hiprtcResult cr = hiprtcCompileProgram(prog, vgpr_form ? 5 : 3, opts);
     if (cr != HIPRTC_SUCCESS) {
         size_t ls = 0;
         hiprtcGetProgramLogSize(prog, &ls);
@@ -1907,10 +1966,65 @@ int rt_jit_get(rt_ctx *ctx, const std::string &src, void **fn, bool mfma, double
     }
     size_t cs = 0;
     hiprtcGetCodeSize(prog, &cs);
-    std::vector<char> code(cs);
+    code.resize(cs);
     hiprtcGetCode(prog, code.data());
     hiprtcDestroyProgram(&prog);
+    disk_cache_store(key, code);
+    return RT_OK;
+}
+
+// the cached entry of (ctx, src), under the lock: RT_OK + *fn, RT_ERR_UNSUPPORTED (rejected),
+// or 1 = not in the cache
+int jit_lookup_locked(const rt_ctx *ctx, const std::string &src, void **fn)
+{
+    auto it = g_jit_cache.find(std::make_pair(ctx, src));
+    if (it == g_jit_cache.end()) return 1;
+    if (!it->second.fn || it->second.rejected) {
+        rt_set_error(it->second.rejected
+                         ? "tree-specialised kernel rejected earlier (differs from the "
+                           "interpreter kernel on the probe batch: miscompiled)"
+                         : "tree-specialised kernel rejected earlier (register spills)");
+        return RT_ERR_UNSUPPORTED;
+    }
+    it->second.refs += 1;
+    *fn = (void *)it->second.fn;
+    return RT_OK;
+}
+
+}  // namespace
+
+// compile (or fetch from the per-context cache / the disk cache) and return the function
+int rt_jit_get(rt_ctx *ctx, const std::string &src, void **fn, bool mfma, double *compile_s)
+{
+    const auto t_begin = std::chrono::steady_clock::now();
+    {
+        std::lock_guard<std::mutex> lock(g_jit_mutex);
+        const int rc = jit_lookup_locked(ctx, src, fn);
+        if (rc != 1) return rc;
+        // A module stays loaded while a batch may still launch it (refs).  When the cache
+        // is full, the kernels no batch refers to any more are dropped (a program that
+        // keeps changing its tree, e.g. MCMC over topologies); if every one is in use the
+        // new batch runs the interpreter kernels.
+        if (g_jit_cache.size() >= 256) {
+            for (auto e = g_jit_cache.begin(); e != g_jit_cache.end();) {
+                if (e->second.refs == 0) {
+                    if (e->second.module) hipModuleUnload(e->second.module);
+                    e = g_jit_cache.erase(e);
+                } else {
+                    ++e;
+                }
+            }
+            if (g_jit_cache.size() >= 256) {
+                rt_set_error("tree-specialised kernel cache is full (256 kernels in use)");
+                return RT_ERR_UNSUPPORTED;
+            }
+        }
+    }
+    std::vector<char> code;
+    bool from_disk = false;
+    RT_TRY(jit_compile(src, mfma, code, &from_disk));
     jit_entry e;
+    RT_HIP(hipSetDevice(ctx->device));           // (a background compile thread starts without one)
     RT_HIP(hipModuleLoadData(&e.module, code.data()));
     RT_HIP(hipModuleGetFunction(&e.fn, e.module, "rt_jit_prune"));
     // A kernel that needs scratch memory (register spills) is never run: it would be
@@ -1925,8 +2039,19 @@ int rt_jit_get(rt_ctx *ctx, const std::string &src, void **fn, bool mfma, double
         e.module = nullptr;
         e.fn = nullptr;
     }
+    std::lock_guard<std::mutex> lock(g_jit_mutex);
+    {
+        // another thread (a background compile of the same source) may have got here first
+        void *other = nullptr;
+        const int rc = jit_lookup_locked(ctx, src, &other);
+        if (rc != 1) {
+            if (e.module) hipModuleUnload(e.module);
+            if (rc == RT_OK) *fn = other;
+            return rc;
+        }
+    }
     e.refs = e.fn ? 1 : 0;
-    g_jit_cache[key] = e;
+    g_jit_cache[std::make_pair((const rt_ctx *)ctx, src)] = e;
     if (!e.fn) {
         rt_set_error("tree-specialised kernel rejected: %d bytes of scratch per work-item", scratch);
         return RT_ERR_UNSUPPORTED;
@@ -1935,6 +2060,104 @@ int rt_jit_get(rt_ctx *ctx, const std::string &src, void **fn, bool mfma, double
     if (compile_s)
         *compile_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     return RT_OK;
+}
+
+// ---- background compilation -----------------------------------------------------------------
+// rt_sites_create does not wait for hiprtc: a job on a host thread of THIS process works
+// through the candidate sources of the batch (fewer tiles if one spills) -- compile or disk
+// cache, module load, scratch check, into the per-context cache -- while the batch runs the
+// interpreter kernel; the caller's thread swaps the kernel in at a later rt_prune / rt_step
+// (api.hip rt_sites_jit_poll: probe verification first).  Never a re-exec, never a fork.
+struct rt_jit_job {
+    rt_ctx *ctx = nullptr;
+    std::vector<std::string> sources;
+    bool mfma = false;
+    std::thread worker;
+    std::atomic<int> done{0};
+    int chosen = -1;              // index of the first candidate that compiled without scratch
+    int rc = RT_ERR_UNSUPPORTED;
+    double seconds = 0.0;
+    std::string error;
+};
+
+namespace {
+std::mutex g_jobs_mutex;
+std::vector<std::shared_ptr<rt_jit_job>> g_jobs;     // every job not yet joined
+}
+
+std::shared_ptr<rt_jit_job> rt_jit_start(rt_ctx *ctx, std::vector<std::string> sources, bool mfma)
+{
+    auto job = std::make_shared<rt_jit_job>();
+    job->ctx = ctx;
+    job->sources = std::move(sources);
+    job->mfma = mfma;
+    rt_jit_job *j = job.get();
+    job->worker = std::thread([j]() {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (size_t k = 0; k < j->sources.size(); ++k) {
+            void *fn = nullptr;
+            const int rc = rt_jit_get(j->ctx, j->sources[k], &fn, j->mfma, nullptr);
+            j->rc = rc;
+            if (rc == RT_OK) {
+                rt_jit_ref(j->ctx, fn, -1);       // the batches take their own references
+                j->chosen = (int)k;
+                break;
+            }
+            j->error = rt_last_error();
+            if (rc != RT_ERR_UNSUPPORTED) break;  // a compiler error, not a spill
+        }
+        j->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        j->done.store(1, std::memory_order_release);
+    });
+    std::lock_guard<std::mutex> lock(g_jobs_mutex);
+    g_jobs.push_back(job);
+    return job;
+}
+
+bool rt_jit_job_done(rt_jit_job *job, bool wait)
+{
+    if (!job) return true;
+    if (wait) {
+        std::lock_guard<std::mutex> lock(g_jobs_mutex);      // one joiner at a time
+        if (job->worker.joinable()) job->worker.join();
+    }
+    return job->done.load(std::memory_order_acquire) != 0;
+}
+
+void rt_jit_job_result(rt_jit_job *job, int *rc, int *chosen, double *seconds, std::string *error)
+{
+    *rc = job->rc;
+    *chosen = job->chosen;
+    *seconds = job->seconds;
+    *error = job->error;
+}
+
+// rt_ctx_destroy: no thread of this context may outlive it
+void rt_jit_join_all(const rt_ctx *ctx)
+{
+    std::vector<std::shared_ptr<rt_jit_job>> mine;
+    {
+        std::lock_guard<std::mutex> lock(g_jobs_mutex);
+        for (auto it = g_jobs.begin(); it != g_jobs.end();) {
+            if ((*it)->ctx == ctx || (*it)->done.load()) {
+                mine.push_back(*it);
+                it = g_jobs.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    }
+    for (auto &j : mine)
+        if (j->worker.joinable()) j->worker.join();
+}
+
+// 1: compiled and usable, -1: compiled and rejected (spills / failed verification), 0: unknown
+int rt_jit_cached(const rt_ctx *ctx, const std::string &src)
+{
+    std::lock_guard<std::mutex> lock(g_jit_mutex);
+    auto it = g_jit_cache.find(std::make_pair(ctx, src));
+    if (it == g_jit_cache.end()) return 0;
+    return it->second.fn && !it->second.rejected ? 1 : -1;
 }
 
 // a batch (or its clone) takes / gives back its reference to a kernel

@@ -101,7 +101,8 @@ class Context(object):
 
     def set_option(self, key, value):
         """Per-context option (rt_ctx_set_option): 'jit' (-1 automatic / 0 / 1),
-        'force_generic', 'jit_block_sites'; value None = back to the process default."""
+        'force_generic', 'jit_block_sites', 'jit_async'; value None = back to the process
+        default."""
         _lib.check(_lib.lib().rt_ctx_set_option(
             self._h, key.encode(), -2 if value is None else int(value)))
 
@@ -407,6 +408,13 @@ class SiteBatch(object):
     @property
     def kernel_name(self):
         return (_lib.lib().rt_sites_kernel_name(self._h) or b'').decode()
+
+    def wait_for_kernel(self):
+        """Block until the background compile of this batch's tree-specialised kernel (if
+        one is pending: rt_set_option 'jit_async') has finished and the batch has switched
+        to it; until then it runs the interpreter kernel, with the same results."""
+        _lib.check(_lib.lib().rt_sites_jit_wait(self._h))
+        return self
 
     def close(self):
         if self._h and not _shutting_down:

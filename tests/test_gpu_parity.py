@@ -38,6 +38,9 @@ def ra():
     ns.mjp, ns.mcy, ns.mcx, ns.mcz = _mjp_dense, _mcy_dense, _mcx_dense, _mcz
     ns.device, ns.lib, ns.synth, ns.pyf = device, _lib, synth, pyfelscore_compat
     ns.ctx = device.get_context()
+    # the suite checks which kernel a batch runs right after creating it: compile inside
+    # rt_sites_create (the background path has its own test below)
+    _lib.check(_lib.lib().rt_set_option(b'jit_async', 0))
     return ns
 
 
@@ -1701,6 +1704,83 @@ def test_objects_in_a_reference_cycle_are_finalised_in_a_safe_order(ra):
     batch = model.upload_sites(leaves, np.zeros((3, len(leaves)), dtype=np.uint8), kind='state')
     ctx.close()
     assert not batch._h and not model._h and not ctx._h
+
+
+def test_background_compile_and_persistent_code_object_cache(ra, tmp_path, monkeypatch):
+    """jit_async: rt_sites_create returns without waiting for hiprtc, the batch (and a clone
+    made meanwhile) runs the interpreter kernel and switches to the tree-specialised one when
+    the compile thread is done -- same log-likelihoods bit for bit; the code object lands in
+    the cache directory and a second context (standing in for a second process) loads it from
+    there instead of compiling."""
+    import time
+    monkeypatch.setenv('RAOTEH_JIT_CACHE_DIR', str(tmp_path / 'jit'))
+    rng = np.random.RandomState(77)
+    for n, nnodes in ((20, 37), (61, 29)):
+        nsites = 6000
+        T, root, obs_nodes, w = _random_case(ra, rng, n, nnodes, nsites)
+        pre, idx, ptr, esd = orc.get_esd_transitions(T, root, n)
+        dense = rng.uniform(0.05, 1.0, size=(nsites, len(obs_nodes), n))
+        ctx = ra.device.Context(0)
+        ctx.set_option('jit_async', 1)
+        model = ra.device.TreeModel(T, root, n, ctx=ctx)
+        model.set_transitions(esd)
+        model.set_root_distn(w)
+        t0 = time.perf_counter()
+        batch = model.upload_sites(obs_nodes, dense, kind='dense')
+        create_s = time.perf_counter() - t0
+        twin = batch.clone()
+        ll0, st0 = model.log_likelihoods(batch)
+        first = batch.kernel_name
+        tot0 = model.fetch_totals(batch)
+        batch.wait_for_kernel()
+        ll1, st1 = model.log_likelihoods(batch)
+        assert batch.kernel_name.startswith('prune_tree_jit'), batch.kernel_name
+        np.testing.assert_array_equal(ll0, ll1)
+        np.testing.assert_array_equal(st0, st1)
+        tot1 = model.fetch_totals(batch)
+        assert tot1[2] == nsites and tot1[0] == pytest.approx(tot0[0], rel=1e-13)
+        assert tot1[0] == pytest.approx(ll1.sum(), rel=1e-12)
+        cold = batch.jit_compile_seconds
+        assert cold > 0
+        # (on a box whose compiler cache is warm the job may finish before the first launch)
+        assert first.startswith(('prune_mfma', 'prune_tree_jit')), first
+        for _ in range(200):                      # the clone swaps on its own, without waiting
+            ll2, _ = model.log_likelihoods(twin)
+            if twin.kernel_name.startswith('prune_tree_jit'):
+                break
+        assert twin.kernel_name.startswith('prune_tree_jit')
+        np.testing.assert_array_equal(ll0, ll2)
+        files = sorted(p.name for p in (tmp_path / 'jit').glob('*.hsaco'))
+        assert files, 'no code object was written to the cache directory'
+        # a second context: nothing in its memory cache, the code object on disk
+        ctx2 = ra.device.Context(0)
+        ctx2.set_option('jit_async', 0)
+        model2 = ra.device.TreeModel(T, root, n, ctx=ctx2)
+        model2.set_transitions(esd)
+        model2.set_root_distn(w)
+        batch2 = model2.upload_sites(obs_nodes, dense, kind='dense')
+        ll3, _ = model2.log_likelihoods(batch2)
+        assert batch2.kernel_name == batch.kernel_name
+        np.testing.assert_array_equal(ll0, ll3)
+        warm = batch2.jit_compile_seconds
+        assert sorted(p.name for p in (tmp_path / 'jit').glob('*.hsaco')) == files
+        assert warm < 0.25, (warm, cold)
+        print('n=%d: rt_sites_create %.3f s, background compile %.3f s, from the disk cache %.4f s'
+              % (n, create_s, cold, warm))
+        ctx2.close()
+        ctx.close()
+    # RAOTEH_JIT_CACHE=0: nothing is read or written
+    monkeypatch.setenv('RAOTEH_JIT_CACHE', '0')
+    monkeypatch.setenv('RAOTEH_JIT_CACHE_DIR', str(tmp_path / 'off'))
+    ctx = ra.device.Context(0)
+    ctx.set_option('jit_async', 0)
+    model = ra.device.TreeModel(T, root, n, ctx=ctx)
+    model.set_transitions(esd)
+    batch = model.upload_sites(obs_nodes, dense, kind='dense')
+    model.log_likelihoods(batch)
+    assert batch.kernel_name.startswith('prune_tree_jit')
+    assert not (tmp_path / 'off').exists()
+    ctx.close()
 
 
 def test_timing_and_clone(ra):
