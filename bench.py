@@ -516,6 +516,43 @@ def measure_next_rows(ctx):
                 sites=nsites, seconds_per_call=best, sites_per_s=nsites / best,
                 what='dwell times, root posteriors and transition counts summed over the batch, '
                      'one host call (expm, passes, site sums, Frechet block exponentials)')
+        # the same statistics on a RESIDENT batch (rt_expect_step): nothing marshalled or
+        # uploaded per call; arithmetic of a call = upward pass + downward pass (products at
+        # the internal nodes) + per-edge site sums, each 2 n^2 flops per edge and site, + one
+        # order-2n block exponential per edge
+        from raoteh_amd import device
+        for name, nsites in (('c3', 10000), ('c5', 50000)):
+            cfg = synth.make_config(name, nsites=nsites)
+            T, root, n = cfg['T'], cfg['root'], cfg['nstates']
+            model = device.TreeModel(T, root, n, ctx=ctx)
+            model.set_rates(Q_default=cfg['Q_default'])
+            model.set_root_distn(cfg['root_distn'])
+            batch = model.upload_sites(cfg['leaves'], synth.leaf_likelihoods(cfg), kind='dense')
+            for _ in range(3):
+                model.expected_history_statistics(batch)
+            times = []
+            for _ in range(9):
+                t0 = time.perf_counter()
+                dwell, rootp, trans = model.expected_history_statistics(batch)
+                times.append(time.perf_counter() - t0)
+            best = float(np.median(times))
+            nedges = T.number_of_edges()
+            ninternal = sum(1 for v in T if T.degree(v) > 1 and v != root)
+            flops = nsites * 2.0 * n * n * (2 * nedges + ninternal)
+            peak, _ = f64_mfma_peak()
+            total_len = sum(d['weight'] for _, _, d in T.edges(data=True))
+            out['expected_history_statistics_resident_%s' % name] = dict(
+                sites=nsites, seconds_per_call=best, seconds_min=min(times), seconds_max=max(times),
+                sites_per_s=nsites / best,
+                roofline=dict(bound='mfma', achieved=flops / best / 1e12, peak=peak, unit='TFLOP/s',
+                              frac=flops / best / 1e12 / peak, algorithmic_flops_per_call=flops,
+                              note='whole call (expm, three passes, Frechet block exponentials, '
+                                   'result copy) against the f64 matrix peak'),
+                dwell_sum_over_tree_length_times_sites=float(dwell.sum() / (total_len * nsites)),
+                what='rt_expect_step: per-edge expm + upward pass + downward pass + site sums + '
+                     'Frechet block exponentials on a resident batch; 2 n + n^2 numbers come back')
+            batch.close()
+            model.close()
         cfg = synth.make_config('c2', nsites=100000)
         T, root, n = cfg['T'], cfg['root'], cfg['nstates']
         index = _sampler.TreeArrays(T, root).node_to_index

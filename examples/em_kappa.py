@@ -5,6 +5,9 @@ history statistics -- the use the reference's get_expected_history_statistics
 (raoteh/sampler/_mjp_dense.py:410-539) is made for, over a whole alignment per
 iteration instead of one site per call:
 
+  (The codon-scale version of this loop on a RESIDENT batch -- rt_expect_step, nothing
+  uploaded per iteration -- is examples/em_codon.py.)
+
   E step  expected dwell time D_i per state and expected number N_ij of i -> j
           changes, summed over the sites (one device call: passes, downward pass,
           per-edge site sums, one Frechet block exponential per edge);

@@ -348,6 +348,22 @@ int rt_prune(rt_model *model, rt_sites *sites);
  * one call: rt_model_recompute_transitions (if recompute_transitions != 0) +
  * rt_prune.                                                                   */
 int rt_step(rt_model *model, rt_sites *sites, int recompute_transitions);
+/* _mjp_dense.get_expected_history_statistics (_mjp_dense.py:410-539) summed over a RESIDENT
+ * batch: (optionally) the per-edge expm from the resident rates, the upward pass, the downward
+ * pass (mc0_esd_get_node_to_distn), the per-edge site sums of J / P and one Frechet block
+ * exponential per edge, all on the device; 2 n + n^2 numbers come back:
+ *   dwell[c]       expected time spent in state c, summed over edges and sites
+ *   root_posterior[c]  sum over sites of the posterior probability of state c at the root
+ *   trans[c][d]    expected number of c -> d transitions (0 where no rate matrix has c -> d)
+ * each site weighted by rt_sites_set_weights (multiplicities of site patterns; default 1).
+ * status (optional, int32[nsites]): 2 where a normalising denominator is zero (the reference
+ * raises NumericalZeroProb).  8 < n <= RT_MAX_EXPECT_STATES, batches created by
+ * rt_sites_create for such n (any observation kind), rates set by rt_model_set_rates.
+ * Synchronous.                                                                          */
+int rt_expect_step(rt_model *model, rt_sites *sites, int recompute_transitions,
+            double *dwell, double *root_posterior, double *trans, int32_t *status);
+/* weights f64[nsites] (copied to the device) or NULL = every site counts once           */
+int rt_sites_set_weights(rt_sites *sites, const double *weights);
 /* loglik f64[nsites] (-inf where status has RT_SITE_ZERO_PROB),
  * status int32[nsites]; either may be NULL.                                 */
 int rt_sites_get_logliks(rt_sites *sites, double *loglik, int32_t *status);

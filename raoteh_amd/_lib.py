@@ -122,6 +122,8 @@ SIGNATURES = {
                                 c_void_p, POINTER(c_void_p)]),
     'rt_sites_clone': (c_int, [c_void_p, POINTER(c_void_p)]),
     'rt_sites_jit_wait': (c_int, [c_void_p]),
+    'rt_expect_step': (c_int, [c_void_p, c_void_p, c_int, _p_f64, _p_f64, _p_f64, _p_i32]),
+    'rt_sites_set_weights': (c_int, [c_void_p, _p_f64]),
     'rt_sites_destroy': (c_int, [c_void_p]),
     'rt_sites_device_bytes': (c_int64, [c_void_p]),
     'rt_prune': (c_int, [c_void_p, c_void_p]),

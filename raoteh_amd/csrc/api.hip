@@ -405,6 +405,7 @@ extern "C" int rt_model_destroy(rt_model *m)
     }
     m->ctx->live_models -= 1;
     hipSetDevice(m->ctx->device);
+    rt_expect_state_release(m);
     hipStreamSynchronize(m->ctx->stream);
     hipFree(m->d_indices); hipFree(m->d_indptr); hipFree(m->d_ops); hipFree(m->d_P);
     hipFree(m->d_Pfrag); hipFree(m->d_Pquad); hipFree(m->d_root); hipFree(m->d_Q); hipFree(m->d_spec); hipFree(m->d_qidx);
@@ -804,7 +805,10 @@ extern "C" int rt_sites_destroy(rt_sites *s)
     // an all-reduce of this batch's totals may still be in flight on the comm stream
     rt_jit_ref(s->model->ctx, s->jit_fn, -1);
     if (s->jit_fn2) rt_jit_ref(s->model->ctx, s->jit_fn2, -1);
-    hipFree(s->d_ops); hipFree(s->d_lane_ops); hipFree(s->d_lane_ops_a); hipFree(s->d_lane_ops_b); hipFree(s->d_obs); hipFree(s->d_loglik); hipFree(s->d_status);
+    if (s->expect_twin) rt_sites_destroy(s->expect_twin);
+    hipFree(s->d_weights);
+    if (!s->obs_borrowed) hipFree(s->d_obs);
+    hipFree(s->d_ops); hipFree(s->d_lane_ops); hipFree(s->d_lane_ops_a); hipFree(s->d_lane_ops_b); hipFree(s->d_loglik); hipFree(s->d_status);
     if (s->model->ctx->comm_stream) hipStreamSynchronize(s->model->ctx->comm_stream);
     hipFree(s->d_partial); hipFree(s->d_partial_alt); hipFree(s->d_scratch); hipFree(s->d_half);
     if (s->totals_slot >= 0) {
@@ -937,7 +941,8 @@ static int sites_alloc(rt_sites *s, bool generic)
                                     : (s->nblocks + tiles - 1) / tiles * waves;
     }
     hipError_t e = hipMalloc((void **)&s->d_ops, s->ops.size() * sizeof(rt_op));
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_obs, std::max<int64_t>(s->obs_bytes, 1024));
+    if (e == hipSuccess && !s->obs_borrowed)
+        e = hipMalloc((void **)&s->d_obs, std::max<int64_t>(s->obs_bytes, 1024));
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_loglik, padded * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_status, padded * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_partial, s->npartials * 16);
@@ -991,7 +996,7 @@ static int sites_alloc(rt_sites *s, bool generic)
         // RAOTEH_INTERP_HALVES=0 / 1 overrides.
         std::vector<rt_op> opsA, opsB;
         bool ih = e == hipSuccess && s->layout == RT_LAYOUT_MFMA && !s->mfma_solo &&
-                  rt_split_at_root(s->ops, &opsA, &opsB);
+                  !s->obs_borrowed && rt_split_at_root(s->ops, &opsA, &opsB);
         if (ih) {
             if (const char *v = getenv("RAOTEH_INTERP_HALVES")) ih = atoi(v) != 0;
             else ih = want_root_halves(s, s->nblocks);
@@ -1790,6 +1795,53 @@ extern "C" int rt_sites_clone(rt_sites *src, rt_sites **out)
     s->counted = true;
     s->model->live_batches += 1;
     *out = s;
+    return RT_OK;
+}
+
+// The batch rt_expect_step runs its passes on: the split-M interpreter kernel's program and
+// outputs over the resident observations of `src` (MFMA layout: the same [tile][slot][k-pair]
+// image whichever pruning kernel the batch itself runs).  Owned by `src`.
+int rt_sites_twin_interpreter(rt_sites *src, rt_sites **out)
+{
+    *out = nullptr;
+    RT_REQUIRE(src->layout == RT_LAYOUT_MFMA && !src->d_scratch,
+               "the batch is not resident in the matrix-pipe layout");
+    rt_sites *s = new (std::nothrow) rt_sites();
+    if (!s) return RT_ERR_NOMEM;
+    s->model = src->model;
+    s->nsites = src->nsites;
+    s->nobs = src->nobs;
+    s->layout = RT_LAYOUT_MFMA;
+    s->mfma_solo = false;
+    s->node_obs = src->node_obs;
+    s->ops = src->ops;
+    s->jit_kind = src->jit_kind;
+    s->obs_borrowed = true;
+    s->d_obs = src->d_obs;
+    const int rc = sites_alloc(s, false);
+    if (rc != RT_OK) {
+        rt_sites_destroy(s);
+        return rc;
+    }
+    // (the expectation launch stores L and M of the whole tree: no root halves)
+    s->interp_halves = false;
+    *out = s;
+    return RT_OK;
+}
+
+// per-site multiplicities of a resident batch (site patterns): f64[nsites], NULL = ones
+extern "C" int rt_sites_set_weights(rt_sites *s, const double *weights)
+{
+    RT_REQUIRE(s, "null pointer");
+    RT_HIP(hipSetDevice(s->model->ctx->device));
+    RT_HIP(hipStreamSynchronize(s->model->ctx->stream));
+    if (!weights) {
+        hipFree(s->d_weights);
+        s->d_weights = nullptr;
+        return RT_OK;
+    }
+    if (!s->d_weights) RT_HIP(hipMalloc((void **)&s->d_weights, (size_t)s->nsites * 8));
+    RT_HIP(hipMemcpy(s->d_weights, weights, (size_t)s->nsites * 8, hipMemcpyHostToDevice));
     return RT_OK;
 }
 

@@ -161,6 +161,7 @@ struct rt_model {
     bool have_P = false;
     bool frag_dirty = true;
     int live_batches = 0;           // site batches created from this model and not yet destroyed
+    void *expect_state = nullptr;   // expect_mfma.hip: device buffers of rt_expect_step (lazy)
 };
 
 // Device layouts of a site batch:
@@ -241,6 +242,12 @@ struct rt_sites {
     std::vector<jit_cand> jit_cands;        // what each candidate source of the job was built with
     std::vector<std::string> jit_srcs;
     int jit_kind = 0;                       // observation kind of the batch (probe batches)
+    // rt_expect_step: per-site multiplicities on the device (null: ones), and the batch's
+    // split-M interpreter twin -- its own program, partial sums and per-site outputs over the
+    // SAME resident observations (obs_borrowed: d_obs belongs to the batch it was made from)
+    double *d_weights = nullptr;
+    rt_sites *expect_twin = nullptr;
+    bool obs_borrowed = false;
     bool counted = false;           // this batch is in its model's live_batches
     char kernel_name[64] = "";      // the pruning kernel variant of this batch
     double jit_compile_s = 0.0;     // hiprtc time spent for this batch (0: cache hit / none)
@@ -340,6 +347,15 @@ int rt_sites_create_interpreter(rt_model *m, int64_t nsites, int kind, int64_t n
                                 const int64_t *obs_nodes, const void *data, rt_sites **out);
 // drops what rt_expectation_weights_mfma keeps between calls (rt_ctx_destroy)
 void rt_expect_cache_release(rt_ctx *ctx);
+// expect.hip: assemble / exponentiate / contract the Frechet blocks on device-resident operands
+int rt_frechet_statistics_device(rt_ctx *ctx, int64_t n, int64_t nedges, const double *dQ,
+                                 const int32_t *dqidx, const double *dt, const double *dW,
+                                 double *dB, double *dE, double *dscale, const double *dones,
+                                 const int32_t *dident, double *ddwell, double *dtrans);
+// ... and what rt_expect_step keeps with a model (rt_model_destroy)
+void rt_expect_state_release(rt_model *m);
+// a split-M interpreter batch over the resident observations of `src` (api.hip)
+int rt_sites_twin_interpreter(rt_sites *src, rt_sites **out);
 // the context's grow-only device scratch (ctx->d_scratch) holds at least `bytes` afterwards
 int rt_scratch_reserve(rt_ctx *ctx, size_t bytes);
 // expectation path on the matrix pipe (expect_mfma.hip); RT_ERR_UNSUPPORTED = not this case

@@ -74,6 +74,26 @@ frechet_contract_kernel(int n, int nedges, const double *__restrict__ Q,
 
 }  // namespace
 
+// The three launches on device-resident operands, asynchronously on the context's stream:
+// Q [nq][n][n], qidx / t / W per edge, scratch B and E [nedges][2n][2n], scale [nedges],
+// ones f64[nedges] and ident int32[nedges] (0, 1, 2, ...); dwell [n] and trans [n][n] out.
+int rt_frechet_statistics_device(rt_ctx *ctx, int64_t n, int64_t nedges, const double *dQ,
+                                 const int32_t *dqidx, const double *dt, const double *dW,
+                                 double *dB, double *dE, double *dscale, const double *dones,
+                                 const int32_t *dident, double *ddwell, double *dtrans)
+{
+    hipStream_t st = ctx->stream;
+    const size_t nn = (size_t)n * n;
+    hipLaunchKernelGGL(frechet_assemble_kernel, dim3((unsigned)nedges), dim3(256), 0, st, (int)n, dQ,
+                       dqidx, dt, dW, dB, dscale);
+    RT_HIP(hipGetLastError());
+    RT_TRY(rt_launch_expm(ctx, 2 * n, nedges, dB, dident, dones, dE, nullptr, nullptr, 0, nullptr));
+    hipLaunchKernelGGL(frechet_contract_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st,
+                       (int)n, (int)nedges, dQ, dqidx, dt, dE, dscale, ddwell, dtrans);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
 extern "C" int rt_mjp_frechet_statistics(rt_ctx *ctx, int64_t n, int64_t nedges, const double *Q,
                                          int64_t nq, const int64_t *q_index, const double *t,
                                          const double *W, double *dwell, double *trans)

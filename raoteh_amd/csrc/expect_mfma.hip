@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <memory>
 #include <vector>
 
 namespace {
@@ -279,6 +280,54 @@ uint64_t fnv1a(const void *p, size_t bytes, uint64_t h = 1469598103934665603ull)
     return h;
 }
 
+// Everything of one pass that happens on the device, asynchronously on the context's stream:
+// upward pass of the split-M interpreter kernel with L and M of every step stored, downward
+// pass, per-edge site sums, W in the reference's [node][a][b] order (slot 0, column 0: the
+// weighted sum of the root posteriors).  `s`: a split-M interpreter batch (MFMA layout, one
+// row tile per wave, no tree-specialised kernel); d_w device weights or null.
+template <int NT, int KS>
+int expect_device_passes(rt_ctx *ctx, rt_model *model, rt_sites *s, const double *d_PT,
+                         const int *d_step_node, const int *d_parent_step,
+                         const unsigned char *d_internal, const double *esd_dev,
+                         const double *d_root_w, const double *d_w, double *d_W, int *d_status,
+                         double *d_rootpart, bool trace)
+{
+    hipStream_t st = ctx->stream;
+    RT_REQUIRE(s->layout == RT_LAYOUT_MFMA && !s->mfma_solo && !s->jit_fn,
+               "unexpected batch layout for the matrix-pipe expectation path");
+    const int64_t n = model->n, nsites = s->nsites;
+    const int nops = (int)s->ops.size();
+    const long nblocks = (long)s->nblocks;
+    const size_t arr = (size_t)nops * nblocks * NT * 256;
+    // the four per-step arrays and the chunk partials live in the context's grow-only scratch
+    // (2.6 GB at 10 000 sites of the codon model: a hipMalloc / hipFree pair per call costs more
+    // than the kernels)
+    const size_t npart = (size_t)nops * EX_CHUNKS * NT * NT * 256;
+    RT_TRY(rt_scratch_reserve(ctx, (4 * arr + npart) * 8));
+    double *d_L = (double *)ctx->d_scratch;
+    double *d_M = d_L + arr, *d_D = d_M + arr, *d_U = d_D + arr, *d_part = d_U + arr;
+    // M of the root step is never written by the upward pass (no product there)
+    s->d_Lout = d_L;
+    s->d_Mout = d_M;
+    const int rc = rt_launch_prune(model, s, false);
+    s->d_Lout = s->d_Mout = nullptr;
+    RT_TRY(rc);
+    if (trace) hipStreamSynchronize(st);
+    RT_HIP(hipMemsetAsync(d_status, 0, (size_t)nsites * 4, st));
+    hipLaunchKernelGGL((expect_down_kernel<NT, KS>), dim3((unsigned)nblocks), dim3(64 * NT), 0, st,
+                       d_PT, nops, d_parent_step, d_internal, d_L, d_M, d_D, d_U, d_root_w, (int)n,
+                       d_status, (long)nsites, nblocks);
+    hipLaunchKernelGGL((expect_wsum_kernel<NT>), dim3((unsigned)(nops - 1), EX_CHUNKS), dim3(64 * NT),
+                       0, st, nops, d_U, d_L, d_w, (long)nsites, nblocks, d_part);
+    hipLaunchKernelGGL(expect_finish_kernel, dim3((unsigned)(nops - 1)), dim3(256), 0, st, (int)n, NT,
+                       nops, d_step_node, esd_dev, d_part, d_W);
+    hipLaunchKernelGGL(expect_root_kernel, dim3(EX_ROOT_CHUNKS), dim3(64), 0, st, (int)n, NT, nops - 1,
+                       d_D, d_w, (long)nsites, nblocks, d_rootpart);
+    hipLaunchKernelGGL(expect_root_finish_kernel, dim3(1), dim3(256), 0, st, (int)n, d_rootpart, d_W);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
 template <int NT, int KS>
 int run_chunk(rt_ctx *ctx, rt_model *model, int64_t n, int64_t nsites, int64_t nobs,
               const int64_t *obs_nodes, int kind, const void *data, const double *esd_dev,
@@ -306,48 +355,16 @@ int run_chunk(rt_ctx *ctx, rt_model *model, int64_t n, int64_t nsites, int64_t n
     }
     if (trace) hipStreamSynchronize(st);
     const auto t1 = now();
-    RT_REQUIRE(s->layout == RT_LAYOUT_MFMA && !s->mfma_solo && !s->jit_fn,
-               "unexpected batch layout for the matrix-pipe expectation path");
-    const int nops = (int)s->ops.size();
-    const long nblocks = (long)s->nblocks;
-    const size_t arr = (size_t)nops * nblocks * NT * 256;
     dev_free mem;
-    double *d_L, *d_M, *d_D, *d_U, *d_part, *d_rootpart, *d_w = nullptr;
+    double *d_rootpart, *d_w = nullptr;
     RT_TRY(mem.alloc(d_rootpart, (size_t)EX_ROOT_CHUNKS * 64));
-    // the four per-step arrays and the chunk partials live in the context's grow-only scratch
-    // (2.6 GB at 10 000 sites of the codon model: a hipMalloc / hipFree pair per call costs more
-    // than the kernels)
-    const size_t npart = (size_t)nops * EX_CHUNKS * NT * NT * 256;
-    RT_TRY(rt_scratch_reserve(ctx, (4 * arr + npart) * 8));
-    d_L = (double *)ctx->d_scratch;
-    d_M = d_L + arr;
-    d_D = d_M + arr;
-    d_U = d_D + arr;
-    d_part = d_U + arr;
     if (site_weights) {
         RT_TRY(mem.alloc(d_w, (size_t)nsites));
         RT_HIP(hipMemcpyAsync(d_w, site_weights, (size_t)nsites * 8, hipMemcpyHostToDevice, st));
     }
-    // M of the root step is never written by the upward pass (no product there)
-    s->d_Lout = d_L;
-    s->d_Mout = d_M;
-    const int rc = rt_launch_prune(model, s, false);
-    s->d_Lout = s->d_Mout = nullptr;
-    RT_TRY(rc);
-    if (trace) hipStreamSynchronize(st);
+    RT_TRY((expect_device_passes<NT, KS>(ctx, model, s, d_PT, d_step_node, d_parent_step, d_internal,
+                                         esd_dev, d_root_w, d_w, d_W, d_status, d_rootpart, trace)));
     const auto t2 = now();
-    RT_HIP(hipMemsetAsync(d_status, 0, (size_t)nsites * 4, st));
-    hipLaunchKernelGGL((expect_down_kernel<NT, KS>), dim3((unsigned)nblocks), dim3(64 * NT), 0, st,
-                       d_PT, nops, d_parent_step, d_internal, d_L, d_M, d_D, d_U, d_root_w, (int)n,
-                       d_status, (long)nsites, nblocks);
-    hipLaunchKernelGGL((expect_wsum_kernel<NT>), dim3((unsigned)(nops - 1), EX_CHUNKS), dim3(64 * NT),
-                       0, st, nops, d_U, d_L, d_w, (long)nsites, nblocks, d_part);
-    hipLaunchKernelGGL(expect_finish_kernel, dim3((unsigned)(nops - 1)), dim3(256), 0, st, (int)n, NT,
-                       nops, d_step_node, esd_dev, d_part, d_W);
-    hipLaunchKernelGGL(expect_root_kernel, dim3(EX_ROOT_CHUNKS), dim3(64), 0, st, (int)n, NT, nops - 1,
-                       d_D, d_w, (long)nsites, nblocks, d_rootpart);
-    hipLaunchKernelGGL(expect_root_finish_kernel, dim3(1), dim3(256), 0, st, (int)n, d_rootpart, d_W);
-    RT_HIP(hipGetLastError());
     RT_HIP(hipStreamSynchronize(st));
     if (trace)
         fprintf(stderr, "[raoteh_amd] expectation pass of %lld sites: batch + packing %.2f ms, scratch "
@@ -493,6 +510,169 @@ int rt_expectation_weights_mfma(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t 
         fprintf(stderr, "[raoteh_amd] expectation call: %.2f ms in all\n",
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() -
                                                           call_start).count());
+    return RT_OK;
+}
+
+// ---- resident expectation step -----------------------------------------------------------------
+// _mjp_dense.get_expected_history_statistics (_mjp_dense.py:410-539) summed over a RESIDENT
+// batch, in one call that moves 2 n + n^2 numbers: nothing is marshalled or uploaded per call
+// (the reference-shaped entry points above re-upload tree, matrices and observations every
+// time: 6.4 ms per call for 2.8 ms of kernels at 10 000 codon sites).  Per model, lazily: the
+// schedule arrays of the downward pass, P^T fragments, W, the Frechet block buffers.
+namespace {
+
+struct expect_state_t {
+    int nops = 0;
+    double *d_PT = nullptr, *d_W = nullptr, *d_B = nullptr, *d_E = nullptr, *d_scale = nullptr;
+    double *d_ones = nullptr, *d_out = nullptr, *d_rootpart = nullptr;
+    int *d_step_node = nullptr, *d_parent_step = nullptr, *d_ident = nullptr, *d_status = nullptr;
+    int64_t status_cap = 0;
+    unsigned char *d_internal = nullptr;
+    ~expect_state_t()
+    {
+        hipFree(d_PT); hipFree(d_W); hipFree(d_B); hipFree(d_E); hipFree(d_scale); hipFree(d_ones);
+        hipFree(d_out); hipFree(d_rootpart); hipFree(d_step_node); hipFree(d_parent_step);
+        hipFree(d_ident); hipFree(d_status); hipFree(d_internal);
+    }
+};
+
+int expect_state_get(rt_model *m, expect_state_t **out)
+{
+    if (m->expect_state) {
+        *out = (expect_state_t *)m->expect_state;
+        return RT_OK;
+    }
+    const int64_t n = m->n, N = m->nnodes;
+    const int nops = (int)m->ops.size();
+    RT_REQUIRE(nops == N && m->ops[(size_t)nops - 1].dst < 0, "unexpected schedule");
+    std::vector<int> step_node((size_t)nops), parent_step((size_t)nops, 0), step_of((size_t)N, -1);
+    std::vector<unsigned char> internal((size_t)nops, 0);
+    for (int i = 0; i < nops; ++i) {
+        step_node[(size_t)i] = m->ops[(size_t)i].node;
+        step_of[(size_t)m->ops[(size_t)i].node] = i;
+        internal[(size_t)i] = m->ops[(size_t)i].pop >= 0;
+    }
+    for (int i = 0; i + 1 < nops; ++i)
+        parent_step[(size_t)i] = step_of[(size_t)m->parent[(size_t)step_node[(size_t)i]]];
+    std::unique_ptr<expect_state_t> st(new (std::nothrow) expect_state_t());
+    if (!st) return RT_ERR_NOMEM;
+    st->nops = nops;
+    const int NT = (int)((n + 15) / 16), KP = ((int)((n + 3) / 4) + 1) / 2;
+    const size_t nn = (size_t)n * n, ne = (size_t)(N - 1), mm = 4 * nn;
+    RT_HIP(hipMalloc((void **)&st->d_PT, (size_t)nops * NT * KP * 128 * 8));
+    RT_HIP(hipMalloc((void **)&st->d_W, (size_t)N * nn * 8));
+    RT_HIP(hipMalloc((void **)&st->d_B, ne * mm * 8));
+    RT_HIP(hipMalloc((void **)&st->d_E, ne * mm * 8));
+    RT_HIP(hipMalloc((void **)&st->d_scale, ne * 8));
+    RT_HIP(hipMalloc((void **)&st->d_ones, ne * 8));
+    RT_HIP(hipMalloc((void **)&st->d_out, (2 * (size_t)n + nn) * 8));
+    RT_HIP(hipMalloc((void **)&st->d_rootpart, (size_t)EX_ROOT_CHUNKS * 64 * 8));
+    RT_HIP(hipMalloc((void **)&st->d_step_node, (size_t)nops * 4));
+    RT_HIP(hipMalloc((void **)&st->d_parent_step, (size_t)nops * 4));
+    RT_HIP(hipMalloc((void **)&st->d_ident, ne * 4));
+    RT_HIP(hipMalloc((void **)&st->d_internal, (size_t)nops));
+    std::vector<double> ones(ne, 1.0);
+    std::vector<int> ident(ne);
+    for (size_t e = 0; e < ne; ++e) ident[e] = (int)e;
+    RT_HIP(hipMemcpy(st->d_ones, ones.data(), ne * 8, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(st->d_ident, ident.data(), ne * 4, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(st->d_step_node, step_node.data(), (size_t)nops * 4, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(st->d_parent_step, parent_step.data(), (size_t)nops * 4, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(st->d_internal, internal.data(), (size_t)nops, hipMemcpyHostToDevice));
+    m->expect_state = st.release();
+    *out = (expect_state_t *)m->expect_state;
+    return RT_OK;
+}
+
+}  // namespace
+
+void rt_expect_state_release(rt_model *m)
+{
+    if (!m || !m->expect_state) return;
+    delete (expect_state_t *)m->expect_state;
+    m->expect_state = nullptr;
+}
+
+extern "C" int rt_expect_step(rt_model *m, rt_sites *s, int recompute_transitions, double *dwell,
+                              double *root_posterior, double *trans, int32_t *status)
+{
+    RT_REQUIRE(m && s && dwell && root_posterior && trans, "null pointer");
+    RT_REQUIRE(s->model == m, "the site batch belongs to another model");
+    RT_REQUIRE(m->d_Q && !m->spectral,
+               "rt_model_set_rates has not been called (the statistics need the rate matrices)");
+    const int64_t n = m->n, N = m->nnodes;
+    if (n <= 8 || n > RT_MAX_EXPECT_STATES || N < 2 || s->layout != RT_LAYOUT_MFMA || s->d_scratch ||
+        m->max_depth > RT_FAST_MAX_DEPTH) {
+        rt_set_error("rt_expect_step: resident batches of 8 < n <= %d states in the matrix-pipe "
+                     "layout (n=%lld here)", RT_MAX_EXPECT_STATES, (long long)n);
+        return RT_ERR_UNSUPPORTED;
+    }
+    rt_ctx *ctx = m->ctx;
+    RT_HIP(hipSetDevice(ctx->device));
+    const int NT = (int)((n + 15) / 16), KS = (int)((n + 3) / 4), KP = (KS + 1) / 2;
+    // the four per-step arrays of the passes: nodes x tiles x 8 KB x NT each
+    const double scratch_gb = 4.0 * (double)N * (double)((s->nsites + 15) / 16) * NT * 2048.0 / 1e9;
+    if (scratch_gb > 96.0) {
+        rt_set_error("rt_expect_step: the passes of this batch need %.0f GB of scratch; split the "
+                     "batch", scratch_gb);
+        return RT_ERR_UNSUPPORTED;
+    }
+    expect_state_t *st = nullptr;
+    RT_TRY(expect_state_get(m, &st));
+    if (!s->expect_twin) RT_TRY(rt_sites_twin_interpreter(s, &s->expect_twin));
+    rt_sites *x = s->expect_twin;
+    if (st->status_cap < s->nsites) {
+        hipFree(st->d_status);
+        st->d_status = nullptr;
+        st->status_cap = 0;
+        RT_HIP(hipMalloc((void **)&st->d_status, (size_t)s->nsites * 4));
+        st->status_cap = s->nsites;
+    }
+    if (recompute_transitions) RT_TRY(rt_model_recompute_transitions(m));
+    RT_REQUIRE(m->have_P, "the model has no transition matrices yet");
+    hipStream_t stream = ctx->stream;
+    hipLaunchKernelGGL(pack_pt_kernel, dim3(512), dim3(256), 0, stream, (int)n, NT, KP, st->nops,
+                       st->d_step_node, m->d_P, st->d_PT);
+    RT_HIP(hipGetLastError());
+    int rc = RT_ERR_UNSUPPORTED;
+#define RT_EX(NTV, KSV)                                                                            \
+    rc = expect_device_passes<NTV, KSV>(ctx, m, x, st->d_PT, st->d_step_node, st->d_parent_step,   \
+                                        st->d_internal, m->d_P, m->d_root, s->d_weights, st->d_W,  \
+                                        st->d_status, st->d_rootpart, false)
+    switch (KS) {
+    case 3: RT_EX(1, 3); break;
+    case 4: RT_EX(1, 4); break;
+    case 5: RT_EX(2, 5); break;
+    case 6: RT_EX(2, 6); break;
+    case 7: RT_EX(2, 7); break;
+    case 8: RT_EX(2, 8); break;
+    case 9: RT_EX(3, 9); break;
+    case 10: RT_EX(3, 10); break;
+    case 11: RT_EX(3, 11); break;
+    case 12: RT_EX(3, 12); break;
+    case 13: RT_EX(4, 13); break;
+    case 14: RT_EX(4, 14); break;
+    case 15: RT_EX(4, 15); break;
+    default: RT_EX(4, 16); break;
+    }
+#undef RT_EX
+    RT_TRY(rc);
+    // slot 0, column 0 of W: the weighted sum of the root posteriors; edges 1 .. N - 1 follow
+    const size_t nn = (size_t)n * n;
+    double *d_dwell = st->d_out, *d_rootp = st->d_out + n, *d_trans = st->d_out + 2 * n;
+    RT_HIP(hipMemcpy2DAsync(d_rootp, 8, st->d_W, (size_t)n * 8, 8, (size_t)n, hipMemcpyDeviceToDevice,
+                            stream));
+    RT_TRY(rt_frechet_statistics_device(ctx, n, N - 1, m->d_Q, m->d_qidx + 1, m->d_t + 1, st->d_W + nn,
+                                        st->d_B, st->d_E, st->d_scale, st->d_ones, st->d_ident, d_dwell,
+                                        d_trans));
+    std::vector<double> out(2 * (size_t)n + nn);
+    RT_HIP(hipMemcpyAsync(out.data(), st->d_out, out.size() * 8, hipMemcpyDeviceToHost, stream));
+    if (status)
+        RT_HIP(hipMemcpyAsync(status, st->d_status, (size_t)s->nsites * 4, hipMemcpyDeviceToHost, stream));
+    RT_HIP(hipStreamSynchronize(stream));
+    memcpy(dwell, out.data(), (size_t)n * 8);
+    memcpy(root_posterior, out.data() + n, (size_t)n * 8);
+    memcpy(trans, out.data() + 2 * n, nn * 8);
     return RT_OK;
 }
 

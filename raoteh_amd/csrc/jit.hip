@@ -2078,6 +2078,13 @@ struct rt_jit_job {
     int rc = RT_ERR_UNSUPPORTED;
     double seconds = 0.0;
     std::string error;
+    // (a job nobody waited for is joined when the last reference goes -- at the latest when
+    // this library's statics are destroyed at exit, which is before the HIP runtime's, loaded
+    // earlier: a joinable std::thread must not be destroyed)
+    ~rt_jit_job()
+    {
+        if (worker.joinable()) worker.join();
+    }
 };
 
 namespace {

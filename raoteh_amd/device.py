@@ -409,6 +409,18 @@ class SiteBatch(object):
     def kernel_name(self):
         return (_lib.lib().rt_sites_kernel_name(self._h) or b'').decode()
 
+    def set_weights(self, weights=None):
+        """Per-site multiplicities for expected_history_statistics (site patterns);
+        None = every site counts once."""
+        if weights is None:
+            _lib.check(_lib.lib().rt_sites_set_weights(self._h, None))
+            return self
+        w = _f64(weights)
+        if w.shape != (self.nsites,):
+            raise ValueError('one weight per site expected')
+        _lib.check(_lib.lib().rt_sites_set_weights(self._h, _ptr(w, c_double)))
+        return self
+
     def wait_for_kernel(self):
         """Block until the background compile of this batch's tree-specialised kernel (if
         one is pending: rt_set_option 'jit_async') has finished and the batch has switched
@@ -571,6 +583,23 @@ class TreeModel(object):
         per-edge expm from the resident rates (optional) + prune; asynchronous."""
         _lib.check(_lib.lib().rt_step(self._h, batch._h,
                                       1 if recompute_transitions else 0))
+
+    def expected_history_statistics(self, batch, recompute_transitions=True,
+                                    return_status=False):
+        """rt_expect_step: the reference's get_expected_history_statistics
+        (_mjp_dense.py:410-539) summed over the resident batch -- (dwell f64[n], summed
+        root posteriors f64[n], transitions f64[n, n]) -- with nothing but those numbers
+        crossing PCIe.  Rates must have been set with set_rates; 8 < nstates <= 64."""
+        n = self.nstates
+        dwell = np.empty(n)
+        rootp = np.empty(n)
+        trans = np.empty((n, n))
+        status = np.zeros(batch.nsites, dtype=np.int32) if return_status else None
+        _lib.check(_lib.lib().rt_expect_step(
+            self._h, batch._h, 1 if recompute_transitions else 0, _ptr(dwell, c_double),
+            _ptr(rootp, c_double), _ptr(trans, c_double),
+            None if status is None else _ptr(status, c_int32)))
+        return (dwell, rootp, trans, status) if return_status else (dwell, rootp, trans)
 
     def allreduce(self, batch):
         _lib.check(_lib.lib().rt_allreduce_totals(self.ctx._h, batch._h))

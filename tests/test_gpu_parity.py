@@ -1119,6 +1119,93 @@ def test_expected_history_statistics_codon_model(ra):
     np.testing.assert_allclose(bt, ref_t, rtol=1e-9, atol=1e-13)
 
 
+@pytest.mark.parametrize('n', [9, 20, 31, 40, 61, 64])
+def test_resident_expectation_step_matches_the_reference_shaped_path(ra, n):
+    """rt_expect_step on an uploaded batch (nothing marshalled per call) against
+    get_expected_history_statistics_batch -- the reference-shaped path that is pinned to the
+    reference's own numbers by tests/golden/expectations.json -- for dense / state / mask
+    batches, per-edge rate matrices, site weights, a batch that runs a tree-specialised
+    pruning kernel, and repeated calls with new rates (an EM loop)."""
+    from raoteh_amd import _mjp_dense
+    rng = np.random.RandomState(300 + n)
+    T, root, leaves = ra.synth.random_tree(23, seed=n, max_children=3)
+
+    def random_rates():
+        Q = rng.exponential(size=(n, n)) * (rng.uniform(size=(n, n)) < 0.5)
+        np.fill_diagonal(Q, 0.0)
+        Q[np.arange(n), (np.arange(n) + 1) % n] += 0.2
+        Q -= np.diag(Q.sum(axis=1))
+        return Q / np.abs(np.diag(Q)).mean()
+
+    Q0 = random_rates()
+    some_edge = list(nx.bfs_edges(T, root))[3]
+    T[some_edge[0]][some_edge[1]]['Q'] = random_rates()        # one edge with its own matrix
+    pi = rng.dirichlet(np.ones(n))
+    nsites = 150
+    states = rng.randint(n, size=(nsites, len(leaves)))
+    states[rng.uniform(size=states.shape) < 0.2] = 255
+    w = rng.randint(1, 4, size=nsites).astype(float)
+    want = _mjp_dense.get_expected_history_statistics_batch(
+        T, root, n, root_distn=pi, Q_default=Q0, weights=w, obs_nodes=leaves, data=states,
+        kind='state')
+    model = ra.device.TreeModel(T, root, n)
+    model.set_rates(Q_default=Q0)
+    model.set_root_distn(pi)
+    total = sum(d['weight'] for _, _, d in T.edges(data=True))
+    dense = np.ones((nsites, len(leaves), n))
+    obs = states != 255
+    dense[obs] = 0.0
+    ii, kk = np.nonzero(obs)
+    dense[ii, kk, states[ii, kk]] = 1.0
+    masks = np.zeros((nsites, len(leaves)), dtype=np.uint64)
+    for sidx in range(n):
+        masks |= dense[..., sidx].astype(np.uint64) << np.uint64(sidx)
+    for kind, data in (('state', states.astype(np.uint8)), ('dense', dense), ('mask', masks)):
+        for jit in (0, 1):
+            ra.lib.check(ra.lib.lib().rt_set_option(b'jit', jit))
+            try:
+                batch = model.upload_sites(leaves, data, kind=kind).set_weights(w)
+            finally:
+                ra.lib.check(ra.lib.lib().rt_set_option(b'jit', -1))
+            ll, _ = model.log_likelihoods(batch)
+            assert batch.kernel_name.startswith('prune_tree_jit' if jit else 'prune_mfma')
+            dwell, rootp, trans, status = model.expected_history_statistics(
+                batch, return_status=True)
+            assert not status.any()
+            np.testing.assert_allclose(dwell, want[0], rtol=1e-10, atol=1e-14)
+            np.testing.assert_allclose(rootp, want[1], rtol=1e-10, atol=1e-14)
+            np.testing.assert_allclose(trans, want[2], rtol=1e-10, atol=1e-13)
+            assert dwell.sum() == pytest.approx(total * w.sum(), rel=1e-10)
+            assert rootp.sum() == pytest.approx(w.sum(), rel=1e-11)
+            # the likelihood path of the same batch is untouched by the expectation step
+            ll2, _ = model.log_likelihoods(batch)
+            np.testing.assert_array_equal(ll, ll2)
+    # new rates, same resident batch: what an EM iteration does
+    Q1 = random_rates()
+    model.set_rates(Q_default=Q1)
+    got = model.expected_history_statistics(batch, recompute_transitions=False)
+    want1 = _mjp_dense.get_expected_history_statistics_batch(
+        T, root, n, root_distn=pi, Q_default=Q1, weights=w, obs_nodes=leaves, data=states,
+        kind='state')
+    for a, b in zip(got, want1):
+        np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-13)
+    batch.set_weights(None)
+    got = model.expected_history_statistics(batch)
+    assert got[1].sum() == pytest.approx(nsites, rel=1e-11)
+    # a site the data rule out: flagged, as the reference raises NumericalZeroProb
+    bad = np.array([[0.0] * n] + [[1.0] * n] * (len(leaves) - 1))[None]
+    b2 = model.upload_sites(leaves, bad, kind='dense')
+    out = model.expected_history_statistics(b2, return_status=True)
+    assert out[3][0] == 2
+    if n <= 8 + 1:
+        T, root, leaves = ra.synth.random_tree(23, seed=n, max_children=3)
+        m4 = ra.device.TreeModel(T, root, 4)
+        m4.set_rates(Q_default=ra.synth.hky85()[0])
+        b4 = m4.upload_sites(leaves, np.zeros((3, len(leaves)), dtype=np.uint8), kind='state')
+        with pytest.raises(ra.lib.RaotehHipError):
+            m4.expected_history_statistics(b4)
+
+
 def test_expected_history_statistics_batch(ra):
     """The batched form: the site sum of the reference's per-site statistics from
     ONE Frechet block exponential per edge, with site-pattern weights."""
