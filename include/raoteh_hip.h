@@ -332,6 +332,10 @@ int rt_sites_clone(rt_sites *sites, rt_sites **clone);
 /* Wait for the background compile of this batch's tree-specialised kernel, if one is
  * pending, and switch the batch to it (see "jit_async").                              */
 int rt_sites_jit_wait(rt_sites *sites);
+/* Join every background compile of the process.  Call it before the process exits if batches
+ * may still be compiling (rt_ctx_destroy does it for its own context): a compile thread must
+ * not be running while exit handlers tear the compiler down.                            */
+int rt_jit_wait_all(void);
 int rt_sites_destroy(rt_sites *sites);
 int64_t rt_sites_device_bytes(const rt_sites *sites);
 /* Seconds rt_sites_create spent in hiprtc for this batch's tree-specialised kernel

@@ -122,6 +122,7 @@ SIGNATURES = {
                                 c_void_p, POINTER(c_void_p)]),
     'rt_sites_clone': (c_int, [c_void_p, POINTER(c_void_p)]),
     'rt_sites_jit_wait': (c_int, [c_void_p]),
+    'rt_jit_wait_all': (c_int, []),
     'rt_expect_step': (c_int, [c_void_p, c_void_p, c_int, _p_f64, _p_f64, _p_f64, _p_i32]),
     'rt_sites_set_weights': (c_int, [c_void_p, _p_f64]),
     'rt_sites_destroy': (c_int, [c_void_p]),
@@ -183,6 +184,9 @@ def lib():
         fn.restype = restype
         fn.argtypes = argtypes
     _lib = handle
+    # background compiles must have finished before the process runs its exit handlers
+    import atexit
+    atexit.register(handle.rt_jit_wait_all)
     return _lib
 
 

@@ -2121,6 +2121,16 @@ std::shared_ptr<rt_jit_job> rt_jit_start(rt_ctx *ctx, std::vector<std::string> s
     return job;
 }
 
+// A compile thread must not be inside hiprtc when the process runs its exit handlers (the
+// compiler's own lazily created statics are destroyed before this library's): a host program
+// that lets batches compile in the background calls this before it exits -- the Python
+// binding registers it with atexit.
+extern "C" int rt_jit_wait_all(void)
+{
+    rt_jit_join_all(nullptr);
+    return RT_OK;
+}
+
 bool rt_jit_job_done(rt_jit_job *job, bool wait)
 {
     if (!job) return true;
@@ -2139,14 +2149,14 @@ void rt_jit_job_result(rt_jit_job *job, int *rc, int *chosen, double *seconds, s
     *error = job->error;
 }
 
-// rt_ctx_destroy: no thread of this context may outlive it
+// rt_ctx_destroy: no thread of this context may outlive it (ctx == nullptr: every job)
 void rt_jit_join_all(const rt_ctx *ctx)
 {
     std::vector<std::shared_ptr<rt_jit_job>> mine;
     {
         std::lock_guard<std::mutex> lock(g_jobs_mutex);
         for (auto it = g_jobs.begin(); it != g_jobs.end();) {
-            if ((*it)->ctx == ctx || (*it)->done.load()) {
+            if (!ctx || (*it)->ctx == ctx || (*it)->done.load()) {
                 mine.push_back(*it);
                 it = g_jobs.erase(it);
             } else {
