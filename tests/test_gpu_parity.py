@@ -2395,6 +2395,104 @@ def test_rao_teh_batch_of_different_sites_and_the_generator(ra, where):
         next(_sampler.gen_restricted_histories(T, Qg, impossible, root))
 
 
+@pytest.mark.parametrize('where', ['device', 'host'])
+def test_rao_teh_stationary_law_on_a_pure_cycle_is_exact(ra, where):
+    """A pure 4-cycle 0 -> 1 -> 2 -> 3 -> 0 (unit rates) on a 3-node tree whose two leaves are
+    observed in state 0: a history is its root state s and the numbers of changes on the two
+    edges, k_a = k_b = -s (mod 4), and the posterior -- the stationary law of a Rao-Teh sweep
+    at ANY uniformization factor -- is known in closed form:
+        p(s, k_a, k_b)  ~  pi_s  Poisson(k_a; t_a)  Poisson(k_b; t_b).
+    Histories that differ by a full turn on an edge are separate modes; a sweep adds a turn
+    only when four new virtual events fall on that edge.  Round 2's soak saw such a case 22
+    standard errors off after 3 000 sweeps at factor 2 and called it slow mixing; here the
+    claim is a test: at factor 2 the law of (root state, total changes) over many chains
+    is (i) visibly short of the turned modes after a few sweeps on short branches and
+    (ii) the exact law, by chi-square, once the chains have mixed -- on long and on short
+    branches, as at factor 16."""
+    from math import exp, factorial
+    from raoteh_amd import _sampler
+    n = 4
+    Q = np.zeros((n, n))
+    for i in range(n):
+        Q[i, (i + 1) % n] = 1.0
+    Q -= np.diag(Q.sum(axis=1))
+    cls = _sampler.DeviceHistoryBatch if where == 'device' else _sampler.HistoryBatch
+    C = 20000 if where == 'device' else 3000
+
+    def exact(ta, tb, kmax=40):
+        law = {}
+        for s in range(n):
+            for ka in range((-s) % n, kmax, n):
+                for kb in range((-s) % n, kmax, n):
+                    w = 0.25 * exp(-ta) * ta ** ka / factorial(ka) * exp(-tb) * tb ** kb / factorial(kb)
+                    law[(s, ka + kb)] = law.get((s, ka + kb), 0.0) + w
+        z = sum(law.values())
+        return dict((k, v / z) for k, v in law.items())
+
+    def observed(batch):
+        root = batch.root_states()
+        total = batch.transition_counts().reshape(C, -1).sum(axis=1)
+        return root, total
+
+    def chi_square(root, total, law):
+        cells = sorted(law, key=lambda k: -law[k])
+        stat, dof, rest_e, rest_o = 0.0, -1, 0.0, 0
+        seen = 0
+        for key in cells:
+            e = law[key] * C
+            o = int(((root == key[0]) & (total == key[1])).sum())
+            seen += o
+            if e >= 8.0:
+                stat += (o - e) ** 2 / e
+                dof += 1
+            else:
+                rest_e += e
+                rest_o += o
+        rest_o += C - seen
+        if rest_e >= 8.0:
+            stat += (rest_o - rest_e) ** 2 / rest_e
+            dof += 1
+        return stat, dof
+
+    for (ta, tb), factor, sweeps in (((3.0, 2.0), 2.0, 400), ((0.9, 0.7), 2.0, 3000),
+                                     ((0.9, 0.7), 16.0, 300)):
+        if where == 'host' and sweeps > 400:
+            continue                         # (the numpy-orchestrated batch: the quick case only)
+        T = nx.Graph()
+        T.add_edge(0, 1, weight=ta)
+        T.add_edge(0, 2, weight=tb)
+        law = exact(ta, tb)
+        # a full turn on some edge: more changes than the 2 (-s mod 4) the root state needs
+        base = lambda st: 2 * ((-st) % n)
+        turned = sum(p for (st, k), p in law.items() if k >= base(st) + 4)
+        b = cls(T, 0, Q, node_to_allowed_states={1: {0}, 2: {0}}, nchains=C,
+                root_distn=np.full(n, 0.25), uniformization_factor=factor, seed=11, ctx=ra.ctx)
+        def run(k):
+            if where == 'device':
+                b.sweep(k)
+            else:
+                for _ in range(k):
+                    b.sweep()
+        if (ta, factor) == (0.9, 2.0):
+            run(3)
+            root, total = observed(b)
+            early = float((total >= 2 * ((-root) % n) + 4).mean())
+            # the start-up histories have no turn; the turned modes fill up from below
+            assert early <= turned + 4.0 * np.sqrt(turned / C), (early, turned)
+            run(sweeps - 3)
+        else:
+            run(sweeps)
+        root, total = observed(b)
+        # structure: both edges carry -s (mod 4) changes, so the total is -2 s (mod 4)
+        assert ((total + 2 * root) % n == 0).all()
+        stat, dof = chi_square(root, total, law)
+        # chi-square upper tail: mean dof, sd sqrt(2 dof); a biased sampler is off by hundreds
+        assert stat < dof + 6.0 * np.sqrt(2.0 * dof) + 10.0, (ta, tb, factor, stat, dof)
+        late = float((total >= 2 * ((-root) % n) + 4).mean())
+        assert abs(late - turned) < 6.0 * np.sqrt(turned * (1 - turned) / C) + 1e-3, \
+            (ta, tb, factor, late, turned)
+
+
 def test_forest_trees_beyond_the_lds_image(ra):
     """Trees with more nodes than the wave-private LDS image holds (csrc/forest.hip,
     FOREST_CAP = 1024) take the coherent global path: the boolean passes and the upward
