@@ -811,6 +811,7 @@ extern "C" int rt_sites_destroy(rt_sites *s)
     hipFree(s->d_ops); hipFree(s->d_lane_ops); hipFree(s->d_lane_ops_a); hipFree(s->d_lane_ops_b); hipFree(s->d_loglik); hipFree(s->d_status);
     if (s->model->ctx->comm_stream) hipStreamSynchronize(s->model->ctx->comm_stream);
     hipFree(s->d_partial); hipFree(s->d_partial_alt); hipFree(s->d_scratch); hipFree(s->d_half);
+    hipFree(s->d_half_count);
     if (s->totals_slot >= 0) {
         // keep the free list sorted (descending) so that batches created one after
         // the other keep getting neighbouring slots
@@ -970,6 +971,10 @@ static int sites_alloc(rt_sites *s, bool generic)
     if (e == hipSuccess && s->jit_halves)      // [tile][half][k-step][lane] (jit.hip)
         e = hipMalloc((void **)&s->d_half,       // (padded to whole groups of <= 8 tiles)
                       (size_t)(s->nblocks + 8) * 2 * ((n + 15) / 16) * 4 * 64 * 8);
+    if (e == hipSuccess && s->jit_halves) {
+        e = hipMalloc((void **)&s->d_half_count, (size_t)(s->nblocks + 8) * 4);
+        if (e == hipSuccess) e = hipMemset(s->d_half_count, 0, (size_t)(s->nblocks + 8) * 4);
+    }
     if (e == hipSuccess)
         e = hipMemcpy(s->d_ops, s->ops.data(), s->ops.size() * sizeof(rt_op),
                       hipMemcpyHostToDevice);
@@ -1076,6 +1081,9 @@ static int sites_halves_setup(rt_sites *s)
 {
     RT_TRY(rt_jit_companion(s->model->ctx, s->jit_fn, "rt_jit_combine", &s->jit_combine));
     s->jit_halves = true;          // sites_alloc allocates d_half
+    // (the pipelined generator folds the combine step into the pruning kernel; the serial
+    // generator, RAOTEH_JIT_SPLIT=serial, has no halves form)
+    s->jit_fold = rt_jit_fold_enabled();
     return RT_OK;
 }
 
@@ -1529,6 +1537,7 @@ static int sites_create_impl(rt_model *m, int64_t nsites, int kind, int64_t nobs
             s->compact_states = 0;
             s->jit_quad = false;
             s->jit_halves = false;
+            s->jit_fold = false;
             s->jit_combine = nullptr;
             s->jit_fused = false;
         }
@@ -1712,6 +1721,11 @@ int rt_sites_jit_poll(rt_sites *s, bool wait)
         hipMalloc((void **)&s->d_half,
                   (size_t)(s->nblocks + 8) * 2 * ((m->n + 15) / 16) * 4 * 64 * 8) != hipSuccess)
         src = RT_ERR_NOMEM;
+    if (src == RT_OK && s->jit_halves && !s->d_half_count) {
+        if (hipMalloc((void **)&s->d_half_count, (size_t)(s->nblocks + 8) * 4) != hipSuccess ||
+            hipMemset(s->d_half_count, 0, (size_t)(s->nblocks + 8) * 4) != hipSuccess)
+            src = RT_ERR_NOMEM;
+    }
     if (src == RT_OK && !rt_jit_verified(m->ctx, fn) && !getenv("RAOTEH_JIT_NO_VERIFY")) {
         src = verify_jit_kernel(s, s->jit_kind);
         rt_jit_set_verified(m->ctx, fn, src == RT_OK);
@@ -1722,6 +1736,7 @@ int rt_sites_jit_poll(rt_sites *s, bool wait)
         s->jit_tiles = 1;
         s->jit_quad = false;
         s->jit_halves = false;
+        s->jit_fold = false;
         s->jit_combine = nullptr;
         return RT_OK;
     }
@@ -1765,6 +1780,7 @@ extern "C" int rt_sites_clone(rt_sites *src, rt_sites **out)
     s->jit_tiles = src->jit_tiles;
     s->jit_quad = src->jit_quad;
     s->jit_halves = src->jit_halves;
+    s->jit_fold = src->jit_fold;
     s->jit_combine = src->jit_combine;
     s->jit_fused = src->jit_fused;
     s->compact_states = src->compact_states;

@@ -95,6 +95,7 @@ struct rt_ctx {
     struct rt_sites *pending_reduce = nullptr;
     size_t expm_attr_lds = 0;      // dynamic-LDS attribute already granted to expm_kernel
     size_t expm_ts_attr_lds[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ... to the Taylor kernels (per NT)
+    size_t expm_split_attr_lds = 0;                           // ... to the two-workgroup form
     double *d_expm_scratch = nullptr;   // matrices of the order > 64 Taylor kernel (grow-only)
     void *expect_cache = nullptr;       // expect_mfma.hip: model + packed batch of the last call
     hipStream_t stream2 = nullptr;      // side stream of two-kernel pruning launches (lazy)
@@ -221,6 +222,10 @@ struct rt_sites {
     bool jit_halves = false;
     void *jit_combine = nullptr;
     double *d_half = nullptr;
+    // folded form: the second workgroup of a pair to arrive finishes the pair's tiles (no
+    // combine launch); d_half_count: one arrival counter per pair, zero between launches
+    bool jit_fold = false;
+    int *d_half_count = nullptr;
     // the same cut for the split-M INTERPRETER kernel (prune.hip rt_interp_halves), used while
     // the batch has no tree-specialised kernel: the two root programs, the P record and the
     // stream position the second one starts at, the root's own stream position (-1: none)
@@ -311,6 +316,7 @@ std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int 
                                bool quad = false);
 std::string rt_jit_mfma_split_source(const std::vector<rt_op> &ops, int n, int K, int T, int D,
                                      int LA);
+bool rt_jit_fold_enabled();
 std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, int n, int K, int T,
                                                int D, int LA, bool halves = false);
 // steps of the two root programs the halves form would run (0, 0: the root has < 2 children)

@@ -24,6 +24,8 @@
 //   step-ordered layout the pruning kernel of this model reads (lane family:
 //   [step][n][n]; MFMA family: A-fragment order), which removes a launch.
 #include "common.h"
+
+#include <algorithm>
 #include "reduce.h"
 
 #include <cstdlib>
@@ -634,15 +636,87 @@ __device__ __forceinline__ void mm_blocked(const double *X, const double *Y, dou
     __syncthreads();
 }
 
+// SPLIT (NT = 4, few matrices): TWO workgroups per matrix.  With 126 edges of a 64-leaf tree
+// the kernel above occupies 126 of 256 CUs and its time is a chain of 5-6 dependent 64^3
+// products.  A Horner step T <- A^3 T + B_j only needs the COLUMNS of T it produces, so after
+// A, A^2 and A^3 (computed by both workgroups, in full) workgroup h of a pair runs the Horner
+// steps on columns 32 h .. 32 h + 31 alone -- 4 x 2 output tiles, one row tile and two MFMAs
+// per k-step and wave instead of 2 x 2 tiles and four -- and stores that half of the result.
+// No exchange between the two, the same arithmetic per entry (bit-identical results).  When the
+// matrix needs squarings (which need all of T) both workgroups run the whole chain.
+struct half_tiles {
+    double v[2][4];          // column tiles 2 h, 2 h + 1 of this wave's row tile
+};
+
+__device__ __forceinline__ void load_half_tiles(const double *M, half_tiles &t, int h)
+{
+    constexpr int LD = 65;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            t.v[v][r] = M[(16 * wave + 4 * r + lq) * LD + 16 * (2 * h + v) + lr];
+}
+
+// C[:, half h] = X * Y[:, half h] + cf0 I + cf1 R1 + cf2 R2 (64 x 64 matrices, LD 65);
+// C may alias Y
+__device__ __forceinline__ void mm_half(const double *X, const double *Y, double *C,
+                                        const double *cf, const half_tiles &R1,
+                                        const half_tiles &R2, int h)
+{
+    constexpr int LD = 65, KS = 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // row tile
+    const int lr = lane & 15, lq = lane >> 4;
+    double4_t acc[2];
+    const double *ap = X + (16 * wave + lr) * LD + lq;
+    const double *bp = Y + lq * LD + 32 * h + lr;
+    {
+        const double c0 = cf[0], c1 = cf[1], c2 = cf[2];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int col = 16 * (2 * h + v) + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * wave + 4 * r + lq;
+                double w = c1 * R1.v[v][r];
+                w += c2 * R2.v[v][r];
+                if (row == col && (double)row < cf[3]) w += c0;
+                acc[v][r] = w;
+            }
+        }
+    }
+    double a0 = ap[0], b00 = bp[0], b01 = bp[16];
+    for (int kk = 0; kk < KS; ++kk) {
+        const int kn = kk + 1 < KS ? kk + 1 : kk;
+        const double a1 = ap[4 * kn], b10 = bp[4 * kn * LD], b11 = bp[4 * kn * LD + 16];
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b00, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b01, acc[1], 0, 0, 0);
+        a0 = a1; b00 = b10; b01 = b11;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        const int col = 16 * (2 * h + v) + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) C[(16 * wave + 4 * r + lq) * LD + col] = acc[v][r];
+    }
+    __syncthreads();
+}
+
 // GLOBAL = false: the four matrices in LDS (n <= 64); true: in scratch[blockIdx] (n <= 128)
 // RAOTEH_EXPM_TRACE=1: workgroup 1 of the Taylor kernel stamps the shader clock at its
 // phase boundaries (printed by the launcher): diagnostics
 __device__ int rt_expm_trace_on = 0;
 __device__ unsigned long long rt_expm_trace[8];
 #define RT_EXPM_STAMP(k)                                                              \
-    if (trace_on && blockIdx.x == 1 && threadIdx.x == 0) rt_expm_trace[k] = __builtin_readcyclecounter()
+    if (trace_on && blockIdx.x == (SPLIT ? 2 : 1) && threadIdx.x == 0)                \
+        rt_expm_trace[k] = __builtin_readcyclecounter()
 
-template <int NT, bool GLOBAL>
+template <int NT, bool GLOBAL, bool SPLIT = false>
 __global__ void __launch_bounds__(TPB)
 expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ qidx,
                    const double *__restrict__ tt, double *__restrict__ P,
@@ -666,7 +740,9 @@ expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ 
     double *B2 = B1 + MSZ;                     // A^3
     double *B3 = B2 + MSZ;                     // T
 
-    const int b = blockIdx.x;
+    static_assert(!SPLIT || (NT == 4 && !GLOBAL), "two workgroups per matrix: 49 <= n <= 64");
+    const int b = SPLIT ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    const int half = SPLIT ? (int)(blockIdx.x & 1) : 0;      // which columns this workgroup stores
     const int tid = threadIdx.x;
     const int nn = n * n;
     const int KSn = (n + 3) / 4, NTn = (n + 15) / 16;      // of the n x n matrix (Pfrag)
@@ -741,7 +817,14 @@ expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ 
             colsum[tid] = sum;
         }
         __syncthreads();
-        for (int jj = 0; jj < RN; ++jj) nrm = fmax(nrm, colsum[jj]);
+        // max over the RN <= 64 column sums: one value per lane and a butterfly (a loop of RN
+        // dependent LDS reads per thread was a quarter of this phase)
+        {
+            const int ln = tid & 63;
+            nrm = ln < RN ? colsum[ln] : 0.0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) nrm = fmax(nrm, __shfl_xor(nrm, o, 64));
+        }
     } else {
         constexpr int PER = (MSZ + TPB - 1) / TPB;
         for (int c0 = 0; c0 < PER; c0 += 8) {
@@ -821,13 +904,47 @@ expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ 
     if (tid < 20) cfs_all[tid >> 2][tid & 3] = (tid & 3) == 3 ? (double)n
                                                              : c_inv_fact[3 * (tid >> 2) + (tid & 3)];
     __syncthreads();
-    for (int jj = q - 2; jj >= 0; --jj)
-        mm_blocked<NT>(B2, B3, B3, cfs_all[jj], B0, B1, &ra, &ra2);    // T = A^3 T + B_j
+    if (SPLIT && s == 0) {
+        if constexpr (SPLIT) {
+            half_tiles ha, ha2;
+            load_half_tiles(B0, ha, half);
+            load_half_tiles(B1, ha2, half);
+            for (int jj = q - 2; jj >= 0; --jj)
+                mm_half(B2, B3, B3, cfs_all[jj], ha, ha2, half);   // T[:, half] = A^3 T[:, half] + B_j
+        }
+    } else {
+        for (int jj = q - 2; jj >= 0; --jj)
+            mm_blocked<NT>(B2, B3, B3, cfs_all[jj], B0, B1, &ra, &ra2);    // T = A^3 T + B_j
+    }
     RT_EXPM_STAMP(5);
     for (int r = 0; r < s; ++r) mm_blocked<NT>(B3, B3, B3, nullptr, nullptr, nullptr);
     RT_EXPM_STAMP(6);
 
     const double *Xb = B3;
+    if constexpr (SPLIT) {
+        // this workgroup's columns only: P in the reference's order, the A fragments of its
+        // k-pairs (column c of P is k-step c / 4: columns 32 h .. 32 h + 31 = pairs 4 h .. 4 h + 3)
+        const int jc = 32 * half + (tid & 31), g = tid >> 5;
+        if (jc < n)
+            for (int i = g; i < n; i += TPB / 32) Pb[i * n + jc] = Xb[i * LD + jc];
+        if (step >= 0 && frag_kind == 1) {
+            const int KP = (KSn + 1) / 2;
+            const int total = NTn * KP * 128;
+            for (int blk = tid >> 7; blk < NTn * 4; blk += TPB >> 7) {
+                const int mm = blk >> 2, qq = 4 * half + (blk & 3);
+                if (qq < KP) {
+                    const int e = (mm * KP + qq) * 128 + (tid & 127);
+                    const int e2 = e & 1;
+                    const int ln = (e >> 1) & 63;
+                    const int row = 16 * mm + (ln & 15);
+                    const int col = 4 * (2 * qq + e2) + (ln >> 4);
+                    Pfrag[(long)step * total + e] = (col < RN) ? Xb[row * LD + col] : 0.0;
+                }
+            }
+        }
+        RT_EXPM_STAMP(7);
+        return;
+    }
     if (!GLOBAL) {               // thread = (column, row group) as in the load: no division
         constexpr int RP = TPB / RN;
         const int jc = tid % RN, g = tid / RN;
@@ -1205,6 +1322,23 @@ int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
                             dim3(TPB), lds_t, (int)n, d_Q, d_qidx, d_t, d_P, d_info,            \
                             d_step_of_node, frag_kind, d_Pfrag, d_Pquad, scratch, red);         \
         } while (0)
+        // few 49..64-state matrices (the edges of one tree): two workgroups per matrix, the
+        // Horner steps in column halves (RAOTEH_EXPM_SPLIT=0 / 1 overrides)
+        bool split2 = nt == 4 && 2 * count + extra <= (int64_t)std::max(2, ctx->num_cus) && !d_Pquad;
+        if (const char *v = getenv("RAOTEH_EXPM_SPLIT")) split2 = nt == 4 && !d_Pquad && atoi(v) != 0;
+        if (split2) {
+            if (lds_t > ctx->expm_split_attr_lds) {
+                RT_HIP(hipFuncSetAttribute((const void *)expm_taylor_kernel<4, false, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
+                ctx->expm_split_attr_lds = lds_t;
+            }
+            snprintf(ctx->slots[RT_K_EXPM].name, sizeof(ctx->slots[RT_K_EXPM].name),
+                     "expm_taylor_ps_mfma_split2");
+            RT_LAUNCH_TIMED(ctx, (expm_taylor_kernel<4, false, true>),
+                            dim3(2u * (unsigned)count + extra), dim3(TPB), lds_t, (int)n, d_Q, d_qidx,
+                            d_t, d_P, d_info, d_step_of_node, frag_kind, d_Pfrag, d_Pquad, scratch,
+                            red);
+        } else
         switch (nt) {
         case 1: RT_TAYLOR(1, false); break;
         case 2: RT_TAYLOR(2, false); break;

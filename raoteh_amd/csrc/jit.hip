@@ -1428,10 +1428,27 @@ void rt_jit_root_halves(const std::vector<rt_op> &ops, int *stepsA, int *stepsB)
 // CU, or as 1 250 workgroups of one, three at a time per CU).  Each writes its root accumulator (own
 // rows) to halfbuf[tile][half][k-step][lane]; the module's second kernel, rt_jit_combine,
 // multiplies the two and runs the root step and the site epilogue unchanged.
+// Root halves, folded: the second workgroup of a pair to arrive finishes the pair's tiles
+// itself (root step + site epilogue), so that a pruning launch is ONE kernel; the pair meets
+// at a counter in device memory, the shares cross the two workgroups' XCDs as agent-scope
+// atomics (write-through / L2-bypassing).
+// BUILT, MEASURED, AND NOT THE DEFAULT (RAOTEH_JIT_FOLD=1 turns it on; bit-identical, in the
+// -m gpu suite): config 3, 250 workgroups of five half-tiles -- the folded kernel takes
+// 176.7 us where the two kernels take 171.1 + 4.1, the step 202.7 us against 203.4: the last
+// arrivers read ten shares per lane past the L2 and run the root step while the rest of the
+// chip has nothing left to do, which costs what the second launch cost.  With an agent-scope
+// release fence per workgroup (an L2 write-back each) the kernel takes 189 us.
+bool rt_jit_fold_enabled()
+{
+    const char *v = getenv("RAOTEH_JIT_FOLD");
+    return v && atoi(v) != 0;
+}
+
 std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, int n, int K, int T,
                                                int D, int LA, bool halves)
 {
     (void)LA;
+    const bool fold = halves && rt_jit_fold_enabled();
     // x of a step is published one step early, so its leaf vector must be in registers a
     // step earlier than in the serial kernel: at least two leaves ahead
     D = std::max(D, 2);
@@ -1505,7 +1522,8 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
          "             const double *__restrict__ root_w, double *__restrict__ loglik,\n"
          "             int *__restrict__ status, double *__restrict__ partial,\n"
          "             long nsites, long nblocks"
-      << (halves ? ", double *__restrict__ halfbuf" : "") << ")\n{\n";
+      << (halves ? ", double *__restrict__ halfbuf" : "")
+      << (fold ? ", int *__restrict__ counters" : "") << ")\n{\n";
     // two OBJECTS, not one array of two: step i reads xb<i & 1> while x of step i + 1 is
     // written to the other one, and only for distinct objects does the compiler know that
     // an LDS read may be hoisted above an earlier LDS write (with one array every read of
@@ -1713,8 +1731,13 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
                 for (int t = 0; t < T; ++t) {
                     o << "    {\n    double *hb = halfbuf + ((size_t)tile" << t << " * 2 + " << prog
                       << ") * " << XT << " + (4 * m) * 64 + lane;\n";
-                    for (int r = 0; r < 4; ++r)
-                        o << "    hb[" << r * 64 << "] = a" << op.pop << "_" << t << "_" << r << ";\n";
+                    for (int r = 0; r < 4; ++r) {
+                        if (fold)
+                            o << "    __hip_atomic_store(&hb[" << r * 64 << "], a" << op.pop << "_" << t
+                              << "_" << r << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n";
+                        else
+                            o << "    hb[" << r * 64 << "] = a" << op.pop << "_" << t << "_" << r << ";\n";
+                    }
                     o << "    }\n";
                 }
                 continue;
@@ -1811,7 +1834,51 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
     stamp(nrec, 0);
     }   // programs
     if (halves) {
-        o << "    }\n}\n";
+        if (fold) {
+            const rt_op &root = ops.back();
+            // The shares are agent-scope atomic stores (write-through: they do not sit dirty
+            // in this XCD's L2), so what the release needs is that they have completed before
+            // the counter moves: a workgroup-scope fence (s_waitcnt) does that.  An agent-scope
+            // release fence adds an L2 write-back per workgroup: measured 189 us instead of
+            // 175 for the kernel (RAOTEH_JIT_FOLD_FENCE=agent brings it back for A/B runs).
+            const char *fs = getenv("RAOTEH_JIT_FOLD_FENCE");
+            const std::string scope = (fs && strcmp(fs, "agent") == 0) ? "agent" : "workgroup";
+            o << "    }\n";
+            o << "    // ---- the pair's second workgroup to arrive finishes its tiles\n"
+                 "    __shared__ int arrived;\n"
+                 "    __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"" << scope << "\");\n"
+                 "    __syncthreads();\n"
+                 "    if (threadIdx.x == 0)\n"
+                 "        arrived = __hip_atomic_fetch_add(&counters[blockIdx.x >> 1], 1, __ATOMIC_RELAXED,\n"
+                 "                                         __HIP_MEMORY_SCOPE_AGENT);\n"
+                 "    __syncthreads();\n"
+                 "    if (arrived == 0) return;\n"
+                 "    if (threadIdx.x == 0)          // (for the next launch)\n"
+                 "        __hip_atomic_store(&counters[blockIdx.x >> 1], 0, __ATOMIC_RELAXED,\n"
+                 "                           __HIP_MEMORY_SCOPE_AGENT);\n"
+                 "    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"" << scope << "\");\n";
+            for (int t = 0; t < T; ++t) {
+                o << "    const double *hx" << t << " = halfbuf + (size_t)tile" << t << " * " << 2 * XT
+                  << " + (4 * m) * 64 + lane;\n";
+                if (root.obs >= 0) {
+                    o << "    const rt_d2 ob" << t << "_0 = g" << t << "[" << (long)root.obs * KP * 64 << "];\n";
+                    o << "    const rt_d2 ob" << t << "_1 = pair1 ? g" << t << "["
+                      << ((long)root.obs * KP + 1) * 64 << "] : zero2;\n";
+                }
+                for (int r = 0; r < 4; ++r) {
+                    o << "    const double xr_" << t << "_" << r << " = __hip_atomic_load(&hx" << t << "["
+                      << r * 64 << "], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * __hip_atomic_load(&hx"
+                      << t << "[" << XT + r * 64 << "], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)";
+                    if (root.obs >= 0) o << " * ob" << t << "_" << (r >> 1) << ((r & 1) ? ".y" : ".x");
+                    o << ";\n";
+                }
+            }
+            emit_root_reduce(o, "xr");
+            emit_site_epilogue(o);
+            o << "}\n";
+        } else {
+            o << "    }\n}\n";
+        }
         // ---- second kernel of the module: root step + site epilogue from the two halves,
         // one tile per workgroup whatever T is
         T = 1;
@@ -2334,7 +2401,22 @@ int rt_launch_prune_jit(rt_model *m, rt_sites *s, const rt_fuse_args *fuse)
         // pruning slot holds the first kernel, RT_K_COMBINE the second)
         double *half = s->d_half;
         const double *chalf = s->d_half;
-        void *hargs[] = {&Pord, &obs, &root_w, &loglik, &status, &partial, &nsites, &nblocks, &half};
+        int *counters = s->d_half_count;
+        void *hargs[] = {&Pord, &obs, &root_w, &loglik, &status, &partial, &nsites, &nblocks, &half,
+                         &counters};
+        if (s->jit_fold) {
+            // one kernel: the second workgroup of every pair finishes the pair's tiles
+            const unsigned tpb = 64u * (unsigned)s->jit_waves;
+            const unsigned groups = (unsigned)((s->nblocks + s->jit_tiles - 1) / s->jit_tiles);
+            if (m->ctx->ev_start)
+                RT_HIP(hipExtModuleLaunchKernel((hipFunction_t)s->jit_fn, 2u * groups * tpb, 1, 1, tpb,
+                                                1, 1, 0, m->ctx->stream, hargs, nullptr,
+                                                m->ctx->ev_start, m->ctx->ev_stop, 0));
+            else
+                RT_HIP(hipModuleLaunchKernel((hipFunction_t)s->jit_fn, 2u * groups, 1, 1, tpb, 1, 1, 0,
+                                             m->ctx->stream, hargs, nullptr));
+            return RT_OK;
+        }
         void *cargs[] = {&chalf, &obs, &root_w, &loglik, &status, &partial, &nsites, &nblocks};
         const unsigned tpb = 64u * (unsigned)s->jit_waves;
         const unsigned tiles = (unsigned)s->nblocks;

@@ -100,6 +100,46 @@ def test_pade_expm_kernels_match_scipy_fixture(ra, monkeypatch):
         assert np.log(lk) == pytest.approx(want, rel=RTOL_LL)
 
 
+@pytest.mark.parametrize('n', [49, 61, 64])
+def test_two_workgroup_expm_is_bit_identical(ra, n, monkeypatch):
+    """csrc/expm.hip, SPLIT: few 49..64-state matrices (the edges of one tree) take two
+    workgroups each, the Horner steps in column halves.  Same arithmetic per entry: the
+    transition matrices, the A fragments the pruning kernels read (through the
+    log-likelihoods) and the order / squarings are those of the one-workgroup kernel, also
+    where squarings force both workgroups through the whole chain."""
+    rng = np.random.RandomState(n)
+    T, root, leaves = ra.synth.balanced_tree(16)
+    Q = rng.exponential(size=(n, n)) * (rng.uniform(size=(n, n)) < 0.4)
+    np.fill_diagonal(Q, 0.0)
+    Q -= np.diag(Q.sum(axis=1))
+    Q /= np.abs(np.diag(Q)).mean()
+    # branch lengths over every degree and into the squarings
+    ts = [1e-6, 1e-3, 0.01, 0.05, 0.1, 0.2, 0.6, 1.5, 7.0]
+    for k, (a, b) in enumerate(T.edges()):
+        T[a][b]['weight'] = ts[k % len(ts)]
+    dense = rng.uniform(0.1, 1.0, size=(40, len(leaves), n))
+    out = {}
+    for split in ('0', '1'):
+        monkeypatch.setenv('RAOTEH_EXPM_SPLIT', split)
+        model = ra.device.TreeModel(T, root, n)
+        model.set_rates(Q_default=Q)
+        name = ra.ctx.kernel_time(0)[2]
+        assert name == ('expm_taylor_ps_mfma_split2' if split == '1' else 'expm_taylor_ps_mfma'), name
+        batch = model.upload_sites(leaves, dense, kind='dense')
+        ll, _ = model.log_likelihoods(batch)
+        model.step(batch)
+        ll2, _ = model.fetch_log_likelihoods(batch)
+        np.testing.assert_array_equal(ll, ll2)
+        out[split] = (model.get_transitions(), model.expm_info(), ll)
+    np.testing.assert_array_equal(out['0'][1], out['1'][1])
+    assert set(out['0'][1][1:, 0]) >= {3, 6, 9, 12, 15} and out['0'][1][:, 1].max() >= 2
+    np.testing.assert_array_equal(out['0'][0], out['1'][0])
+    np.testing.assert_array_equal(out['0'][2], out['1'][2])
+    import scipy.linalg
+    pre, idx, ptr, esd = orc.get_expm_augmented_transitions(T, root, n, Q_default=Q)
+    np.testing.assert_allclose(out['1'][0][1:], esd[1:], rtol=1e-9, atol=1e-14)
+
+
 def test_spectral_reconstruction_matches_the_reference_qtop(ra):
     """csrc/spectral.hip through rt_expm_spectral and rt_model_set_rates_spectral against
     examples/p53/qtop.py's own getp_spectral_v2 outputs (tests/golden/spectral.json), and
@@ -717,16 +757,19 @@ def test_tree_specialised_kernel_is_bit_identical(ra, n):
         # ('h5': five half-tiles per workgroup)
         variants = (((0, 0), (1, 64), (1, 49), (1, 7)) if n <= 4 else
                     ((0, 0), (1, 64), (1, 2), (1, 3), (1, 4)) if n <= 32 else
-                    ((0, 0), (1, 64), (1, 2), (1, 3), (1, 'h'), (1, 'h5')) if n <= 64 else
+                    # ('hu': the halves with the combine step folded into the pruning kernel,
+                    # RAOTEH_JIT_FOLD=1)
+                    ((0, 0), (1, 64), (1, 2), (1, 3), (1, 'h'), (1, 'h5'), (1, 'hu')) if n <= 64 else
                     # 64 < n <= 128: NT = 5..8 waves share one or two tiles
-                    ((0, 0), (1, 64), (1, 2), (1, 'h')))
+                    ((0, 0), (1, 64), (1, 2), (1, 'h'), (1, 'hu')))
         for jit, bs in variants:
             ra.lib.check(set_option(b'jit', jit))
             if n <= 4:
                 ra.lib.check(set_option(b'jit_block_sites', bs))
             elif jit:
-                os.environ['RAOTEH_JIT_TILES'] = str(1 if bs in (64, 'h') else 5 if bs == 'h5' else bs)
-                os.environ['RAOTEH_JIT_HALVES'] = '1' if bs in ('h', 'h5') else '0'
+                os.environ['RAOTEH_JIT_TILES'] = str(1 if bs in (64, 'h', 'hu') else 5 if bs == 'h5' else bs)
+                os.environ['RAOTEH_JIT_HALVES'] = '1' if bs in ('h', 'h5', 'hu') else '0'
+                os.environ['RAOTEH_JIT_FOLD'] = '1' if bs == 'hu' else '0'
             try:
                 batch = model.upload_sites(obs_nodes, dense, kind='dense')
                 ll, st = model.log_likelihoods(batch)
@@ -740,11 +783,12 @@ def test_tree_specialised_kernel_is_bit_identical(ra, n):
                 ra.lib.check(set_option(b'jit_block_sites', 0))
                 os.environ.pop('RAOTEH_JIT_TILES', None)
                 os.environ.pop('RAOTEH_JIT_HALVES', None)
+                os.environ.pop('RAOTEH_JIT_FOLD', None)
         assert out[0, 0][3].startswith(('prune_lane', 'prune_mfma')), out[0, 0][3]
         for key in variants[1:]:
             assert out[key][3].startswith('prune_tree_jit'), out[key][3]
             # (a root with one child cannot be cut)
-            assert ('halves' in out[key][3]) == (key[1] in ('h', 'h5') and T.degree(root) > 1), \
+            assert ('halves' in out[key][3]) == (key[1] in ('h', 'h5', 'hu') and T.degree(root) > 1), \
                 out[key][3]
             np.testing.assert_array_equal(out[0, 0][0], out[key][0])
             np.testing.assert_array_equal(out[0, 0][1], out[key][1])

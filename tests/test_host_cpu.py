@@ -7,6 +7,7 @@ CPU-side tests of the product's host logic (no GPU, no compute calls):
 * the product package never imports the oracle
 """
 import ctypes
+import itertools
 import os
 import re
 
@@ -540,8 +541,12 @@ def test_root_halves_source_covers_every_step_once(monkeypatch):
     buf = ctypes.create_string_buffer(1 << 24)
     monkeypatch.setenv('RAOTEH_JIT_HALVES', '1')
     seen_cut = 0
-    for seed, nnodes, n, tiles in ((1, 9, 33, 1), (2, 14, 61, 1), (3, 23, 64, 5), (4, 31, 48, 3),
-                                   (5, 12, 61, 2), (6, 5, 40, 1)):
+    for fold, (seed, nnodes, n, tiles) in itertools.product(
+            (False, True), ((1, 9, 33, 1), (2, 14, 61, 1), (3, 23, 64, 5), (4, 31, 48, 3),
+                            (5, 12, 61, 2), (6, 5, 40, 1))):
+        # RAOTEH_JIT_FOLD=1: the pair's second workgroup finishes the sites in the pruning
+        # kernel itself; the default: the separate combine launch
+        monkeypatch.setenv('RAOTEH_JIT_FOLD', '1' if fold else '0')
         T, root, leaves = synth.random_tree(nnodes, seed=seed, max_children=4)
         ta = TreeArrays(T, root)
         inner = [v for v in T if v not in leaves]
@@ -579,8 +584,16 @@ def test_root_halves_source_covers_every_step_once(monkeypatch):
         # the second kernel: product of the two shares (times the root's own observation)
         assert len(re.findall(r'const double xr_0_\d = ha\[\d+\] \* ha\[\d+\]', combine)) == 4
         assert ('ob_0' in combine) == (ta.node_to_index[root] in obs)
-        assert 'loglik[site]' in combine and 'loglik[site]' not in main
-    assert seen_cut >= 4
+        assert 'loglik[site]' in combine
+        assert ('loglik[site]' in main) == fold
+        assert ('int *__restrict__ counters' in main) == fold
+        if fold:
+            tail = progB.split("the pair's second workgroup", 1)[1]
+            assert tail.count('__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup")') == 1
+            assert progB.count('__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")') == 1
+            assert len(re.findall(r'const double xr_\d+_\d = __hip_atomic_load\(&hx', tail)) == 4 * tiles
+            assert main.count('__hip_atomic_store(&hb[') == 2 * 4 * tiles
+    assert seen_cut >= 8
 
 
 def test_pyfelscore_compat_exports_every_name_the_reference_calls():
