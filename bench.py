@@ -521,7 +521,7 @@ def measure_next_rows(ctx):
         # the internal nodes) + per-edge site sums, each 2 n^2 flops per edge and site, + one
         # order-2n block exponential per edge
         from raoteh_amd import device
-        for name, nsites in (('c3', 10000), ('c5', 50000)):
+        for name, nsites in (('c3', 10000), ('c5', 50000), ('c2', 100000)):
             cfg = synth.make_config(name, nsites=nsites)
             T, root, n = cfg['T'], cfg['root'], cfg['nstates']
             model = device.TreeModel(T, root, n, ctx=ctx)

@@ -5,8 +5,9 @@ history statistics -- the use the reference's get_expected_history_statistics
 (raoteh/sampler/_mjp_dense.py:410-539) is made for, over a whole alignment per
 iteration instead of one site per call:
 
-  (The codon-scale version of this loop on a RESIDENT batch -- rt_expect_step, nothing
-  uploaded per iteration -- is examples/em_codon.py.)
+  (The alignment is uploaded ONCE; an iteration sets the new rates and calls
+  model.expected_history_statistics(batch) -- rt_expect_step, 2 n + n^2 numbers back.  The
+  codon-scale version of this loop is examples/em_codon.py.)
 
   E step  expected dwell time D_i per state and expected number N_ij of i -> j
           changes, summed over the sites (one device call: passes, downward pass,
@@ -30,7 +31,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 
-from raoteh_amd import _mjp_dense, synth          # noqa: E402
+from raoteh_amd import device, synth          # noqa: E402
 
 
 def main(argv):
@@ -48,12 +49,15 @@ def main(argv):
         np.fill_diagonal(R, 0.0)
         return R - np.diag(R.sum(axis=1))
 
+    model = device.TreeModel(T, root, n)
+    model.set_root_distn(pi)
+    model.set_rates(Q_default=rate_matrix(1.0, 1.0))
+    batch = model.upload_sites(cfg['leaves'], states, kind='state')
     mu, kappa = 1.0, 1.0
     for it in range(12):
         t0 = time.perf_counter()
-        dwell, _, trans = _mjp_dense.get_expected_history_statistics_batch(
-            T, root, n, root_distn=pi, Q_default=rate_matrix(mu, kappa),
-            obs_nodes=cfg['leaves'], data=states, kind='state')
+        model.set_rates(Q_default=rate_matrix(mu, kappa))
+        dwell, _, trans = model.expected_history_statistics(batch, recompute_transitions=False)
         dt = time.perf_counter() - t0
         exposure = dwell[:, None] * pi[None, :]
         mu_kappa = trans[ts].sum() / exposure[ts].sum()

@@ -361,9 +361,10 @@ int rt_step(rt_model *model, rt_sites *sites, int recompute_transitions);
  *   trans[c][d]    expected number of c -> d transitions (0 where no rate matrix has c -> d)
  * each site weighted by rt_sites_set_weights (multiplicities of site patterns; default 1).
  * status (optional, int32[nsites]): 2 where a normalising denominator is zero (the reference
- * raises NumericalZeroProb).  8 < n <= RT_MAX_EXPECT_STATES, batches created by
- * rt_sites_create for such n (any observation kind), rates set by rt_model_set_rates.
- * Synchronous.                                                                          */
+ * raises NumericalZeroProb).  n <= RT_MAX_EXPECT_STATES, batches created by rt_sites_create
+ * (n > 4: any observation kind; n <= 4: the fused lane kernel works on allowed sets, so a
+ * dense batch counts a state as allowed where its likelihood is not zero), rates set by
+ * rt_model_set_rates.  Synchronous.                                                     */
 int rt_expect_step(rt_model *model, rt_sites *sites, int recompute_transitions,
             double *dwell, double *root_posterior, double *trans, int32_t *status);
 /* weights f64[nsites] (copied to the device) or NULL = every site counts once           */

@@ -406,6 +406,7 @@ extern "C" int rt_model_destroy(rt_model *m)
     m->ctx->live_models -= 1;
     hipSetDevice(m->ctx->device);
     rt_expect_state_release(m);
+    rt_expect_lane_release(m);
     hipStreamSynchronize(m->ctx->stream);
     hipFree(m->d_indices); hipFree(m->d_indptr); hipFree(m->d_ops); hipFree(m->d_P);
     hipFree(m->d_Pfrag); hipFree(m->d_Pquad); hipFree(m->d_root); hipFree(m->d_Q); hipFree(m->d_spec); hipFree(m->d_qidx);
@@ -807,6 +808,7 @@ extern "C" int rt_sites_destroy(rt_sites *s)
     if (s->jit_fn2) rt_jit_ref(s->model->ctx, s->jit_fn2, -1);
     if (s->expect_twin) rt_sites_destroy(s->expect_twin);
     hipFree(s->d_weights);
+    hipFree(s->d_sets);
     if (!s->obs_borrowed) hipFree(s->d_obs);
     hipFree(s->d_ops); hipFree(s->d_lane_ops); hipFree(s->d_lane_ops_a); hipFree(s->d_lane_ops_b); hipFree(s->d_loglik); hipFree(s->d_status);
     if (s->model->ctx->comm_stream) hipStreamSynchronize(s->model->ctx->comm_stream);

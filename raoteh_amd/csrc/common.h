@@ -163,6 +163,7 @@ struct rt_model {
     bool frag_dirty = true;
     int live_batches = 0;           // site batches created from this model and not yet destroyed
     void *expect_state = nullptr;   // expect_mfma.hip: device buffers of rt_expect_step (lazy)
+    void *expect_lane_state = nullptr;  // passes.hip: its n <= 8 form (plan, pattern bits)
 };
 
 // Device layouts of a site batch:
@@ -251,6 +252,7 @@ struct rt_sites {
     // split-M interpreter twin -- its own program, partial sums and per-site outputs over the
     // SAME resident observations (obs_borrowed: d_obs belongs to the batch it was made from)
     double *d_weights = nullptr;
+    unsigned char *d_sets = nullptr;        // n <= 8: allowed sets [node][site] (built once)
     rt_sites *expect_twin = nullptr;
     bool obs_borrowed = false;
     bool counted = false;           // this batch is in its model's live_batches
@@ -360,6 +362,9 @@ int rt_frechet_statistics_device(rt_ctx *ctx, int64_t n, int64_t nedges, const d
                                  const int32_t *dident, double *ddwell, double *dtrans);
 // ... and what rt_expect_step keeps with a model (rt_model_destroy)
 void rt_expect_state_release(rt_model *m);
+// passes.hip: the n <= 8 form of rt_expect_step's passes (W and status on the device)
+int rt_expect_lane_resident(rt_model *m, rt_sites *s, double *d_W, int *d_status);
+void rt_expect_lane_release(rt_model *m);
 // a split-M interpreter batch over the resident observations of `src` (api.hip)
 int rt_sites_twin_interpreter(rt_sites *src, rt_sites **out);
 // the context's grow-only device scratch (ctx->d_scratch) holds at least `bytes` afterwards

@@ -545,6 +545,7 @@ int expect_state_get(rt_model *m, expect_state_t **out)
     const int64_t n = m->n, N = m->nnodes;
     const int nops = (int)m->ops.size();
     RT_REQUIRE(nops == N && m->ops[(size_t)nops - 1].dst < 0, "unexpected schedule");
+    const bool mfma = n > 4;                   // (n <= 4: the fused lane kernel of passes.hip)
     std::vector<int> step_node((size_t)nops), parent_step((size_t)nops, 0), step_of((size_t)N, -1);
     std::vector<unsigned char> internal((size_t)nops, 0);
     for (int i = 0; i < nops; ++i) {
@@ -559,7 +560,7 @@ int expect_state_get(rt_model *m, expect_state_t **out)
     st->nops = nops;
     const int NT = (int)((n + 15) / 16), KP = ((int)((n + 3) / 4) + 1) / 2;
     const size_t nn = (size_t)n * n, ne = (size_t)(N - 1), mm = 4 * nn;
-    RT_HIP(hipMalloc((void **)&st->d_PT, (size_t)nops * NT * KP * 128 * 8));
+    if (mfma) RT_HIP(hipMalloc((void **)&st->d_PT, (size_t)nops * NT * KP * 128 * 8));
     RT_HIP(hipMalloc((void **)&st->d_W, (size_t)N * nn * 8));
     RT_HIP(hipMalloc((void **)&st->d_B, ne * mm * 8));
     RT_HIP(hipMalloc((void **)&st->d_E, ne * mm * 8));
@@ -601,17 +602,20 @@ extern "C" int rt_expect_step(rt_model *m, rt_sites *s, int recompute_transition
     RT_REQUIRE(m->d_Q && !m->spectral,
                "rt_model_set_rates has not been called (the statistics need the rate matrices)");
     const int64_t n = m->n, N = m->nnodes;
-    if (n <= 8 || n > RT_MAX_EXPECT_STATES || N < 2 || s->layout != RT_LAYOUT_MFMA || s->d_scratch ||
-        m->max_depth > RT_FAST_MAX_DEPTH) {
-        rt_set_error("rt_expect_step: resident batches of 8 < n <= %d states in the matrix-pipe "
-                     "layout (n=%lld here)", RT_MAX_EXPECT_STATES, (long long)n);
+    const bool lane = n <= 4;                  // resident in the lane layout: the fused lane kernel
+    if (n > RT_MAX_EXPECT_STATES || N < 2 || s->d_scratch || m->max_depth > RT_FAST_MAX_DEPTH ||
+        s->layout != (lane ? RT_LAYOUT_LANE : RT_LAYOUT_MFMA)) {
+        rt_set_error("rt_expect_step: resident batches of n <= %d states on trees the fast "
+                     "kernels take (n=%lld here)", RT_MAX_EXPECT_STATES, (long long)n);
         return RT_ERR_UNSUPPORTED;
     }
     rt_ctx *ctx = m->ctx;
     RT_HIP(hipSetDevice(ctx->device));
     const int NT = (int)((n + 15) / 16), KS = (int)((n + 3) / 4), KP = (KS + 1) / 2;
-    // the four per-step arrays of the passes: nodes x tiles x 8 KB x NT each
-    const double scratch_gb = 4.0 * (double)N * (double)((s->nsites + 15) / 16) * NT * 2048.0 / 1e9;
+    // the four per-step arrays of the passes: nodes x tiles x 8 KB x NT each (n <= 8: one
+    // array of nodes x states x sites doubles)
+    const double scratch_gb = lane ? (double)N * (double)n * (double)s->nsites * 8.0 / 1e9
+                                   : 4.0 * (double)N * (double)((s->nsites + 15) / 16) * NT * 2048.0 / 1e9;
     if (scratch_gb > 96.0) {
         rt_set_error("rt_expect_step: the passes of this batch need %.0f GB of scratch; split the "
                      "batch", scratch_gb);
@@ -619,27 +623,37 @@ extern "C" int rt_expect_step(rt_model *m, rt_sites *s, int recompute_transition
     }
     expect_state_t *st = nullptr;
     RT_TRY(expect_state_get(m, &st));
-    if (!s->expect_twin) RT_TRY(rt_sites_twin_interpreter(s, &s->expect_twin));
-    rt_sites *x = s->expect_twin;
-    if (st->status_cap < s->nsites) {
+    const int64_t status_need = (s->nsites + 63) / 64 * 64;
+    if (st->status_cap < status_need) {
         hipFree(st->d_status);
         st->d_status = nullptr;
         st->status_cap = 0;
-        RT_HIP(hipMalloc((void **)&st->d_status, (size_t)s->nsites * 4));
-        st->status_cap = s->nsites;
+        RT_HIP(hipMalloc((void **)&st->d_status, (size_t)status_need * 4));
+        st->status_cap = status_need;
     }
     if (recompute_transitions) RT_TRY(rt_model_recompute_transitions(m));
     RT_REQUIRE(m->have_P, "the model has no transition matrices yet");
     hipStream_t stream = ctx->stream;
-    hipLaunchKernelGGL(pack_pt_kernel, dim3(512), dim3(256), 0, stream, (int)n, NT, KP, st->nops,
-                       st->d_step_node, m->d_P, st->d_PT);
-    RT_HIP(hipGetLastError());
     int rc = RT_ERR_UNSUPPORTED;
+    rt_sites *x = nullptr;
+    if (lane) {
+        RT_HIP(hipMemsetAsync(st->d_status, 0, (size_t)status_need * 4, stream));
+        RT_TRY(rt_expect_lane_resident(m, s, st->d_W, st->d_status));
+        rc = RT_OK;
+    } else {
+        if (!s->expect_twin) RT_TRY(rt_sites_twin_interpreter(s, &s->expect_twin));
+        x = s->expect_twin;
+        hipLaunchKernelGGL(pack_pt_kernel, dim3(512), dim3(256), 0, stream, (int)n, NT, KP, st->nops,
+                           st->d_step_node, m->d_P, st->d_PT);
+        RT_HIP(hipGetLastError());
+    }
 #define RT_EX(NTV, KSV)                                                                            \
     rc = expect_device_passes<NTV, KSV>(ctx, m, x, st->d_PT, st->d_step_node, st->d_parent_step,   \
                                         st->d_internal, m->d_P, m->d_root, s->d_weights, st->d_W,  \
                                         st->d_status, st->d_rootpart, false)
+    if (!lane)
     switch (KS) {
+    case 2: RT_EX(1, 2); break;
     case 3: RT_EX(1, 3); break;
     case 4: RT_EX(1, 4); break;
     case 5: RT_EX(2, 5); break;

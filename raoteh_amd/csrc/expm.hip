@@ -588,22 +588,27 @@ __device__ __forceinline__ void mm_blocked(const double *X, const double *Y, dou
                     }
                 }
     }
-    double a0[RH], b0[RH];
+    double a0[RH], b0[RH], a1[RH], b1[RH];
 #pragma unroll
-    for (int u = 0; u < RH; ++u) { a0[u] = ap[u][0]; b0[u] = bp[u][0]; }
+    for (int u = 0; u < RH; ++u) {
+        a0[u] = ap[u][0];
+        b0[u] = bp[u][0];
+        a1[u] = ap[u][KS > 1 ? 4 : 0];
+        b1[u] = bp[u][KS > 1 ? 4 * LD : 0];
+    }
     for (int kk = 0; kk < KS; ++kk) {
-        // operands of the next k-step first (the last iteration re-reads its own)
-        const int kn = kk + 1 < KS ? kk + 1 : kk;
-        double a1[RH], b1[RH];
+        // operands two k-steps ahead (the last iterations re-read the last k-step's)
+        const int kn = kk + 2 < KS ? kk + 2 : KS - 1;
+        double a2[RH], b2[RH];
 #pragma unroll
-        for (int u = 0; u < RH; ++u) { a1[u] = ap[u][4 * kn]; b1[u] = bp[u][4 * kn * LD]; }
+        for (int u = 0; u < RH; ++u) { a2[u] = ap[u][4 * kn]; b2[u] = bp[u][4 * kn * LD]; }
 #pragma unroll
         for (int u = 0; u < RH; ++u)
 #pragma unroll
             for (int v = 0; v < RH; ++v)
                 acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[v], acc[u][v], 0, 0, 0);
 #pragma unroll
-        for (int u = 0; u < RH; ++u) { a0[u] = a1[u]; b0[u] = b1[u]; }
+        for (int u = 0; u < RH; ++u) { a0[u] = a1[u]; b0[u] = b1[u]; a1[u] = a2[u]; b1[u] = b2[u]; }
     }
     if (out) {
 #pragma unroll
@@ -689,13 +694,18 @@ __device__ __forceinline__ void mm_half(const double *X, const double *Y, double
             }
         }
     }
+    // operands two k-steps ahead (one wave per SIMD: nobody else hides the LDS latency, and a
+    // k-step is only two MFMAs long)
     double a0 = ap[0], b00 = bp[0], b01 = bp[16];
+    double a1 = ap[4], b10 = bp[4 * LD], b11 = bp[4 * LD + 16];
+#pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
-        const int kn = kk + 1 < KS ? kk + 1 : kk;
-        const double a1 = ap[4 * kn], b10 = bp[4 * kn * LD], b11 = bp[4 * kn * LD + 16];
+        const int kn = kk + 2 < KS ? kk + 2 : KS - 1;
+        const double a2 = ap[4 * kn], b20 = bp[4 * kn * LD], b21 = bp[4 * kn * LD + 16];
         acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b00, acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b01, acc[1], 0, 0, 0);
         a0 = a1; b00 = b10; b01 = b11;
+        a1 = a2; b10 = b20; b11 = b21;
     }
     __syncthreads();
 #pragma unroll

@@ -13,6 +13,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <memory>
 
 namespace {
 
@@ -1358,6 +1359,198 @@ int expectation_weights_lane(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t nsi
     }
     return RT_OK;
 }
+
+// ---- n <= 8 on a RESIDENT batch (rt_expect_step) -------------------------------------------
+// The same fused lane-per-site kernel, with everything it needs already on the device: the
+// transition matrices of the model (their zero patterns are read off by a kernel), the
+// allowed sets of the batch (built once per batch from its resident layout), the stack
+// program of the tree (once per model).
+
+struct expect_lane_state_t {
+    lane_plan lp;
+    bool p_in_lds = false;
+    int waves_per_group = 1;
+    size_t lds_bytes = 0;
+    int4 *d_ops = nullptr;
+    int *d_par = nullptr, *d_node_of_k = nullptr;
+    unsigned char *d_rb = nullptr, *d_cb = nullptr;
+    ~expect_lane_state_t()
+    {
+        hipFree(d_ops); hipFree(d_par); hipFree(d_rb); hipFree(d_cb);
+    }
+};
+
+// rowbits[v][a] bit b / colbits[v][b] bit a: P_v[a][b] > 0
+__global__ void __launch_bounds__(64)
+pattern_bits_kernel(int n, const double *__restrict__ esd, unsigned char *__restrict__ rowbits,
+                    unsigned char *__restrict__ colbits)
+{
+    const int v = blockIdx.x, t = threadIdx.x;
+    if (t >= n) return;
+    unsigned rb = 0, cb = 0;
+    if (v > 0)
+        for (int k = 0; k < n; ++k) {
+            if (esd[((size_t)v * n + t) * n + k] > 0.0) rb |= 1u << k;
+            if (esd[((size_t)v * n + k) * n + t] > 0.0) cb |= 1u << k;
+        }
+    rowbits[(size_t)v * n + t] = (unsigned char)rb;
+    colbits[(size_t)v * n + t] = (unsigned char)cb;
+}
+
+// allowed sets of the observed nodes from the lane family's resident layouts: dense
+// [block][k][pair][lane][2] (a state is allowed where its likelihood is not zero), or one
+// byte per leaf (compact == 1: a state, 255 = unobserved; compact == 2: the set itself)
+__global__ void __launch_bounds__(256)
+sets_from_lane_batch_kernel(int n, long nsites, long S, int K, int block_sites, int compact,
+                            const void *__restrict__ obs, const int *__restrict__ node_of_k,
+                            unsigned char *__restrict__ sets)
+{
+    const long total = nsites * K;
+    const unsigned full = (1u << n) - 1u;
+    const int hp = ((n + 1) & ~1) / 2, KQ = (K + 3) / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int k = (int)(i % K);
+        const long site = i / K;
+        const long blk = site / block_sites;
+        const int lane = (int)(site - blk * block_sites);
+        unsigned m = 0;
+        if (compact) {
+            const unsigned w = ((const unsigned *)obs)[((size_t)blk * KQ + (k >> 2)) * block_sites + lane];
+            const unsigned b = (w >> (8 * (k & 3))) & 255u;
+            m = compact == 2 ? (b & full) : (b >= (unsigned)n ? full : 1u << b);
+        } else {
+            const double *o = (const double *)obs + (((size_t)blk * K + k) * hp * block_sites + lane) * 2;
+            for (int st = 0; st < n; ++st)
+                if (o[(size_t)(st >> 1) * block_sites * 2 + (st & 1)] != 0.0) m |= 1u << st;
+        }
+        sets[(size_t)node_of_k[k] * S + site] = (unsigned char)m;
+    }
+}
+
+}  // namespace
+
+void rt_expect_lane_release(rt_model *m)
+{
+    if (!m || !m->expect_lane_state) return;
+    delete (expect_lane_state_t *)m->expect_lane_state;
+    m->expect_lane_state = nullptr;
+}
+
+// W f64[nnodes][n][n] (device; slot 0, column 0: the weighted root posterior sums) and the
+// per-site status for a resident lane-family batch; asynchronous on the context's stream
+int rt_expect_lane_resident(rt_model *m, rt_sites *s, double *d_W, int *d_status)
+{
+    rt_ctx *ctx = m->ctx;
+    const int64_t n = m->n, nnodes = m->nnodes, nsites = s->nsites;
+    RT_REQUIRE(n <= 8 && s->layout == RT_LAYOUT_LANE && !s->d_scratch,
+               "not a resident lane-family batch");
+    hipStream_t st = ctx->stream;
+    const size_t nn = (size_t)n * n, wcount = (size_t)nnodes * nn;
+    expect_lane_state_t *ls = (expect_lane_state_t *)m->expect_lane_state;
+    if (!ls) {
+        std::unique_ptr<expect_lane_state_t> fresh(new (std::nothrow) expect_lane_state_t());
+        if (!fresh) return RT_ERR_NOMEM;
+        if (!build_lane_plan(nnodes, m->indices.data(), m->indptr.data(), m->parent, fresh->lp)) {
+            rt_set_error("rt_expect_step: no LDS stack program for this tree");
+            return RT_ERR_UNSUPPORTED;
+        }
+        const size_t wave_bytes = (size_t)fresh->lp.nslots * n * 512 + (((size_t)nnodes * 64 + 15) & ~(size_t)15);
+        const size_t topo = (((size_t)nnodes * (16 + 4 + 2 * n)) + 15) & ~(size_t)15;
+        const size_t pbytes = ((size_t)nnodes * nn + 1) / 2 * 2 * 8;
+        const size_t cap = 160 * 1024;
+        if (topo + wave_bytes > cap) {
+            rt_set_error("rt_expect_step: the tree does not fit the LDS of the fused kernel");
+            return RT_ERR_UNSUPPORTED;
+        }
+        fresh->p_in_lds = topo + pbytes + wave_bytes <= cap && pbytes <= 64 * 1024;
+        const size_t shared = topo + (fresh->p_in_lds ? pbytes : 0);
+        int best = 1, best_resident = 0;
+        for (int w = 1; w <= 8; ++w) {
+            const size_t bytes = shared + w * wave_bytes;
+            if (bytes > cap) break;
+            const int resident = (int)(cap / bytes) * w;
+            if (resident > best_resident) { best_resident = resident; best = w; }
+        }
+        fresh->waves_per_group = best;
+        fresh->lds_bytes = shared + best * wave_bytes;
+        RT_HIP(hipMalloc((void **)&fresh->d_ops, (size_t)nnodes * 16));
+        RT_HIP(hipMalloc((void **)&fresh->d_par, (size_t)nnodes * 4));
+        RT_HIP(hipMalloc((void **)&fresh->d_rb, (size_t)nnodes * n));
+        RT_HIP(hipMalloc((void **)&fresh->d_cb, (size_t)nnodes * n));
+        std::vector<int> par(m->parent.begin(), m->parent.end());
+        par[0] = 0;
+        RT_HIP(hipMemcpy(fresh->d_ops, fresh->lp.ops.data(), (size_t)nnodes * 16, hipMemcpyHostToDevice));
+        RT_HIP(hipMemcpy(fresh->d_par, par.data(), (size_t)nnodes * 4, hipMemcpyHostToDevice));
+        m->expect_lane_state = fresh.release();
+        ls = (expect_lane_state_t *)m->expect_lane_state;
+    }
+    const long S = (long)((nsites + 63) / 64 * 64);
+    const int G = (int)(S / 64);
+    // the allowed sets of the batch, once
+    if (!s->d_sets) {
+        const int K = (int)s->nobs;
+        std::vector<int> node_of_k((size_t)std::max(K, 1), 0);
+        for (const rt_op &op : s->ops)
+            if (op.obs >= 0) node_of_k[(size_t)op.obs] = op.node;
+        int *d_nk = nullptr;
+        RT_HIP(hipMalloc((void **)&s->d_sets, (size_t)nnodes * S));
+        RT_HIP(hipMalloc((void **)&d_nk, node_of_k.size() * 4));
+        RT_HIP(hipMemcpyAsync(d_nk, node_of_k.data(), node_of_k.size() * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(sets_fill_kernel, dim3(2048), dim3(256), 0, st, (long)nnodes * S, (int)n,
+                           s->d_sets);
+        if (K > 0)
+            hipLaunchKernelGGL(sets_from_lane_batch_kernel, dim3(2048), dim3(256), 0, st, (int)n,
+                               (long)nsites, S, K, s->block_sites, s->compact_states,
+                               (const void *)s->d_obs, d_nk, s->d_sets);
+        RT_HIP(hipGetLastError());
+        RT_HIP(hipStreamSynchronize(st));
+        hipFree(d_nk);
+    }
+    const size_t arr = (size_t)nnodes * n * S * 8;
+    scratch_plan plan;
+    const size_t o_L = plan.take(arr), o_part = plan.take((size_t)G * wcount * 8);
+    RT_TRY(scratch_reserve(ctx, plan.total));
+    double *d_L = (double *)(ctx->d_scratch + o_L), *d_part = (double *)(ctx->d_scratch + o_part);
+    hipLaunchKernelGGL(pattern_bits_kernel, dim3((unsigned)nnodes), dim3(64), 0, st, (int)n, m->d_P,
+                       ls->d_rb, ls->d_cb);
+    const size_t lds_bytes = ls->lds_bytes;
+    const int wpg = ls->waves_per_group;
+#define RT_EXPECT_RES_ONE(NV, PL)                                                            \
+    do {                                                                                      \
+        if (lds_bytes > 64 * 1024)                                                            \
+            RT_HIP(hipFuncSetAttribute((const void *)expect_lane_lds_kernel<NV, PL>,          \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,            \
+                                       (int)lds_bytes));                                      \
+        hipLaunchKernelGGL((expect_lane_lds_kernel<NV, PL>), dim3((unsigned)((G + wpg - 1) / wpg)), \
+                           dim3(64 * wpg), lds_bytes, st, (int)nnodes, (long)nsites, S,       \
+                           ls->lp.nslots, ls->d_ops, ls->d_par, m->d_P, ls->d_rb, ls->d_cb,   \
+                           m->d_root, s->d_weights, s->d_sets, d_L, d_part, d_status,         \
+                           (unsigned long long *)nullptr);                                    \
+    } while (0)
+#define RT_EXPECT_RES(NV)                                                                    \
+    do {                                                                                      \
+        if (ls->p_in_lds) RT_EXPECT_RES_ONE(NV, true);                                        \
+        else RT_EXPECT_RES_ONE(NV, false);                                                    \
+    } while (0)
+    switch ((int)n) {
+    case 1: RT_EXPECT_RES(1); break;
+    case 2: RT_EXPECT_RES(2); break;
+    case 3: RT_EXPECT_RES(3); break;
+    case 4: RT_EXPECT_RES(4); break;
+    case 5: RT_EXPECT_RES(5); break;
+    case 6: RT_EXPECT_RES(6); break;
+    case 7: RT_EXPECT_RES(7); break;
+    default: RT_EXPECT_RES(8); break;
+    }
+#undef RT_EXPECT_RES
+#undef RT_EXPECT_RES_ONE
+    hipLaunchKernelGGL(sum_parts_wide_kernel, dim3((unsigned)((wcount + 3) / 4)), dim3(256), 0, st, G,
+                       (long)wcount, d_part, d_W);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
+namespace {
 
 int expectation_weights_impl(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t nsites,
         const int64_t *idx, const int64_t *ptr, const double *esd, const double *root_distn,

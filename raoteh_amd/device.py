@@ -589,7 +589,8 @@ class TreeModel(object):
         """rt_expect_step: the reference's get_expected_history_statistics
         (_mjp_dense.py:410-539) summed over the resident batch -- (dwell f64[n], summed
         root posteriors f64[n], transitions f64[n, n]) -- with nothing but those numbers
-        crossing PCIe.  Rates must have been set with set_rates; 8 < nstates <= 64."""
+        crossing PCIe.  Rates must have been set with set_rates; nstates <= 64 (for
+        nstates <= 4 a dense batch is read as allowed sets: likelihood != 0)."""
         n = self.nstates
         dwell = np.empty(n)
         rootp = np.empty(n)

@@ -1163,7 +1163,7 @@ def test_expected_history_statistics_codon_model(ra):
     np.testing.assert_allclose(bt, ref_t, rtol=1e-9, atol=1e-13)
 
 
-@pytest.mark.parametrize('n', [9, 20, 31, 40, 61, 64])
+@pytest.mark.parametrize('n', [2, 4, 5, 8, 9, 20, 31, 40, 61, 64])
 def test_resident_expectation_step_matches_the_reference_shaped_path(ra, n):
     """rt_expect_step on an uploaded batch (nothing marshalled per call) against
     get_expected_history_statistics_batch -- the reference-shaped path that is pinned to the
@@ -1212,7 +1212,8 @@ def test_resident_expectation_step_matches_the_reference_shaped_path(ra, n):
             finally:
                 ra.lib.check(ra.lib.lib().rt_set_option(b'jit', -1))
             ll, _ = model.log_likelihoods(batch)
-            assert batch.kernel_name.startswith('prune_tree_jit' if jit else 'prune_mfma')
+            assert batch.kernel_name.startswith('prune_tree_jit' if jit else
+                                                ('prune_lane' if n <= 4 else 'prune_mfma'))
             dwell, rootp, trans, status = model.expected_history_statistics(
                 batch, return_status=True)
             assert not status.any()
@@ -1241,13 +1242,14 @@ def test_resident_expectation_step_matches_the_reference_shaped_path(ra, n):
     b2 = model.upload_sites(leaves, bad, kind='dense')
     out = model.expected_history_statistics(b2, return_status=True)
     assert out[3][0] == 2
-    if n <= 8 + 1:
-        T, root, leaves = ra.synth.random_tree(23, seed=n, max_children=3)
-        m4 = ra.device.TreeModel(T, root, 4)
-        m4.set_rates(Q_default=ra.synth.hky85()[0])
-        b4 = m4.upload_sites(leaves, np.zeros((3, len(leaves)), dtype=np.uint8), kind='state')
-        with pytest.raises(ra.lib.RaotehHipError):
-            m4.expected_history_statistics(b4)
+    # the generic fallback layout is not resident in a form the passes read
+    ra.lib.check(ra.lib.lib().rt_set_option(b'force_generic', 1))
+    try:
+        bg = model.upload_sites(leaves, dense, kind='dense')
+    finally:
+        ra.lib.check(ra.lib.lib().rt_set_option(b'force_generic', 0))
+    with pytest.raises(ra.lib.RaotehHipError):
+        model.expected_history_statistics(bg)
 
 
 def test_expected_history_statistics_batch(ra):
