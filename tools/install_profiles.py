@@ -8,7 +8,7 @@ import shutil
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
-for w in ('c2', 'c3', 'c5'):
+for w in ('c2', 'c3', 'c5', 'c6'):
     base = os.path.join('gpurun_out', 'prof_' + w)
     summ = os.path.join(base, 'summary.json')
     if not os.path.exists(summ):
