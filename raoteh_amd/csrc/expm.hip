@@ -602,11 +602,13 @@ __device__ __forceinline__ void mm_blocked(const double *X, const double *Y, dou
         double a2[RH], b2[RH];
 #pragma unroll
         for (int u = 0; u < RH; ++u) { a2[u] = ap[u][4 * kn]; b2[u] = bp[u][4 * kn * LD]; }
+        __builtin_amdgcn_sched_barrier(0);      // the reads stay ahead of the MFMAs (see mm_half)
 #pragma unroll
         for (int u = 0; u < RH; ++u)
 #pragma unroll
             for (int v = 0; v < RH; ++v)
                 acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[v], acc[u][v], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < RH; ++u) { a0[u] = a1[u]; b0[u] = b1[u]; a1[u] = a2[u]; b1[u] = b2[u]; }
     }
@@ -666,12 +668,18 @@ __device__ __forceinline__ void load_half_tiles(const double *M, half_tiles &t, 
             t.v[v][r] = M[(16 * wave + 4 * r + lq) * LD + 16 * (2 * h + v) + lr];
 }
 
+// (RAOTEH_EXPM_TRACE: finer stamps of one Horner half product, slots 8..13)
+__device__ unsigned long long rt_expm_fine[8];
+#define RT_FINE(k) if (fine && threadIdx.x == 0) rt_expm_fine[k] = __builtin_readcyclecounter()
+
 // C[:, half h] = X * Y[:, half h] + cf0 I + cf1 R1 + cf2 R2 (64 x 64 matrices, LD 65);
 // C may alias Y
 __device__ __forceinline__ void mm_half(const double *X, const double *Y, double *C,
-                                        const double *cf, const half_tiles &R1,
-                                        const half_tiles &R2, int h)
+                                        double c0, double c1, double c2, double nd,
+                                        const half_tiles &R1, const half_tiles &R2, int h,
+                                        bool fine = false)
 {
+    RT_FINE(0);
     constexpr int LD = 65, KS = 16;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // row tile
@@ -679,42 +687,51 @@ __device__ __forceinline__ void mm_half(const double *X, const double *Y, double
     double4_t acc[2];
     const double *ap = X + (16 * wave + lr) * LD + lq;
     const double *bp = Y + lq * LD + 32 * h + lr;
-    {
-        const double c0 = cf[0], c1 = cf[1], c2 = cf[2];
-#pragma unroll
-        for (int v = 0; v < 2; ++v) {
-            const int col = 16 * (2 * h + v) + lr;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * wave + 4 * r + lq;
-                double w = c1 * R1.v[v][r];
-                w += c2 * R2.v[v][r];
-                if (row == col && (double)row < cf[3]) w += c0;
-                acc[v][r] = w;
-            }
-        }
-    }
     // operands two k-steps ahead (one wave per SIMD: nobody else hides the LDS latency, and a
-    // k-step is only two MFMAs long)
+    // k-step is only two MFMAs long); the first ones are requested before the accumulators are
+    // seeded, and the coefficients of the step arrive in registers (read from LDS here, four
+    // dependent-looking reads stood in front of the first MFMA: 1 200-1 500 clocks of a half
+    // product's 4 700, fine stamps of RAOTEH_EXPM_TRACE)
     double a0 = ap[0], b00 = bp[0], b01 = bp[16];
     double a1 = ap[4], b10 = bp[4 * LD], b11 = bp[4 * LD + 16];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        const int col = 16 * (2 * h + v) + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * wave + 4 * r + lq;
+            double w = c1 * R1.v[v][r];
+            w += c2 * R2.v[v][r];
+            if (row == col && (double)row < nd) w += c0;
+            acc[v][r] = w;
+        }
+    }
+    RT_FINE(1);
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
         const int kn = kk + 2 < KS ? kk + 2 : KS - 1;
         const double a2 = ap[4 * kn], b20 = bp[4 * kn * LD], b21 = bp[4 * kn * LD + 16];
+        // (pinned: left alone the scheduler sinks every operand read to just before its MFMA
+        // and waits for it in full -- read, wait, two MFMAs, read, wait: 103 clocks per MFMA)
+        __builtin_amdgcn_sched_barrier(0);
         acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b00, acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b01, acc[1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         a0 = a1; b00 = b10; b01 = b11;
         a1 = a2; b10 = b20; b11 = b21;
     }
+    RT_FINE(2);
     __syncthreads();
+    RT_FINE(3);
 #pragma unroll
     for (int v = 0; v < 2; ++v) {
         const int col = 16 * (2 * h + v) + lr;
 #pragma unroll
         for (int r = 0; r < 4; ++r) C[(16 * wave + 4 * r + lq) * LD + col] = acc[v][r];
     }
+    RT_FINE(4);
     __syncthreads();
+    RT_FINE(5);
 }
 
 // GLOBAL = false: the four matrices in LDS (n <= 64); true: in scratch[blockIdx] (n <= 128)
@@ -919,8 +936,19 @@ expm_taylor_kernel(int n, const double *__restrict__ Q, const int *__restrict__ 
             half_tiles ha, ha2;
             load_half_tiles(B0, ha, half);
             load_half_tiles(B1, ha2, half);
-            for (int jj = q - 2; jj >= 0; --jj)
-                mm_half(B2, B3, B3, cfs_all[jj], ha, ha2, half);   // T[:, half] = A^3 T[:, half] + B_j
+            // (the coefficients of all four possible steps in registers: block-uniform loads
+            // from constant memory, long before they are needed)
+            double hc[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 3; ++e) hc[u][e] = c_inv_fact[3 * u + e];
+            const double nd = (double)n;
+#pragma unroll
+            for (int u = 3; u >= 0; --u)
+                if (u <= q - 2)            // T[:, half] = A^3 T[:, half] + B_u
+                    mm_half(B2, B3, B3, hc[u][0], hc[u][1], hc[u][2], nd, ha, ha2, half,
+                            trace_on && blockIdx.x == 2 && u == 0);
         }
     } else {
         for (int jj = q - 2; jj >= 0; --jj)
@@ -1367,6 +1395,11 @@ int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
             RT_HIP(hipStreamSynchronize(ctx->stream));
             if (armed) {
                 RT_HIP(hipMemcpyFromSymbol(tr, HIP_SYMBOL(rt_expm_trace), sizeof tr));
+                unsigned long long fn[8];
+                RT_HIP(hipMemcpyFromSymbol(fn, HIP_SYMBOL(rt_expm_fine), sizeof fn));
+                fprintf(stderr, "[raoteh_amd] last Horner half product: seed + first operands %llu, k loop "
+                        "%llu, barrier %llu, write-back %llu, barrier %llu\n", fn[1] - fn[0],
+                        fn[2] - fn[1], fn[3] - fn[2], fn[4] - fn[3], fn[5] - fn[4]);
                 fprintf(stderr, "[raoteh_amd] expm trace (clocks, workgroup 1): load + norm %llu, order %llu, "
                         "A^2 A^3 %llu, block %llu, Horner %llu, squarings %llu, store %llu; total %llu\n",
                         tr[1] - tr[0], tr[2] - tr[1], tr[3] - tr[2], tr[4] - tr[3], tr[5] - tr[4],

@@ -30,7 +30,8 @@ def main():
     cases = 0
     worst = 0.0
     while time.time() - t0 < budget:
-        n = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 12, 16, 17, 20, 31, 32, 33, 40, 48, 61, 64]))
+        n = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 12, 16, 17, 20, 31, 32, 33, 40, 48, 61, 64,
+                            65, 80, 97, 112, 122, 128]))
         nnodes = int(rng.randint(2, 70))
         nsites = int(rng.choice([1, 15, 16, 17, 63, 64, 65, 200, 1000, 3000]))
         T, root, leaves = synth.random_tree(nnodes, seed=int(rng.randint(1 << 30)),
@@ -98,6 +99,8 @@ def main():
                 os.environ['RAOTEH_JIT_TILES'] = str(tiles)
                 if halves:
                     os.environ['RAOTEH_JIT_HALVES'] = halves
+                    # (the combine step folded into the pruning kernel for every other cut)
+                    os.environ['RAOTEH_JIT_FOLD'] = '1' if (cases + tiles) % 2 else '0'
                 _lib.check(set_option(b'jit_block_sites', bs if n <= 4 else 0))
             try:
                 if jit and states is not None:
@@ -112,6 +115,7 @@ def main():
                 _lib.check(set_option(b'jit_block_sites', 0))
                 os.environ.pop('RAOTEH_JIT_TILES', None)
                 os.environ.pop('RAOTEH_JIT_HALVES', None)
+                os.environ.pop('RAOTEH_JIT_FOLD', None)
         ref = out[0]
         if only is not None:
             ok = wst == 0
