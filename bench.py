@@ -567,9 +567,27 @@ def measure_next_rows(ctx):
         batch.sweep(20)
         rows = batch.sizes()[0]
         dt = (time.perf_counter() - t0) / 20
+        # bytes a sweep has to move (csrc/forest.hip; R rows before the split, R' = R + events
+        # after it, K chunk-tree nodes, n states): count reads (len, state) and writes the
+        # 16-bit counts; split reads the rows and the counts and writes (edge, len, chunk) of
+        # the new rows and (parent, set) of the chunks; the forest passes read / write the
+        # sets twice and write + read the messages (n doubles per chunk node) and the sampled
+        # states; merge reads the new rows + chunk states and writes (edge, len, state)
+        R = rows
+        sizes = batch.sizes()
+        K = sizes[1]
+        Rn = K + 100000 * (len(index) - 2)
+        sweep_bytes = (12 + 2) * R + (16 + 2) * R + 16 * Rn + 12 * K + 4 * 8 * K + \
+            3 * 8 * n * K + 4 * K + (16 + 4) * Rn + 4 * K + 16 * R
         out['rao_teh_sweep_c2'] = dict(
             chains=100000, ms_per_sweep=dt * 1e3, chain_sweeps_per_s=100000 / dt,
-            segments_per_chain=rows / 100000.0,
+            segments_per_chain=rows / 100000.0, chunk_nodes_per_chain=K / 100000.0,
+            roofline=dict(bound='hbm', achieved=sweep_bytes / dt / 1e9, peak=HBM_PEAK_GBS,
+                          unit='GB/s', frac=sweep_bytes / dt / 1e9 / HBM_PEAK_GBS,
+                          algorithmic_bytes_per_sweep=sweep_bytes,
+                          note='seven kernels per sweep (count, scan, split, sets, pmap, sample, '
+                               'merge), one wave per chain: latency- and launch-bound, not '
+                               'HBM-bound'),
             what='one Rao-Teh sweep of every chain, histories resident on the device')
         # the reference's optional spectral path (examples/p53/qtop.py): the decomposition of
         # the one reversible rate matrix is the caller's, once per matrix; a step rebuilds all

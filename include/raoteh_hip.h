@@ -304,7 +304,7 @@ int rt_build_schedule(int64_t nnodes, const int64_t *tree_csr_indices,
  * 64); automatic = batches of at least 65 536 / n sites.  Results are
  * bit-identical with and without it.  "jit_block_sites" (0 automatic, 1..64):
  * sites per wave of those kernels (automatic balances the waves over the CUs). */
-/* "jit_async" (1 default / 0): for n > 4, rt_sites_create does not wait for hiprtc -- a host
+/* "jit_async" (1 default / 0): rt_sites_create does not wait for hiprtc -- a host
  * thread of this process compiles the kernel (or loads its code object from the persistent
  * cache directory: RAOTEH_JIT_CACHE_DIR, default ~/.cache/raoteh_amd/jit; RAOTEH_JIT_CACHE=0
  * disables it) while the batch runs the interpreter kernel; a later rt_prune / rt_step swaps

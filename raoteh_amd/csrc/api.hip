@@ -809,6 +809,8 @@ extern "C" int rt_sites_destroy(rt_sites *s)
     if (s->expect_twin) rt_sites_destroy(s->expect_twin);
     hipFree(s->d_weights);
     hipFree(s->d_sets);
+    hipFree(s->d_raw);
+    hipFree(s->d_raw_src);
     if (!s->obs_borrowed) hipFree(s->d_obs);
     hipFree(s->d_ops); hipFree(s->d_lane_ops); hipFree(s->d_lane_ops_a); hipFree(s->d_lane_ops_b); hipFree(s->d_loglik); hipFree(s->d_status);
     if (s->model->ctx->comm_stream) hipStreamSynchronize(s->model->ctx->comm_stream);
@@ -916,7 +918,8 @@ static int program_stack_slots(const std::vector<int32_t> &prog, int64_t slot_by
 
 static bool want_root_halves(const rt_sites *s, int64_t ntiles);
 
-static int sites_alloc(rt_sites *s, bool generic)
+// sizes of the resident layout (blocks, bytes, partial sums) -> *padded = sites incl. padding
+static void sites_layout_sizes(rt_sites *s, int64_t *padded_out)
 {
     rt_model *m = s->model;
     const int64_t n = m->n;
@@ -943,6 +946,15 @@ static int sites_alloc(rt_sites *s, bool generic)
         s->npartials = s->mfma_solo ? (s->nblocks + 3) / 4 * 4
                                     : (s->nblocks + tiles - 1) / tiles * waves;
     }
+    *padded_out = padded;
+}
+
+static int sites_alloc(rt_sites *s, bool generic)
+{
+    rt_model *m = s->model;
+    const int64_t n = m->n;
+    int64_t padded = 0;
+    sites_layout_sizes(s, &padded);
     hipError_t e = hipMalloc((void **)&s->d_ops, s->ops.size() * sizeof(rt_op));
     if (e == hipSuccess && !s->obs_borrowed)
         e = hipMalloc((void **)&s->d_obs, std::max<int64_t>(s->obs_bytes, 1024));
@@ -1378,6 +1390,22 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
         rt_jit_lane_source(s->ops, (int)s->model->n, (int)s->nobs, D, LA, S, WG, states, fuse);
     s->jit_prefetch = D;
     s->jit_lookahead = LA;
+    // not in this context's cache yet: compile in the background; the batch is created in the
+    // interpreter's layout, keeps the caller's observations on the device and is packed again
+    // for the kernel when it arrives (rt_sites_jit_poll)
+    if (!forced && opt_jit_async(s->model->ctx) && rt_jit_cached(s->model->ctx, src) == 0) {
+        s->jit_lane.S = S;
+        s->jit_lane.WG = WG;
+        s->jit_lane.D = D;
+        s->jit_lane.LA = LA;
+        s->jit_lane.compact = states;
+        s->jit_lane.fuse = fuse;
+        s->jit_srcs.assign(1, src);
+        s->jit_cands.assign(1, rt_sites::jit_cand{1, false, false});
+        s->jit_job = rt_jit_start(s->model->ctx, std::vector<std::string>(1, src), false);
+        s->keep_raw = true;
+        return RT_OK;
+    }
     const int rc = rt_jit_get(s->model->ctx, src, &s->jit_fn, false, &s->jit_compile_s);
     if (rc != RT_OK && (!forced || rc == RT_ERR_UNSUPPORTED)) {
         // the interpreter kernel (prune.hip) computes the same numbers;
@@ -1685,6 +1713,93 @@ static int verify_jit_kernel(rt_sites *s, int kind)
     return rc;
 }
 
+static void sites_drop_raw(rt_sites *s)
+{
+    hipFree(s->d_raw);
+    hipFree(s->d_raw_src);
+    s->d_raw = nullptr;
+    s->d_raw_src = nullptr;
+    s->keep_raw = false;
+}
+
+// Lane family: the kernel is there.  Verify it (the probe batches take the kernel's parameters
+// from the batch), then move the batch to the kernel's resident layout: new block size /
+// compact encoding, the observations packed again from the retained device copy.
+static int sites_lane_switch(rt_sites *s, const std::string &src)
+{
+    rt_model *m = s->model;
+    rt_ctx *ctx = m->ctx;
+    void *fn = nullptr;
+    if (rt_jit_get(ctx, src, &fn, false, nullptr) != RT_OK) {
+        sites_drop_raw(s);
+        return RT_OK;
+    }
+    const int old_S = s->block_sites, old_waves = s->jit_waves, old_compact = s->compact_states;
+    const int old_D = s->jit_prefetch, old_LA = s->jit_lookahead;
+    s->jit_fn = fn;
+    s->block_sites = s->jit_lane.S;
+    s->jit_waves = s->jit_lane.WG;
+    s->compact_states = s->jit_lane.compact;
+    s->jit_fused = s->jit_lane.fuse;
+    s->jit_prefetch = s->jit_lane.D;
+    s->jit_lookahead = s->jit_lane.LA;
+    int rc = RT_OK;
+    if (!rt_jit_verified(ctx, fn) && !getenv("RAOTEH_JIT_NO_VERIFY")) {
+        rc = verify_jit_kernel(s, s->jit_kind);
+        rt_jit_set_verified(ctx, fn, rc == RT_OK);
+    }
+    if (rc == RT_OK && ctx->pending_reduce == s) rc = rt_flush_reduce(ctx);
+    if (rc == RT_OK) rc = hipStreamSynchronize(ctx->stream) == hipSuccess ? RT_OK : RT_ERR_HIP;
+    double *n_obs = nullptr, *n_ll = nullptr, *n_part = nullptr, *n_alt = nullptr;
+    int32_t *n_st = nullptr;
+    int64_t padded = 0;
+    const int64_t old_nblocks = s->nblocks, old_bytes = s->obs_bytes, old_np = s->npartials;
+    if (rc == RT_OK) {
+        sites_layout_sizes(s, &padded);
+        hipError_t e = hipMalloc((void **)&n_obs, std::max<int64_t>(s->obs_bytes, 1024));
+        if (e == hipSuccess) e = hipMalloc((void **)&n_ll, padded * 8);
+        if (e == hipSuccess) e = hipMalloc((void **)&n_st, padded * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&n_part, s->npartials * 16);
+        if (e == hipSuccess) e = hipMemset(n_part, 0, s->npartials * 16);
+        if (e == hipSuccess && s->jit_fused) {
+            e = hipMalloc((void **)&n_alt, s->npartials * 16);
+            if (e == hipSuccess) e = hipMemset(n_alt, 0, s->npartials * 16);
+        }
+        if (e != hipSuccess) rc = RT_ERR_NOMEM;
+    }
+    if (rc == RT_OK) {
+        std::swap(s->d_obs, n_obs);
+        rc = rt_sites_pack_device(s, s->jit_kind, s->d_raw, s->d_raw_src);
+        if (rc == RT_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = RT_ERR_HIP;
+        if (rc != RT_OK) std::swap(s->d_obs, n_obs);
+    }
+    if (rc != RT_OK) {
+        // stay on the interpreter kernel and its layout
+        hipFree(n_obs); hipFree(n_ll); hipFree(n_st); hipFree(n_part); hipFree(n_alt);
+        rt_jit_ref(ctx, fn, -1);
+        s->jit_fn = nullptr;
+        s->block_sites = old_S;
+        s->jit_waves = old_waves;
+        s->compact_states = old_compact;
+        s->jit_fused = false;
+        s->jit_prefetch = old_D;
+        s->jit_lookahead = old_LA;
+        s->nblocks = old_nblocks;
+        s->obs_bytes = old_bytes;
+        s->npartials = old_np;
+        sites_drop_raw(s);
+        return RT_OK;
+    }
+    hipFree(n_obs);                          // (the interpreter's image, after the swap above)
+    hipFree(s->d_loglik); hipFree(s->d_status); hipFree(s->d_partial); hipFree(s->d_partial_alt);
+    s->d_loglik = n_ll;
+    s->d_status = n_st;
+    s->d_partial = n_part;
+    s->d_partial_alt = n_alt;
+    sites_drop_raw(s);
+    return RT_OK;
+}
+
 // The background job of this batch is done (or `wait`: join it): take the kernel it left in
 // the context's cache, verify it on a probe batch if nobody has yet, and from the next launch
 // on the batch runs it.  Any failure leaves the batch on the interpreter kernel.
@@ -1705,10 +1820,12 @@ int rt_sites_jit_poll(rt_sites *s, bool wait)
     srcs.swap(s->jit_srcs);
     if (rc != RT_OK || chosen < 0 || chosen >= (int)cands.size()) {
         rt_set_error("background compile: %s", err.c_str());
+        sites_drop_raw(s);
         return RT_OK;
     }
     rt_model *m = s->model;
     RT_HIP(hipSetDevice(m->ctx->device));
+    if (s->layout == RT_LAYOUT_LANE) return sites_lane_switch(s, srcs[(size_t)chosen]);
     void *fn = nullptr;
     if (rt_jit_get(m->ctx, srcs[(size_t)chosen], &fn, true, nullptr) != RT_OK) return RT_OK;
     const rt_sites::jit_cand c = cands[(size_t)chosen];
@@ -1760,6 +1877,9 @@ extern "C" int rt_sites_clone(rt_sites *src, rt_sites **out)
     RT_REQUIRE(src && out, "null pointer");
     *out = nullptr;
     RT_HIP(hipSetDevice(src->model->ctx->device));
+    // (a lane-family batch changes its resident layout when its kernel arrives: wait for it
+    // rather than cloning the image it is about to leave)
+    if (src->jit_job && src->layout == RT_LAYOUT_LANE) RT_TRY(rt_sites_jit_poll(src, true));
     rt_sites *s = new (std::nothrow) rt_sites();
     if (!s) return RT_ERR_NOMEM;
     s->model = src->model;

@@ -248,6 +248,13 @@ struct rt_sites {
     std::vector<jit_cand> jit_cands;        // what each candidate source of the job was built with
     std::vector<std::string> jit_srcs;
     int jit_kind = 0;                       // observation kind of the batch (probe batches)
+    // lane family (n <= 4): the kernel's resident layout differs from the interpreter's, so
+    // while the job runs the batch keeps the caller's observations on the device (d_raw, in
+    // the caller's format) and packs them again at the switch; what the kernel was built for:
+    bool keep_raw = false;
+    void *d_raw = nullptr;
+    int *d_raw_src = nullptr;
+    struct { int S = 64, WG = 1, D = 1, LA = 1, compact = 0; bool fuse = false; } jit_lane;
     // rt_expect_step: per-site multiplicities on the device (null: ones), and the batch's
     // split-M interpreter twin -- its own program, partial sums and per-site outputs over the
     // SAME resident observations (obs_borrowed: d_obs belongs to the batch it was made from)
@@ -377,6 +384,7 @@ int rt_expectation_weights_mfma(rt_ctx *ctx, int64_t nnodes, int64_t n, int64_t 
                                 double *edge_weights, int32_t *status);
 int rt_sites_pack(rt_sites *s, int kind, const int64_t *obs_order,
                   const void *data);
+int rt_sites_pack_device(rt_sites *s, int kind, const void *d_in, const int *d_src);
 
 static inline int64_t rt_round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 // doubles per step of the quad-block table (rt_model::d_Pquad): ceil(n/4)^2 blocks of 16,

@@ -1347,26 +1347,14 @@ int rt_launch_pfrag(rt_model *m)
     return RT_OK;
 }
 
-int rt_sites_pack(rt_sites *s, int kind, const int64_t *src_of_k, const void *data)
+// the user's observations (already on the device) -> the batch's resident layout
+int rt_sites_pack_device(rt_sites *s, int kind, const void *d_in, const int *d_src)
 {
     rt_model *m = s->model;
     hipStream_t st = m->ctx->stream;
     const int n = (int)m->n;
     const int K = (int)s->nobs;
-    size_t in_bytes;
-    if (kind == RT_OBS_DENSE) in_bytes = (size_t)s->nsites * K * n * 8;
-    else if (kind == RT_OBS_STATE) in_bytes = (size_t)s->nsites * K;
-    else in_bytes = (size_t)s->nsites * K * 8 * (size_t)((n + 63) / 64);
-    void *d_in = nullptr;
-    int *d_src = nullptr;
-    std::vector<int> src(K);
-    for (int k = 0; k < K; ++k) src[k] = (int)src_of_k[k];
     if (K > 0) {
-        RT_HIP(hipMalloc(&d_in, in_bytes));
-        RT_HIP(hipMalloc((void **)&d_src, sizeof(int) * K));
-        RT_HIP(hipMemcpyAsync(d_in, data, in_bytes, hipMemcpyHostToDevice, st));
-        RT_HIP(hipMemcpyAsync(d_src, src.data(), sizeof(int) * K,
-                              hipMemcpyHostToDevice, st));
         const size_t total = (size_t)s->obs_bytes / 8;
         size_t blocks = (total + 255) / 256;
         if (blocks > 65536) blocks = 65536;
@@ -1390,9 +1378,43 @@ int rt_sites_pack(rt_sites *s, int kind, const int64_t *src_of_k, const void *da
                                KP, s->d_obs, total);
         }
         RT_HIP(hipGetLastError());
+    }
+    return RT_OK;
+}
+
+int rt_sites_pack(rt_sites *s, int kind, const int64_t *src_of_k, const void *data)
+{
+    rt_model *m = s->model;
+    hipStream_t st = m->ctx->stream;
+    const int n = (int)m->n;
+    const int K = (int)s->nobs;
+    size_t in_bytes;
+    if (kind == RT_OBS_DENSE) in_bytes = (size_t)s->nsites * K * n * 8;
+    else if (kind == RT_OBS_STATE) in_bytes = (size_t)s->nsites * K;
+    else in_bytes = (size_t)s->nsites * K * 8 * (size_t)((n + 63) / 64);
+    void *d_in = nullptr;
+    int *d_src = nullptr;
+    std::vector<int> src(K);
+    for (int k = 0; k < K; ++k) src[k] = (int)src_of_k[k];
+    if (K > 0) {
+        RT_HIP(hipMalloc(&d_in, in_bytes));
+        RT_HIP(hipMalloc((void **)&d_src, sizeof(int) * K));
+        RT_HIP(hipMemcpyAsync(d_in, data, in_bytes, hipMemcpyHostToDevice, st));
+        RT_HIP(hipMemcpyAsync(d_src, src.data(), sizeof(int) * K,
+                              hipMemcpyHostToDevice, st));
+        const int rc = rt_sites_pack_device(s, kind, d_in, d_src);
         RT_HIP(hipStreamSynchronize(st));
-        RT_HIP(hipFree(d_in));
-        RT_HIP(hipFree(d_src));
+        if (rc == RT_OK && s->keep_raw) {
+            // a lane-family batch whose tree-specialised kernel is still compiling: the
+            // kernel's resident layout differs (sites per wave, compact states), so the
+            // observations are packed again when it arrives (rt_sites_jit_poll)
+            s->d_raw = d_in;
+            s->d_raw_src = d_src;
+        } else {
+            RT_HIP(hipFree(d_in));
+            RT_HIP(hipFree(d_src));
+        }
+        return rc;
     }
     return RT_OK;
 }

@@ -1902,6 +1902,65 @@ def test_background_compile_and_persistent_code_object_cache(ra, tmp_path, monke
               % (n, create_s, cold, warm))
         ctx2.close()
         ctx.close()
+    # the lane family (n <= 4): the kernel's resident layout differs from the interpreter's
+    # (sites per wave, one byte per observed state), so the batch keeps the caller's
+    # observations on the device and is packed again when the kernel arrives
+    for n, kind in ((4, 'state'), (3, 'dense'), (4, 'mask')):
+        nsites = 30000
+        T, root, obs_nodes, w = _random_case(ra, rng, n, 41, nsites)
+        pre, idx, ptr, esd = orc.get_esd_transitions(T, root, n)
+        states = rng.randint(0, n, size=(nsites, len(obs_nodes))).astype(np.uint8)
+        states[rng.uniform(size=states.shape) < 0.2] = 255
+        dense = np.ones((nsites, len(obs_nodes), n))
+        seen = states != 255
+        dense[seen] = 0.0
+        ii, kk = np.nonzero(seen)
+        dense[ii, kk, states[ii, kk]] = 1.0
+        masks = np.zeros((nsites, len(obs_nodes)), dtype=np.uint64)
+        for sidx in range(n):
+            masks |= dense[..., sidx].astype(np.uint64) << np.uint64(sidx)
+        data = {'state': states, 'dense': dense, 'mask': masks}[kind]
+        ctx = ra.device.Context(0)
+        ctx.set_option('jit_async', 1)
+        model = ra.device.TreeModel(T, root, n, ctx=ctx)
+        model.set_transitions(esd)
+        model.set_root_distn(w)
+        batch = model.upload_sites(obs_nodes, data, kind=kind)
+        bytes0 = batch.device_bytes
+        ll0, st0 = model.log_likelihoods(batch)
+        first = batch.kernel_name
+        batch.wait_for_kernel()
+        ll1, st1 = model.log_likelihoods(batch)
+        assert batch.kernel_name.startswith('prune_tree_jit<%d' % n), batch.kernel_name
+        assert first.startswith(('prune_lane', 'prune_tree_jit')), first
+        np.testing.assert_array_equal(ll0, ll1)
+        np.testing.assert_array_equal(st0, st1)
+        if kind != 'dense':
+            assert batch.device_bytes < bytes0 / 8          # one byte per leaf now
+            assert 'states' in batch.kernel_name or 'masks' in batch.kernel_name
+        twin = batch.clone()
+        ll2, _ = model.log_likelihoods(twin)
+        np.testing.assert_array_equal(ll0, ll2)
+        want, wst = orc.batch_log_likelihoods(idx, ptr, esd, [pre.index(v) for v in obs_nodes],
+                                              dense[:200], w)
+        np.testing.assert_allclose(ll1[:200][wst == 0], want[wst == 0], rtol=RTOL_LL)
+        tot = model.fetch_totals(batch)
+        ok = np.isfinite(ll1)
+        assert tot[2] == nsites and tot[0] == pytest.approx(ll1[ok].sum(), rel=1e-12)
+        # the expectation step works on the switched batch too
+        if kind == 'state':
+            Q = rng.exponential(size=(n, n))
+            np.fill_diagonal(Q, 0.0)
+            Q -= np.diag(Q.sum(axis=1))
+            model.set_rates(Q_default=Q)
+            d1 = model.expected_history_statistics(batch)
+            ctx.set_option('jit', 0)
+            plain = model.upload_sites(obs_nodes, data, kind=kind)
+            ctx.set_option('jit', None)
+            d2 = model.expected_history_statistics(plain)
+            for a, b in zip(d1, d2):
+                np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-14)
+        ctx.close()
     # RAOTEH_JIT_CACHE=0: nothing is read or written
     monkeypatch.setenv('RAOTEH_JIT_CACHE', '0')
     monkeypatch.setenv('RAOTEH_JIT_CACHE_DIR', str(tmp_path / 'off'))
