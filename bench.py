@@ -516,6 +516,55 @@ def measure_next_rows(ctx):
                 sites=nsites, seconds_per_call=best, sites_per_s=nsites / best,
                 what='dwell times, root posteriors and transition counts summed over the batch, '
                      'one host call (expm, passes, site sums, Frechet block exponentials)')
+        # observed codon STATES instead of dense leaf vectors (type x, the compact encoding of
+        # SURVEY 8d -- an optimisation reported beside the headline, never in it): the
+        # tree-specialised kernel's leaf steps gather columns of P, half of the matrix steps go
+        from raoteh_amd import device as _device, _lib as _l
+        cfg = synth.make_config('c3', nsites=10000)
+        T, root, n = cfg['T'], cfg['root'], cfg['nstates']
+        model = _device.TreeModel(T, root, n, ctx=ctx)
+        model.set_rates(Q_default=cfg['Q_default'])
+        model.set_root_distn(cfg['root_distn'])
+        bs = model.upload_sites(cfg['leaves'], cfg['leaf_states'].astype(np.uint8), kind='state')
+        bd = model.upload_sites(cfg['leaves'], synth.leaf_likelihoods(cfg), kind='dense')
+        bs.wait_for_kernel()
+        bd.wait_for_kernel()
+        lls, _ = model.log_likelihoods(bs)
+        lld, _ = model.log_likelihoods(bd)
+        for _ in range(20):
+            model.step(bs)
+        ctx.sync()
+        ctx.set_timing(1)
+        ctx.reset_timing()
+        times = []
+        for _ in range(9):
+            ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                model.step(bs)
+            ctx.sync()
+            times.append((time.perf_counter() - t0) / 20)
+        kms, kcnt, kname = ctx.kernel_time(_l.RT_K_PRUNE)
+        ctx.set_timing(0)
+        dt = float(np.median(times))
+        nedges = T.number_of_edges()
+        inner_edges = sum(1 for v in T if T.degree(v) > 1 and v != root)
+        flops = 10000 * (2.0 * n * n * inner_edges + n * nedges + 2.0 * n)
+        peak, _ = f64_mfma_peak()
+        out['leaf_states_step_c3'] = dict(
+            sites=10000, ms_per_step=dt * 1e3, sites_per_s=10000 / dt, kernel=bs.kernel_name,
+            avg_kernel_us=kms / max(kcnt, 1) * 1e3,
+            bit_identical_to_dense_batch=bool(np.array_equal(lls, lld)),
+            roofline=dict(bound='mfma', achieved=flops / (kms / max(kcnt, 1) * 1e-3) / 1e12, peak=peak,
+                          unit='TFLOP/s', frac=flops / (kms / max(kcnt, 1) * 1e-3) / 1e12 / peak,
+                          algorithmic_flops_per_launch=flops,
+                          note='products at the %d inner edges only: a leaf edge is a column gather'
+                               % inner_edges),
+            what='one step (expm of every edge + pruning) of the C3 batch uploaded as uint8 codon '
+                 'states: NOT the headline encoding (dense f64 leaf vectors)')
+        bs.close()
+        bd.close()
+        model.close()
         # the same statistics on a RESIDENT batch (rt_expect_step): nothing marshalled or
         # uploaded per call; arithmetic of a call = upward pass + downward pass (products at
         # the internal nodes) + per-edge site sums, each 2 n^2 flops per edge and site, + one

@@ -816,6 +816,7 @@ extern "C" int rt_sites_destroy(rt_sites *s)
     if (s->model->ctx->comm_stream) hipStreamSynchronize(s->model->ctx->comm_stream);
     hipFree(s->d_partial); hipFree(s->d_partial_alt); hipFree(s->d_scratch); hipFree(s->d_half);
     hipFree(s->d_half_count);
+    hipFree(s->d_leafw);
     if (s->totals_slot >= 0) {
         // keep the free list sorted (descending) so that batches created one after
         // the other keep getting neighbouring slots
@@ -985,6 +986,8 @@ static int sites_alloc(rt_sites *s, bool generic)
     if (e == hipSuccess && s->jit_halves)      // [tile][half][k-step][lane] (jit.hip)
         e = hipMalloc((void **)&s->d_half,       // (padded to whole groups of <= 8 tiles)
                       (size_t)(s->nblocks + 8) * 2 * ((n + 15) / 16) * 4 * 64 * 8);
+    if (e == hipSuccess && s->sparse_ok)
+        e = hipMalloc((void **)&s->d_leafw, (size_t)s->nblocks * ((s->nobs + 3) / 4) * 16 * 4 + 64);
     if (e == hipSuccess && s->jit_halves) {
         e = hipMalloc((void **)&s->d_half_count, (size_t)(s->nblocks + 8) * 4);
         if (e == hipSuccess) e = hipMemset(s->d_half_count, 0, (size_t)(s->nblocks + 8) * 4);
@@ -1108,6 +1111,7 @@ struct jit_override {
     bool halves = false;      // split-M family: the two root programs as separate workgroups
     bool fuse = false;        // lane family: the kernel can compute its own transitions
     bool no_solo = false;     // n <= 32: the split-M interpreter kernel, not the one-wave one
+    bool sparse = false;      // split-M family: leaf steps gather columns of P (leaf states)
 };
 
 // Background compile for an MFMA-family batch: candidates the cache already knows as
@@ -1144,10 +1148,12 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
         const std::string src =
             !mfma ? rt_jit_lane_source(s->ops, n, K, ov->D, ov->LA, ov->S, ov->WG, ov->compact,
                                        ov->fuse)
+            : split && ov->sparse ? rt_jit_mfma_split_source(s->ops, n, K, ov->T, ov->D, ov->LA, true)
             : split ? split_source(s->ops, n, K, ov->T, ov->D, ov->LA, ov->halves)
                     : rt_jit_mfma_source(s->ops, n, K, ov->T, ov->D, ov->LA, ov->quad);
         RT_TRY(rt_jit_get(s->model->ctx, src, &s->jit_fn, mfma));
-        if (split && ov->halves) RT_TRY(sites_halves_setup(s));
+        s->jit_sparse = split && ov->sparse;
+        if (split && ov->halves && !ov->sparse) RT_TRY(sites_halves_setup(s));
         s->jit_quad = mfma && !split && ov->quad;
         s->jit_prefetch = ov->D;
         s->jit_lookahead = ov->LA;
@@ -1207,6 +1213,32 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
             s->jit_prefetch = D;
             s->jit_lookahead = LA;
             int rc = RT_ERR_UNSUPPORTED;
+            // Observed states at the leaves (type x): the kernel whose leaf steps gather
+            // columns of P instead of multiplying (half of the steps of a binary tree); one or
+            // two tiles per workgroup, the serial generator (few steps consume their
+            // predecessor once the leaves are out of the chain of matrix steps)
+            if (s->sparse_ok) {
+                int Ts = (ntiles >= 2048 && !wide) ? 2 : 1;
+                if (const char *v = getenv("RAOTEH_JIT_TILES")) Ts = std::min(2, std::max(1, atoi(v)));
+                std::vector<rt_sites::jit_cand> cands;
+                for (int t = Ts; t >= 1; --t) cands.push_back({t, false, false, true});
+                auto make = [&](const rt_sites::jit_cand &c) {
+                    return rt_jit_mfma_split_source(s->ops, (int)s->model->n, (int)s->nobs, c.T, D, LA, true);
+                };
+                if (!forced && opt_jit_async(s->model->ctx) && sites_jit_start_async(s, cands, make))
+                    return RT_OK;
+                for (const auto &c : cands) {
+                    rc = rt_jit_get(s->model->ctx, make(c), &s->jit_fn, true, &s->jit_compile_s);
+                    if (rc == RT_OK) {
+                        s->jit_tiles = c.T;
+                        s->jit_waves = (int)((s->model->n + 15) / 16);
+                        s->jit_sparse = true;
+                        return RT_OK;
+                    }
+                    if (rc != RT_ERR_UNSUPPORTED) break;
+                }
+                rc = RT_ERR_UNSUPPORTED;       // spilled: the dense kernels below
+            }
             // fewer tiles if it spills: halves at T, halves at one tile, then the whole tree.
             // Unless the kernel is already in this context's cache, a background job works
             // through that list while the batch runs the interpreter kernel.
@@ -1451,6 +1483,8 @@ extern "C" int rt_jit_source(int64_t nnodes, const int64_t *idx, const int64_t *
                              getenv("RAOTEH_JIT_FUSE_EXPM") && atoi(getenv("RAOTEH_JIT_FUSE_EXPM")) != 0)
         : n <= 32 ? rt_jit_mfma_source(m.ops, (int)n, (int)nobs, std::min(T, 4), (int)prefetch, 1,
                                        !(getenv("RAOTEH_JIT_QUAD") && atoi(getenv("RAOTEH_JIT_QUAD")) == 0))
+                  : getenv("RAOTEH_JIT_SOURCE_SPARSE")
+                        ? rt_jit_mfma_split_source(m.ops, (int)n, (int)nobs, std::min(T, 2), 2, 1, true)
                   : split_source(m.ops, (int)n, (int)nobs,
                                  getenv("RAOTEH_JIT_HALVES") && atoi(getenv("RAOTEH_JIT_HALVES"))
                                      ? T : std::min(T, 3), (int)prefetch, 1,
@@ -1524,6 +1558,18 @@ static int sites_create_impl(rt_model *m, int64_t nsites, int kind, int64_t nobs
     if (const char *v = getenv("RAOTEH_LANE_VARIANT")) s->lane_dma = strcmp(v, "dma") == 0;
     if (const char *r = getenv("RAOTEH_LANE_RING")) s->lane_ring = atoi(r);
     else s->lane_ring = s->lane_dma ? 0 : 8;      // 0: rt_launch_prune picks what fits
+    // observed STATES, all at leaves, none unobserved, split-M family: the kernel's leaf steps
+    // may gather columns of P (jit.hip, `sparse`); the dense image stays (interpreter kernel)
+    if (kind == RT_OBS_STATE && s->layout == RT_LAYOUT_MFMA && !s->mfma_solo && !generic && nobs > 0 &&
+        !getenv("RAOTEH_JIT_NO_SPARSE") && (!ov || ov->sparse)) {
+        bool ok = true;
+        for (const rt_op &op : s->ops)
+            if (op.obs >= 0 && !(op.pop < 0 && op.dst >= 0)) ok = false;
+        const unsigned char *bytes = (const unsigned char *)data;
+        const size_t count = (size_t)nsites * (size_t)nobs;
+        for (size_t i = 0; ok && i < count; ++i) ok = bytes[i] < m->n;
+        s->sparse_ok = ok;
+    }
     int rc = sites_jit(s, generic, kind, ov);    // before the layout is fixed: block_sites
     // a freshly compiled kernel is checked against the interpreter kernel on a probe batch
     // before any user batch may launch it; if it fails this batch runs the interpreter
@@ -1566,6 +1612,7 @@ static int sites_create_impl(rt_model *m, int64_t nsites, int kind, int64_t nobs
             s->jit_tiles = 1;
             s->compact_states = 0;
             s->jit_quad = false;
+            s->jit_sparse = false;
             s->jit_halves = false;
             s->jit_fold = false;
             s->jit_combine = nullptr;
@@ -1636,7 +1683,7 @@ static int verify_jit_kernel(rt_sites *s, int kind)
     for (int64_t v = 0; v < N; ++v)
         if (s->node_obs[(size_t)v] >= 0) obs_nodes[(size_t)s->node_obs[(size_t)v]] = v;
     // observations of the kind the kernel was specialised for (compact kernels read bytes)
-    const int pkind = s->compact_states == 1 ? RT_OBS_STATE
+    const int pkind = (s->compact_states == 1 || s->jit_sparse) ? RT_OBS_STATE
                     : s->compact_states == 2 ? RT_OBS_MASK : RT_OBS_DENSE;
     (void)kind;
     std::vector<double> dense;
@@ -1654,7 +1701,8 @@ static int verify_jit_kernel(rt_sites *s, int kind)
         states.resize((size_t)np * K);
         for (unsigned char &v : states) {
             const double u = next();
-            v = u < 0.15 ? 255 : (unsigned char)((int)(next() * n) % (int)n);
+            // (the column-gathering kernels take batches without unobserved leaves only)
+            v = (u < 0.15 && !s->jit_sparse) ? 255 : (unsigned char)((int)(next() * n) % (int)n);
         }
         data = states.data();
     } else {
@@ -1679,6 +1727,7 @@ static int verify_jit_kernel(rt_sites *s, int kind)
     same.quad = s->jit_quad;
     same.halves = s->jit_halves;
     same.fuse = s->jit_fused;
+    same.sparse = s->jit_sparse;
     if (rc == RT_OK)
         rc = sites_create_impl(tm, np, pkind, K, obs_nodes.data(), data, &interp, &si);
     if (rc == RT_OK)
@@ -1832,6 +1881,7 @@ int rt_sites_jit_poll(rt_sites *s, bool wait)
     const bool split = m->n > 32 || !s->mfma_solo;
     s->jit_fn = fn;
     s->jit_tiles = c.T;
+    s->jit_sparse = split && c.sparse;
     s->jit_quad = !split && c.quad;
     if (split) s->jit_waves = (int)((m->n + 15) / 16);
     int src = RT_OK;
@@ -1854,6 +1904,7 @@ int rt_sites_jit_poll(rt_sites *s, bool wait)
         s->jit_fn = nullptr;
         s->jit_tiles = 1;
         s->jit_quad = false;
+        s->jit_sparse = false;
         s->jit_halves = false;
         s->jit_fold = false;
         s->jit_combine = nullptr;
@@ -1913,7 +1964,13 @@ extern "C" int rt_sites_clone(rt_sites *src, rt_sites **out)
     s->jit_srcs = src->jit_srcs;
     s->jit_kind = src->jit_kind;
     s->jit_compile_s = src->jit_compile_s;
+    s->sparse_ok = src->sparse_ok;
+    s->jit_sparse = src->jit_sparse;
     int rc = sites_alloc(s, src->d_scratch != nullptr);
+    if (rc == RT_OK && s->d_leafw && src->d_leafw &&
+        hipMemcpyAsync(s->d_leafw, src->d_leafw, (size_t)s->nblocks * ((s->nobs + 3) / 4) * 16 * 4,
+                       hipMemcpyDeviceToDevice, src->model->ctx->stream) != hipSuccess)
+        rc = RT_ERR_HIP;
     if (rc == RT_OK && s->obs_bytes > 0) {
         // on the library's stream: a device-to-device hipMemcpy returns before the copy
         // has run and the (non-blocking) stream of the kernels does not wait for the

@@ -244,7 +244,7 @@ struct rt_sites {
     // background compile of the tree-specialised kernel (MFMA family): the batch runs the
     // interpreter kernel until the job is done and rt_sites_jit_poll swaps the kernel in
     std::shared_ptr<rt_jit_job> jit_job;
-    struct jit_cand { int T; bool halves; bool quad; };
+    struct jit_cand { int T; bool halves; bool quad; bool sparse = false; };
     std::vector<jit_cand> jit_cands;        // what each candidate source of the job was built with
     std::vector<std::string> jit_srcs;
     int jit_kind = 0;                       // observation kind of the batch (probe batches)
@@ -255,6 +255,12 @@ struct rt_sites {
     void *d_raw = nullptr;
     int *d_raw_src = nullptr;
     struct { int S = 64, WG = 1, D = 1, LA = 1, compact = 0; bool fuse = false; } jit_lane;
+    // n > 32, observed STATES at leaves only, none unobserved: next to the dense image the
+    // batch keeps the state bytes (leafw[tile][ceil(K/4)][16 sites], four stream positions per
+    // word) for the tree-specialised kernel whose leaf steps gather columns of P (jit.hip)
+    bool sparse_ok = false;
+    bool jit_sparse = false;
+    unsigned *d_leafw = nullptr;
     // rt_expect_step: per-site multiplicities on the device (null: ones), and the batch's
     // split-M interpreter twin -- its own program, partial sums and per-site outputs over the
     // SAME resident observations (obs_borrowed: d_obs belongs to the batch it was made from)
@@ -324,7 +330,7 @@ std::string rt_jit_lane_source(const std::vector<rt_op> &ops, int n, int K, int 
 std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int T, int D, int LA,
                                bool quad = false);
 std::string rt_jit_mfma_split_source(const std::vector<rt_op> &ops, int n, int K, int T, int D,
-                                     int LA);
+                                     int LA, bool sparse = false);
 bool rt_jit_fold_enabled();
 std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, int n, int K, int T,
                                                int D, int LA, bool halves = false);

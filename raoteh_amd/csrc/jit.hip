@@ -30,6 +30,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <map>
@@ -1063,8 +1064,17 @@ std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int 
 //   * pending accumulators (own rows: 4 doubles per lane and tile) in named
 //     registers, no LDS stack, no program fetch, no branches.
 // Same accumulation order as the interpreter: bit-identical results.
+// sparse = observed STATES at the leaves (type x, _mcx.py:12-23: the reference's own fast case):
+// the product of a leaf's edge with a one-hot vector is a COLUMN of P_e, so a leaf step is four
+// 8-byte gathers from the transition matrices in the reference's order (P[node][row][state],
+// L2-resident) instead of an x exchange, a barrier and KS MFMAs -- half of the steps of a binary
+// tree.  The matrix pipe computes that product as fma(P, 1, 0) plus exact zeros, so the gathered
+// column is its result bit for bit (the probe verification checks it against the interpreter on
+// the dense expansion).  Leaf states arrive as bytes, four stream positions per word:
+// leafw[tile][ceil(K/4)][16 sites].  Only for batches whose observed nodes are all leaves and
+// whose states are all observed (api.hip).
 std::string rt_jit_mfma_split_source(const std::vector<rt_op> &ops, int n, int K, int T, int D,
-                                     int LA)
+                                     int LA, bool sparse)
 {
     const int NT = (n + 15) / 16;
     const int KS = (n + 3) / 4;
@@ -1077,7 +1087,8 @@ std::string rt_jit_mfma_split_source(const std::vector<rt_op> &ops, int n, int K
         if (op.dst >= 0) nslots = std::max(nslots, (op.dst & 255) + 1);
     }
     std::ostringstream o;
-    o << "// generated by raoteh_amd/csrc/jit.hip (split-M MFMA family): " << nrec << " steps, "
+    o << "// generated by raoteh_amd/csrc/jit.hip (split-M MFMA family" << (sparse ? ", leaf states" : "")
+      << "): " << nrec << " steps, "
       << n << " states, " << K << " observed nodes, " << T << " tiles per workgroup of " << NT
       << " waves, prefetch " << D << " leaves / " << LA << " P records\n";
     o << "typedef double rt_d2 __attribute__((ext_vector_type(2)));\n";
@@ -1101,7 +1112,9 @@ std::string rt_jit_mfma_split_source(const std::vector<rt_op> &ops, int n, int K
          "rt_jit_prune(const double *__restrict__ Pfrag, const rt_d2 *__restrict__ obs,\n"
          "             const double *__restrict__ root_w, double *__restrict__ loglik,\n"
          "             int *__restrict__ status, double *__restrict__ partial,\n"
-         "             long nsites, long nblocks)\n{\n";
+         "             long nsites, long nblocks"
+      << (sparse ? ", const unsigned *__restrict__ leafw, const double *__restrict__ Pesd" : "")
+      << ")\n{\n";
     o << "    __shared__ double xb[2][" << T << "][" << XT << "];   // [buffer][tile][k-step][lane]\n";
     o << "    __shared__ double red[" << T << "][" << NT << "][16];\n";
     o << "    const int lane = threadIdx.x & 63;\n";
@@ -1143,19 +1156,80 @@ std::string rt_jit_mfma_split_source(const std::vector<rt_op> &ops, int n, int K
                 o << "    const rt_d2 A" << i << "_" << q << " = ag[" << at << "];\n";
         }
     };
-    for (int k = 0; k < std::min(D, K); ++k) emit_obs_load(k);
-    for (int i = 0; i < std::min(LA, nrec); ++i)
-        if (ops[(size_t)i].dst >= 0) emit_a_load(i);
+    auto is_sparse_leaf = [&](const rt_op &op) {
+        return sparse && op.pop < 0 && op.obs >= 0 && op.dst >= 0;
+    };
+    if (sparse) {
+        // the state bytes of every leaf of the workgroup's tiles, four per word
+        const int KW = (K + 3) / 4;
+        for (int t = 0; t < T; ++t)
+            for (int w = 0; w < KW; ++w)
+                o << "    const unsigned lw" << w << "_" << t << " = leafw[((size_t)(tile" << t
+                  << " < nblocks ? tile" << t << " : nblocks - 1) * " << KW << " + " << w
+                  << ") * 16 + (lane & 15)];\n";
+        for (int r = 0; r < 4; ++r)
+            o << "    const int prow" << r << " = (16 * m + " << 4 * r << " + (lane >> 4)) * " << n << ";\n";
+    }
+    // the four entries of this lane of column `state` of P_node (zero in the padded rows)
+    auto emit_gather = [&](int i) {
+        const rt_op &op = ops[(size_t)i];
+        for (int t = 0; t < T; ++t) {
+            o << "    const int st" << i << "_" << t << " = (int)((lw" << (op.obs >> 2) << "_" << t
+              << " >> " << 8 * (op.obs & 3) << ") & 255u);\n";
+            for (int r = 0; r < 4; ++r)
+                o << "    const double pc" << i << "_" << t << "_" << r << " = rowok" << r << " ? Pesd["
+                  << (long)op.node * n * n << " + prow" << r << " + st" << i << "_" << t << "] : 0.0;\n";
+        }
+    };
+    if (!sparse)
+        for (int k = 0; k < std::min(D, K); ++k) emit_obs_load(k);
+    // (sparse: the steps that multiply, in order -- the A fragments run LA of THOSE ahead)
+    std::vector<int> msteps;
+    for (int i = 0; i < nrec; ++i)
+        if (!is_sparse_leaf(ops[(size_t)i])) msteps.push_back(i);
+    if (sparse) {
+        for (int q = 0; q < std::min(LA, (int)msteps.size()); ++q)
+            if (ops[(size_t)msteps[(size_t)q]].dst >= 0) emit_a_load(msteps[(size_t)q]);
+    } else {
+        for (int i = 0; i < std::min(LA, nrec); ++i)
+            if (ops[(size_t)i].dst >= 0) emit_a_load(i);
+    }
+    // gathers are requested one matrix step ahead of the leaf step that folds them: those of
+    // the leaves in front of the first matrix step here, the others at the matrix step before
+    if (sparse)
+        for (int i = 0; i < nrec && is_sparse_leaf(ops[(size_t)i]); ++i) emit_gather(i);
 
     std::string dep = "lane";
+    int nmfma = 0;                           // matrix steps so far (the x buffers alternate over THESE)
     for (int i = 0; i < nrec; ++i) {
         const rt_op &op = ops[(size_t)i];
+        if (is_sparse_leaf(op)) {
+            // ---- a leaf with an observed state: its message is a column of P
+            o << "    {   // step " << i << ": leaf " << op.node << " (column of P)\n";
+            const int d = op.dst & 255;
+            const bool first = (op.dst >> 8) != 0;
+            for (int t = 0; t < T; ++t)
+                for (int r = 0; r < 4; ++r)
+                    o << "    a" << d << "_" << t << "_" << r << (first ? " = " : " *= ") << "pc" << i
+                      << "_" << t << "_" << r << ";\n";
+            o << "    }\n";
+            continue;
+        }
         o << "    asm volatile(\"\" : \"+v\"(ag)";
         for (int t = 0; t < T; ++t) o << ", \"+v\"(g" << t << ")";
         o << " : \"v\"(" << dep << "));\n";
         o << "    __builtin_amdgcn_sched_barrier(0);\n";
-        if (i + LA < nrec && ops[(size_t)(i + LA)].dst >= 0) emit_a_load(i + LA);
-        if (op.obs >= 0 && op.obs + D < K) emit_obs_load(op.obs + D);
+        if (sparse) {
+            // the A fragments of the next matrix steps, and the columns of the leaves that
+            // follow this step
+            const size_t q = (size_t)(std::find(msteps.begin(), msteps.end(), i) - msteps.begin());
+            if (q + (size_t)LA < msteps.size() && ops[(size_t)msteps[q + (size_t)LA]].dst >= 0)
+                emit_a_load(msteps[q + (size_t)LA]);
+            for (int j = i + 1; j < nrec && is_sparse_leaf(ops[(size_t)j]); ++j) emit_gather(j);
+        } else {
+            if (i + LA < nrec && ops[(size_t)(i + LA)].dst >= 0) emit_a_load(i + LA);
+            if (op.obs >= 0 && op.obs + D < K) emit_obs_load(op.obs + D);
+        }
         if (op.dst >= 0) dep = "a" + std::to_string(op.dst & 255) + "_0_0";
         o << "    {   // step " << i << ": node " << op.node << "\n";
         stamp(i, 0);
@@ -1200,7 +1274,7 @@ std::string rt_jit_mfma_split_source(const std::vector<rt_op> &ops, int n, int K
                 o << "        lik" << t << " = tot;\n    }\n";
             }
         } else {
-            const int b = i & 1;
+            const int b = sparse ? (nmfma++ & 1) : (i & 1);
             for (int t = 0; t < T; ++t)
                 for (int r = 0; r < 4; ++r)
                     o << "    xb[" << b << "][" << t << "][(4 * m + " << r << ") * 64 + lane] = x" << t
@@ -2361,8 +2435,15 @@ int rt_launch_prune_jit(rt_model *m, rt_sites *s, const rt_fuse_args *fuse)
     long nsites = (long)s->nsites;
     long nblocks = (long)s->nblocks;
     long tile0 = 0, stride1 = 1;     // declared by the one-wave MFMA family only
-    void *args[] = {&Pord, &obs, &root_w, &loglik, &status, &partial, &nsites, &nblocks, &tile0,
-                    &stride1};
+    // the column-gathering split-M kernels declare the leaf-state words and the transition
+    // matrices in the reference's order in those two places
+    const unsigned *leafw = s->d_leafw;
+    const double *Pesd = m->d_P;
+    void *args_dense[] = {&Pord, &obs, &root_w, &loglik, &status, &partial, &nsites, &nblocks, &tile0,
+                          &stride1};
+    void *args_sparse[] = {&Pord, &obs, &root_w, &loglik, &status, &partial, &nsites, &nblocks, &leafw,
+                           &Pesd};
+    void **args = s->jit_sparse ? args_sparse : args_dense;
     if (s->jit_fn2) {
         // main kernel: jit_split_tiles tiles, jit_tiles per wave (one wave per SIMD); the rest
         // one tile per wave on the side stream, at the same time.  The timing events, when

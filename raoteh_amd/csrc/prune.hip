@@ -1319,6 +1319,31 @@ __global__ void pack_sites_mfma_kernel(int kind, const void *__restrict__ data,
     }
 }
 
+// leaf states as bytes for the column-gathering kernels (jit.hip, `sparse`): word w of
+// (tile, site) holds stream positions 4w .. 4w+3; sites past the batch read state 0
+__global__ void pack_leaf_words_kernel(const unsigned char *__restrict__ data,
+                                       const int *__restrict__ src_of_k, long nsites, long nobs,
+                                       int K, long nblocks16, unsigned *__restrict__ out)
+{
+    const int KW = (K + 3) / 4;
+    const size_t total = (size_t)nblocks16 * KW * 16;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(e & 15);
+        const size_t r = e >> 4;
+        const int w = (int)(r % KW);
+        const long site = (long)(r / KW) * 16 + lane;
+        unsigned word = 0;
+        for (int j = 0; j < 4; ++j) {
+            const int k = 4 * w + j;
+            unsigned st = 0;
+            if (k < K && site < nsites) st = data[(size_t)site * nobs + src_of_k[k]];
+            word |= (st & 255u) << (8 * j);
+        }
+        out[e] = word;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -1376,6 +1401,10 @@ int rt_sites_pack_device(rt_sites *s, int kind, const void *d_in, const int *d_s
             hipLaunchKernelGGL(pack_sites_mfma_kernel, dim3((unsigned)blocks), dim3(256),
                                0, st, kind, d_in, d_src, (long)s->nsites, (long)K, K, n,
                                KP, s->d_obs, total);
+            if (s->d_leafw && kind == RT_OBS_STATE)
+                hipLaunchKernelGGL(pack_leaf_words_kernel, dim3(1024), dim3(256), 0, st,
+                                   (const unsigned char *)d_in, d_src, (long)s->nsites, (long)K, K,
+                                   (long)s->nblocks, s->d_leafw);
         }
         RT_HIP(hipGetLastError());
     }
@@ -1750,7 +1779,7 @@ int rt_launch_prune(rt_model *m, rt_sites *s, bool defer_reduce, bool fuse_expm)
             else
             snprintf(jit_name, sizeof(s->kernel_name), "prune_tree_jit_mfma%s<%d,T%d%s>",
                      s->jit_quad ? "4x4" : "", (int)m->n, s->jit_tiles,
-                     s->jit_halves ? ",halves" : "");
+                     s->jit_sparse ? ",leaf-states" : s->jit_halves ? ",halves" : "");
         name = jit_name;
     } else if (s->layout == RT_LAYOUT_LANE) {
         switch ((int)m->n) {

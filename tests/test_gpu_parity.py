@@ -920,6 +920,93 @@ def test_reference_format_passes_above_64_states(ra, n):
     np.testing.assert_allclose(J, np.array(want_joint), rtol=1e-11, atol=1e-300)
 
 
+@pytest.mark.parametrize('n', [33, 61, 64, 90, 122])
+def test_leaf_state_kernels_gather_columns_bit_identically(ra, n, monkeypatch):
+    """Observed STATES at the leaves (type x, the reference's _mcx case) above 32 states: the
+    tree-specialised kernel's leaf steps gather columns of P instead of multiplying (jit.hip,
+    `sparse`) -- the same numbers bit for bit as the interpreter kernel on the dense expansion,
+    for one and two tiles per workgroup, random multifurcating trees, compiled in the
+    foreground and in the background; batches it does not cover (an unobserved leaf, an
+    observed inner node) take the dense kernels."""
+    rng = np.random.RandomState(4000 + n)
+    set_option = ra.lib.lib().rt_set_option
+    for nnodes, nsites in ((2, 40), (9, 130), (40, 700)):
+        T, root, obs_nodes, w = _random_case(ra, rng, n, nnodes, nsites, internal_obs=False)
+        pre, idx, ptr, esd = orc.get_esd_transitions(T, root, n)
+        states = rng.randint(0, n, size=(nsites, len(obs_nodes))).astype(np.uint8)
+        dense = np.zeros((nsites, len(obs_nodes), n))
+        ii, kk = np.indices(states.shape)
+        dense[ii, kk, states] = 1.0
+        want, wst = orc.batch_log_likelihoods(idx, ptr, esd, [pre.index(v) for v in obs_nodes],
+                                              dense, w)
+        model = ra.device.TreeModel(T, root, n)
+        model.set_transitions(esd)
+        model.set_root_distn(w)
+        ra.lib.check(set_option(b'jit', 0))
+        try:
+            ref_ll, ref_st = model.log_likelihoods(model.upload_sites(obs_nodes, states, kind='state'))
+        finally:
+            ra.lib.check(set_option(b'jit', -1))
+        np.testing.assert_array_equal(ref_st & 1, wst)
+        np.testing.assert_allclose(ref_ll[wst == 0], want[wst == 0], rtol=RTOL_LL)
+        for tiles in (1, 2):
+            monkeypatch.setenv('RAOTEH_JIT_TILES', str(tiles))
+            ra.lib.check(set_option(b'jit', 1))
+            try:
+                batch = model.upload_sites(obs_nodes, states, kind='state')
+                ll, st = model.log_likelihoods(batch)
+                assert 'leaf-states' in batch.kernel_name and ('T%d' % tiles) in batch.kernel_name, \
+                    batch.kernel_name
+                np.testing.assert_array_equal(ll, ref_ll)
+                np.testing.assert_array_equal(st, ref_st)
+                twin = batch.clone()
+                ll2, _ = model.log_likelihoods(twin)
+                assert 'leaf-states' in twin.kernel_name
+                np.testing.assert_array_equal(ll2, ref_ll)
+                tot = model.fetch_totals(batch)
+                assert tot[2] == nsites and tot[0] == pytest.approx(ref_ll[wst == 0].sum(), rel=1e-12)
+                # dense input of the same batch: the dense kernels, the same numbers
+                dll, _ = model.log_likelihoods(model.upload_sites(obs_nodes, dense, kind='dense'))
+                np.testing.assert_array_equal(dll, ref_ll)
+            finally:
+                ra.lib.check(set_option(b'jit', -1))
+                monkeypatch.delenv('RAOTEH_JIT_TILES')
+        # not covered: an unobserved leaf / an observed inner node -> the dense kernels
+        ra.lib.check(set_option(b'jit', 1))
+        try:
+            gap = states.copy()
+            gap[0, 0] = 255
+            b1 = model.upload_sites(obs_nodes, gap, kind='state')
+            model.log_likelihoods(b1)
+            assert 'leaf-states' not in b1.kernel_name and b1.kernel_name.startswith('prune_tree_jit')
+            inner = [v for v in T if T.degree(v) > 1 and v != root]
+            if inner:
+                more = obs_nodes + inner[:1]
+                st2 = np.concatenate([states, rng.randint(0, n, size=(nsites, 1)).astype(np.uint8)], axis=1)
+                b2 = model.upload_sites(more, st2, kind='state')
+                model.log_likelihoods(b2)
+                assert 'leaf-states' not in b2.kernel_name
+        finally:
+            ra.lib.check(set_option(b'jit', -1))
+    # in the background: interpreter first, the column-gathering kernel after the switch
+    ctx = ra.device.Context(0)
+    ctx.set_option('jit_async', 1)
+    nsites = max(70000 // n, 700)
+    T, root, obs_nodes, w = _random_case(ra, rng, n, 21, nsites, internal_obs=False)
+    pre, idx, ptr, esd = orc.get_esd_transitions(T, root, n)
+    states = rng.randint(0, n, size=(nsites, len(obs_nodes))).astype(np.uint8)
+    model = ra.device.TreeModel(T, root, n, ctx=ctx)
+    model.set_transitions(esd)
+    model.set_root_distn(w)
+    batch = model.upload_sites(obs_nodes, states, kind='state')
+    ll0, _ = model.log_likelihoods(batch)
+    batch.wait_for_kernel()
+    ll1, _ = model.log_likelihoods(batch)
+    assert 'leaf-states' in batch.kernel_name, batch.kernel_name
+    np.testing.assert_array_equal(ll0, ll1)
+    ctx.close()
+
+
 def test_deep_caterpillar_and_wide_star(ra):
     rng = np.random.RandomState(11)
     n = 4
