@@ -310,6 +310,15 @@ int rt_build_schedule(int64_t nnodes, const int64_t *tree_csr_indices,
  * disables it) while the batch runs the interpreter kernel; a later rt_prune / rt_step swaps
  * the kernel in once it is there and has passed the probe verification.  rt_sites_jit_wait
  * blocks until that has happened (or failed: the batch then stays on the interpreter).   */
+/* "rescale" (0 default / 1): batches created while it is set rescale their messages on the
+ * way up -- whenever the largest entry of a site's message falls below 2^-256 the message is
+ * multiplied by the exact power of two that brings it back to [1, 2) and the exponent is kept
+ * per site; log-likelihood = log(scaled likelihood) + exponent ln 2.  The reference never
+ * rescales (_mc0_dense.py:184-209 works on plain f64): a tree of a thousand leaves is "zero
+ * probability" there and, by default, here.  With the option such a batch keeps the
+ * interpreter kernels (no tree-specialised kernel); a batch that never comes near the
+ * threshold gets the default kernels' numbers bit for bit (powers of two are exact).
+ * Likelihood evaluation only (rt_prune / rt_step): expectations stay unscaled.             */
 int rt_set_option(const char *key, int64_t value);
 /* The same options for ONE context (they take precedence over the process-wide
  * defaults above; value -2 = back to the default): two contexts on two threads can

@@ -740,6 +740,9 @@ static std::atomic<int> g_jit_block_sites{0};    // 0 = automatic (see sites_jit
 // 1: rt_sites_create does not wait for hiprtc (MFMA family): the batch runs the interpreter
 // kernel until the background job is done; 0: compile inside rt_sites_create
 static std::atomic<int> g_jit_async{1};
+// 1: batches created from now on rescale their messages by powers of two (interpreter kernels
+// only; prune.hip, rescale_exponent): trees of a thousand leaves whose likelihood underflows f64
+static std::atomic<int> g_rescale{0};
 
 static int parse_option(const char *key, int64_t value, int *which, int *out)
 {
@@ -753,6 +756,7 @@ static int parse_option(const char *key, int64_t value, int *which, int *out)
         return RT_OK;
     }
     if (strcmp(key, "jit_async") == 0) { *which = 3; *out = value != 0; return RT_OK; }
+    if (strcmp(key, "rescale") == 0) { *which = 4; *out = value != 0; return RT_OK; }
     rt_set_error("unknown option %s", key);
     return RT_ERR_INVALID;
 }
@@ -762,7 +766,7 @@ extern "C" int rt_set_option(const char *key, int64_t value)
     int which = 0, v = 0;
     RT_TRY(parse_option(key, value, &which, &v));
     (which == 0 ? g_force_generic : which == 1 ? g_jit : which == 2 ? g_jit_block_sites
-                                                                     : g_jit_async).store(v);
+     : which == 3 ? g_jit_async : g_rescale).store(v);
     return RT_OK;
 }
 
@@ -777,7 +781,8 @@ extern "C" int rt_ctx_set_option(rt_ctx *ctx, const char *key, int64_t value)
         RT_TRY(parse_option(key, value, &which, &v));
     }
     (which == 0 ? ctx->opt_force_generic : which == 1 ? ctx->opt_jit
-     : which == 2 ? ctx->opt_jit_block_sites : ctx->opt_jit_async) = v;
+     : which == 2 ? ctx->opt_jit_block_sites : which == 3 ? ctx->opt_jit_async
+                                              : ctx->opt_rescale) = v;
     return RT_OK;
 }
 
@@ -790,6 +795,11 @@ static int opt_jit_async(const rt_ctx *c)
 {
     if (const char *v = getenv("RAOTEH_JIT_ASYNC")) return atoi(v) != 0;
     return c->opt_jit_async != RT_OPT_UNSET ? c->opt_jit_async : g_jit_async.load();
+}
+static int opt_rescale(const rt_ctx *c)
+{
+    if (const char *v = getenv("RAOTEH_RESCALE")) return atoi(v) != 0;
+    return c->opt_rescale != RT_OPT_UNSET ? c->opt_rescale : g_rescale.load();
 }
 static int opt_jit_block_sites(const rt_ctx *c)
 {
@@ -1017,7 +1027,7 @@ static int sites_alloc(rt_sites *s, bool generic)
         // cut and the same policy as the specialised kernel's (want_root_halves).
         // RAOTEH_INTERP_HALVES=0 / 1 overrides.
         std::vector<rt_op> opsA, opsB;
-        bool ih = e == hipSuccess && s->layout == RT_LAYOUT_MFMA && !s->mfma_solo &&
+        bool ih = e == hipSuccess && s->layout == RT_LAYOUT_MFMA && !s->mfma_solo && !s->rescale &&
                   !s->obs_borrowed && rt_split_at_root(s->ops, &opsA, &opsB);
         if (ih) {
             if (const char *v = getenv("RAOTEH_INTERP_HALVES")) ih = atoi(v) != 0;
@@ -1543,6 +1553,9 @@ static int sites_create_impl(rt_model *m, int64_t nsites, int kind, int64_t nobs
     const bool generic = opt_force_generic(m->ctx) || m->max_depth > RT_FAST_MAX_DEPTH ||
                          (m->n > 64 && nt_waves * m->max_depth * 2048 + 20 * 1024 > 160 * 1024);
     s->layout = (generic || m->n <= 4) ? RT_LAYOUT_LANE : RT_LAYOUT_MFMA;
+    // rescaling lives in the interpreter kernels: no tree-specialised kernel for such a batch,
+    // and the lane family's VGPR-ring variant (the LDS-DMA variant fuses cherries)
+    s->rescale = opt_rescale(m->ctx) != 0 && !ov;
     // tuning knobs of the lane family (A/B measurements)
     // Default: leaf vectors through the LDS-DMA ring (3 slots) when two 4-wave
     // workgroups (shared P table + rings + accumulator stacks) fit on a CU;
@@ -1556,12 +1569,13 @@ static int sites_create_impl(rt_model *m, int64_t nsites, int kind, int64_t nobs
     s->mfma_solo = s->layout == RT_LAYOUT_MFMA && m->n <= 32 && !getenv("RAOTEH_MFMA_NO_SOLO");
     if (ov && ov->no_solo) s->mfma_solo = false;
     if (const char *v = getenv("RAOTEH_LANE_VARIANT")) s->lane_dma = strcmp(v, "dma") == 0;
+    if (s->rescale) s->lane_dma = false;
     if (const char *r = getenv("RAOTEH_LANE_RING")) s->lane_ring = atoi(r);
     else s->lane_ring = s->lane_dma ? 0 : 8;      // 0: rt_launch_prune picks what fits
     // observed STATES, all at leaves, none unobserved, split-M family: the kernel's leaf steps
     // may gather columns of P (jit.hip, `sparse`); the dense image stays (interpreter kernel)
     if (kind == RT_OBS_STATE && s->layout == RT_LAYOUT_MFMA && !s->mfma_solo && !generic && nobs > 0 &&
-        !getenv("RAOTEH_JIT_NO_SPARSE") && (!ov || ov->sparse)) {
+        !s->rescale && !getenv("RAOTEH_JIT_NO_SPARSE") && (!ov || ov->sparse)) {
         bool ok = true;
         for (const rt_op &op : s->ops)
             if (op.obs >= 0 && !(op.pop < 0 && op.dst >= 0)) ok = false;
@@ -1570,7 +1584,7 @@ static int sites_create_impl(rt_model *m, int64_t nsites, int kind, int64_t nobs
         for (size_t i = 0; ok && i < count; ++i) ok = bytes[i] < m->n;
         s->sparse_ok = ok;
     }
-    int rc = sites_jit(s, generic, kind, ov);    // before the layout is fixed: block_sites
+    int rc = sites_jit(s, generic || s->rescale, kind, ov);    // before the layout is fixed: block_sites
     // a freshly compiled kernel is checked against the interpreter kernel on a probe batch
     // before any user batch may launch it; if it fails this batch runs the interpreter
     // (RAOTEH_JIT_NO_VERIFY: diagnostics only, tests/soak/spill_probe.py)
@@ -1938,6 +1952,7 @@ extern "C" int rt_sites_clone(rt_sites *src, rt_sites **out)
     s->nobs = src->nobs;
     s->layout = src->layout;
     s->lane_dma = src->lane_dma;
+    s->rescale = src->rescale;
     s->mfma_solo = src->mfma_solo;
     s->lane_ring = src->lane_ring;
     s->jit_fn = src->jit_fn;

@@ -87,6 +87,7 @@ struct rt_ctx {
     int opt_jit = -2;
     int opt_jit_block_sites = -2;
     int opt_jit_async = -2;
+    int opt_rescale = -2;
     // The batch whose per-wave partial sums still await their fixed-order reduction.
     // rt_step defers it: the reduction of step j rides as one extra workgroup of step
     // j + 1's expm launch (two launches per step instead of three: on config 2 the two
@@ -231,6 +232,9 @@ struct rt_sites {
     // the batch has no tree-specialised kernel: the two root programs, the P record and the
     // stream position the second one starts at, the root's own stream position (-1: none)
     bool interp_halves = false;
+    // "rescale" option at creation: messages rescaled by powers of two, exponent per site
+    // (interpreter kernels only; such a batch never gets a tree-specialised kernel)
+    bool rescale = false;
     int32_t *d_lane_ops_a = nullptr, *d_lane_ops_b = nullptr;
     int half_nops[2] = {0, 0};
     int half_rec1 = 0, half_kobs1 = 0, half_kroot = -1;

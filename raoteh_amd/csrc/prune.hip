@@ -57,22 +57,46 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// escale: the site's messages were multiplied by 2^-escale on the way up (opt-in rescaling:
+// exact powers of two, so the mantissa of the likelihood is what it would have been)
 __device__ __forceinline__ void finish_site(double lik, bool negative,
                                             bool valid, double *loglik,
                                             int *status, long site,
-                                            double &sum, double &nzero)
+                                            double &sum, double &nzero, int escale = 0)
 {
     const bool ok = lik > 0.0;
     if (valid) {
-        loglik[site] = ok ? log(lik) : -INFINITY;
+        double ll = ok ? log(lik) : -INFINITY;
+        if (ok && escale != 0) {
+            // in range: undo the scaling exactly and take the logarithm of the true value;
+            // out of range: log(m 2^e) = log(m) + e ln 2
+            const double back = ldexp(lik, escale);
+            ll = (back > 0x1p-1000 && back < 0x1p1000) ? log(back)
+                                                       : log(lik) + (double)escale * 0.6931471805599453094;
+        }
+        loglik[site] = ll;
         status[site] = (ok ? RT_SITE_OK : RT_SITE_ZERO_PROB) |
                        (negative ? RT_SITE_NEGATIVE : 0);
-        sum = ok ? log(lik) : 0.0;
+        sum = ok ? ll : 0.0;
         nzero = ok ? 0.0 : 1.0;
     } else {
         sum = 0.0;
         nzero = 0.0;
     }
+}
+
+// Opt-in rescaling ("rescale", interpreter kernels): when the largest entry of a site's
+// message drops below 2^-256 the message is multiplied by the power of two that brings it
+// back to [1, 2) and the exponent is remembered per site.  Powers of two are exact: a batch
+// that never comes near the threshold gets the numbers of the plain kernels bit for bit, and
+// a 1 000-leaf tree (e^-6000: zero in f64 without this; the reference has no rescaling
+// either) gets its log-likelihood.  -> the exponent to ADD to the site's tally (<= 0), 0: none
+__device__ __forceinline__ int rescale_exponent(double mx)
+{
+    if (!(mx < 0x1p-256) || !(mx > 0.0)) return 0;
+    int e;
+    frexp(mx, &e);              // mx = f 2^e, f in [0.5, 1)
+    return e - 1;               // 2^-(e-1) mx in [1, 2)
 }
 
 // ---------------------------------------------------------------------------
@@ -132,7 +156,7 @@ enum {
 // B = site blocks per wave: B = 2 gives every lane two independent sites, which
 // (i) halves the scalar work, the schedule fetches and the P reads per site and
 // (ii) gives the scheduler two independent dependency chains to interleave.
-template <int N, bool PLDS, int B = 1>
+template <int N, bool PLDS, int B = 1, bool RESC = false>
 struct LaneCtx {
     const RT_CONST_AS int4_t *ops_c;
     const RT_CONST_AS double *P_c;       // step-ordered P through the scalar cache
@@ -148,6 +172,26 @@ struct LaneCtx {
     double cur[B][N];              // register-cached top accumulator
     double lik[B];
     bool negative[B];
+    int escale[B];                 // RESC: exponent tally of the lane's site
+
+    // RESC: t = P x is about to be deposited; x's largest entry decides (rescale_exponent)
+    __device__ __forceinline__ void rescale_result(const double (&x)[B][N], double (&t)[B][N])
+    {
+        if constexpr (RESC) {
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                double mx = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) mx = fmax(mx, x[b][j]);
+                const int e = rescale_exponent(mx);
+                if (e != 0) {
+#pragma unroll
+                    for (int r = 0; r < N; ++r) t[b][r] = ldexp(t[b][r], -e);
+                    escale[b] += e;
+                }
+            }
+        }
+    }
 
     __device__ __forceinline__ void init()
     {
@@ -155,6 +199,7 @@ struct LaneCtx {
         i = 0;
 #pragma unroll
         for (int b = 0; b < B; ++b) {
+            escale[b] = 0;
             lik[b] = 0.0;
             negative[b] = false;
 #pragma unroll
@@ -253,8 +298,8 @@ struct LaneCtx {
         double t[B][N];
         if (flags & LOP_FAST) {
             if (flags & LOP_SPILL) spill();
-            if constexpr (HAS_OBS) matvec(p, o, t);
-            else matvec(p, cur, t);
+            if constexpr (HAS_OBS) { matvec(p, o, t); rescale_result(o, t); }
+            else { matvec(p, cur, t); rescale_result(cur, t); }
             deposit(flags, t, true);
             return;
         }
@@ -294,6 +339,7 @@ struct LaneCtx {
             }
         } else {
             matvec(p, x, t);
+            rescale_result(x, t);
             if ((flags & LOP_FIRST) && (flags & LOP_SPILL)) spill();
             deposit(flags, t, false);
         }
@@ -353,7 +399,7 @@ struct LaneCtx {
 // cache cannot hold P for a 64-leaf tree (16 KB + schedule), and an L2 round
 // trip per step is what the wave then waits for.  PLDS = false: one wave per
 // workgroup, P through the scalar cache (trees whose P table does not fit LDS).
-template <int N, int R, bool PLDS>
+template <int N, int R, bool PLDS, bool RESC = false>
 __global__ void __launch_bounds__(PLDS ? 256 : 64)
 prune_lane_kernel(const double *__restrict__ Pord,   // [nops][N][N]
                   const int4_t *__restrict__ ops, int nops,   // lane program
@@ -374,7 +420,7 @@ prune_lane_kernel(const double *__restrict__ Pord,   // [nops][N][N]
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long gw = (long)blockIdx.x * WPB + wave;    // site block of this wave
 
-    LaneCtx<N, PLDS> C;
+    LaneCtx<N, PLDS, 1, RESC> C;
     unsigned char *stack_base = smem;
     if (PLDS) {
         double *pl = (double *)smem;
@@ -431,7 +477,8 @@ prune_lane_kernel(const double *__restrict__ Pord,   // [nops][N][N]
 
     const long site = gw * 64 + lane;
     double sum, nzero;
-    finish_site(C.lik[0], C.negative[0], site < nsites, loglik, status, site, sum, nzero);
+    finish_site(C.lik[0], C.negative[0], site < nsites, loglik, status, site, sum, nzero,
+                C.escale[0]);
     sum = wave_sum(sum);
     nzero = wave_sum(nzero);
     if (lane == 0) {
@@ -620,7 +667,8 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
                   const double *__restrict__ root_w, int n, int lds_slots,
                   double *__restrict__ loglik, int *__restrict__ status,
                   double *__restrict__ partial, long nsites, long nblocks16,
-                  double *__restrict__ Lout, double *__restrict__ Mout, rt_interp_halves hv)
+                  double *__restrict__ Lout, double *__restrict__ Mout, rt_interp_halves hv,
+                  int rescale)
 {
     // Lout / Mout (optional): own rows of L_v and of the message M_v = P_v L_v of every step,
     // [step][tile][m][r][lane] -- what the downward pass and the site sums of the expectation
@@ -688,6 +736,7 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
     double lik = 0.0;
     bool negative = false;
     double cur[4] = {1.0, 1.0, 1.0, 1.0};      // register-cached top accumulator
+    int escale = 0;               // rescaling: exponent tally of this lane's site (lane & 15)
 
     for (int i = 0; i < nops; ++i) {
         const int flags = op.x;
@@ -784,6 +833,21 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
             const double b = xb[kk * 64 + lane];
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], b, acc, 0, 0, 0);
         }
+        if (rescale) {
+            // every wave of the tile sees all of x as its B operands: the site's largest
+            // entry, the same number in every lane of the site and in every wave
+            double xmax = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) xmax = fmax(xmax, xb[kk * 64 + lane]);
+            xmax = fmax(xmax, __shfl_xor(xmax, 16, 64));
+            xmax = fmax(xmax, __shfl_xor(xmax, 32, 64));
+            const int e = rescale_exponent(xmax);
+            if (e != 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = ldexp(acc[r], -e);
+                escale += e;
+            }
+        }
         if (STORE && live) {
             double *mo = Mout + ((size_t)i * nblocks16 + gt) * (NT * 256) + (m * 4) * 64 + lane;
 #pragma unroll
@@ -818,7 +882,7 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
     const long site = blk * 16 + (lane & 15);
     const bool valid = live && m == 0 && lane < 16 && site < nsites;
     double sum, nzero;
-    finish_site(lik, negative, valid, loglik, status, site, sum, nzero);
+    finish_site(lik, negative, valid, loglik, status, site, sum, nzero, escale);
     sum = wave_sum(sum);
     nzero = wave_sum(nzero);
     if (lane == 0) {
@@ -916,7 +980,7 @@ prune_mfma_solo_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][
                        const double *__restrict__ obs, int K,  // [blk16][K][KP][64][2]
                        const double *__restrict__ root_w, int n, int lds_slots,
                        double *__restrict__ loglik, int *__restrict__ status,
-                       double *__restrict__ partial, long nsites, long nblocks16)
+                       double *__restrict__ partial, long nsites, long nblocks16, int rescale)
 {
     constexpr int MW = NT * 4;                 // message doubles per lane
     constexpr int KP = (KS + 1) / 2;           // k-step pairs
@@ -959,6 +1023,7 @@ prune_mfma_solo_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][
 
     double lik = 0.0;
     bool negative = false;
+    int escale = 0;               // rescaling: exponent tally of this lane's site
     double cur[MW];
 #pragma unroll
     for (int j = 0; j < MW; ++j) cur[j] = 1.0;
@@ -1037,6 +1102,19 @@ prune_mfma_solo_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][
         for (int m = 0; m < NT; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) t[m * 4 + r] = acc[m][r];
+        if (rescale) {
+            double xmax = 0.0;
+#pragma unroll
+            for (int j = 0; j < KS; ++j) xmax = fmax(xmax, x[j]);
+            xmax = fmax(xmax, __shfl_xor(xmax, 16, 64));
+            xmax = fmax(xmax, __shfl_xor(xmax, 32, 64));
+            const int e = rescale_exponent(xmax);
+            if (e != 0) {
+#pragma unroll
+                for (int j = 0; j < MW; ++j) t[j] = ldexp(t[j], -e);
+                escale += e;
+            }
+        }
 
         if (flags & LOP_FIRST) {
             if (flags & LOP_SPILL) {
@@ -1066,7 +1144,7 @@ prune_mfma_solo_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][
     const long site = gw * 16 + (lane & 15);
     const bool valid = lane < 16 && site < nsites;
     double sum, nzero;
-    finish_site(lik, negative, valid, loglik, status, site, sum, nzero);
+    finish_site(lik, negative, valid, loglik, status, site, sum, nzero, escale);
     sum = wave_sum(sum);
     nzero = wave_sum(nzero);
     if (lane == 0) {
@@ -1087,13 +1165,14 @@ prune_generic_kernel(const double *__restrict__ P,   // [nnodes][n][n]
                      const double *__restrict__ root_w,
                      double *__restrict__ loglik, int *__restrict__ status,
                      double *__restrict__ partial, double *__restrict__ scratch,
-                     long nsp, long nsites)
+                     long nsp, long nsites, int rescale)
 {
     const int lane = threadIdx.x;
     const long blk = blockIdx.x;
     const long site = blk * 64 + lane;
     double lik = 0.0;
     bool negative = false;
+    int escale = 0;
     for (int i = 0; i < nops; ++i) {
         const rt_op op = ops[i];
         double x[NMAX];
@@ -1120,18 +1199,28 @@ prune_generic_kernel(const double *__restrict__ P,   // [nnodes][n][n]
             const int dslot = op.dst & 255;
             const bool first = (op.dst >> 8) != 0;
             const double *Pe = P + (long)op.node * n * n;
+            int e = 0;
+            if (rescale) {
+                double mx = 0.0;
+#pragma unroll
+                for (int j = 0; j < NMAX; ++j)
+                    if (j < n) mx = fmax(mx, x[j]);
+                e = rescale_exponent(mx);
+                escale += e;
+            }
             for (int r = 0; r < n; ++r) {
                 double s = 0.0;
 #pragma unroll
                 for (int j = 0; j < NMAX; ++j)
                     if (j < n) s = fma(Pe[r * n + j], x[j], s);
+                if (e != 0) s = ldexp(s, -e);
                 double *d = scratch + ((long)dslot * n + r) * nsp + site;
                 *d = first ? s : *d * s;
             }
         }
     }
     double sum, nzero;
-    finish_site(lik, negative, site < nsites, loglik, status, site, sum, nzero);
+    finish_site(lik, negative, site < nsites, loglik, status, site, sum, nzero, escale);
     sum = wave_sum(sum);
     nzero = wave_sum(nzero);
     if (lane == 0) {
@@ -1448,7 +1537,7 @@ int rt_sites_pack(rt_sites *s, int kind, const int64_t *src_of_k, const void *da
     return RT_OK;
 }
 
-template <int N, int R>
+template <int N, int R, bool RESC = false>
 static int launch_lane_reg(rt_model *m, rt_sites *s, bool *plds_out)
 {
     // the deepest accumulator never leaves the register cache
@@ -1462,7 +1551,7 @@ static int launch_lane_reg(rt_model *m, rt_sites *s, bool *plds_out)
     const int depth_arg = getenv("RAOTEH_LANE_NOLOAD") ? -depth : depth;
     if (plds) {
         const int lds = ptab + 4 * stack;
-        auto kern = prune_lane_kernel<N, R, true>;
+        auto kern = prune_lane_kernel<N, R, true, RESC>;
         RT_HIP(hipFuncSetAttribute((const void *)kern,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         RT_LAUNCH_TIMED(m->ctx, kern, dim3((unsigned)((s->nblocks + 3) / 4)), dim3(256), lds,
@@ -1470,7 +1559,7 @@ static int launch_lane_reg(rt_model *m, rt_sites *s, bool *plds_out)
                            s->d_obs, (int)s->nobs, m->d_root, depth_arg, s->d_loglik,
                            s->d_status, s->d_partial, (long)s->nsites, (long)s->nblocks);
     } else {
-        auto kern = prune_lane_kernel<N, R, false>;
+        auto kern = prune_lane_kernel<N, R, false, RESC>;
         RT_HIP(hipFuncSetAttribute((const void *)kern,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, stack));
         RT_LAUNCH_TIMED(m->ctx, kern, dim3((unsigned)s->nblocks), dim3(64), stack,
@@ -1545,6 +1634,9 @@ static int launch_lane(rt_model *m, rt_sites *s, const char **name)
         default: R = 3; RT_DMA_CASE(3); break;
         }
 #undef RT_DMA_CASE
+    } else if (s->rescale) {
+        R = 8;
+        rc = launch_lane_reg<N, 8, true>(m, s, &plds);
     } else {
         switch (R) {
         case 4: rc = launch_lane_reg<N, 4>(m, s, &plds); break;
@@ -1556,8 +1648,8 @@ static int launch_lane(rt_model *m, rt_sites *s, const char **name)
     if (s->lane_dma)
         snprintf(s->kernel_name, sizeof(s->kernel_name), "prune_lane<%d,dma,R%d,B%d,W%d>", N, R, B, W);
     else
-        snprintf(s->kernel_name, sizeof(s->kernel_name), "prune_lane<%d,%s,R%d>", N,
-                 plds ? "reg+ldsP" : "reg", R);
+        snprintf(s->kernel_name, sizeof(s->kernel_name), "prune_lane<%d,%s,R%d%s>", N,
+                 plds ? "reg+ldsP" : "reg", R, s->rescale ? ",rescale" : "");
     *name = s->kernel_name;
     return rc;
 }
@@ -1576,7 +1668,8 @@ static int launch_mfma_inst(rt_model *m, rt_sites *s)
             RT_LAUNCH_TIMED(m->ctx, kern, dim3(grid), dim3(256), lds, m->d_Pfrag,
                                (const int4_t *)s->d_lane_ops, (int)s->ops.size(), s->d_obs,
                                (int)s->nobs, m->d_root, (int)m->n, lds_slots, s->d_loglik,
-                               s->d_status, s->d_partial, (long)s->nsites, (long)s->nblocks);
+                               s->d_status, s->d_partial, (long)s->nsites, (long)s->nblocks,
+                               (int)s->rescale);
             return RT_OK;
         }
     }
@@ -1601,7 +1694,7 @@ static int launch_mfma_inst(rt_model *m, rt_sites *s)
                            m->d_Pfrag, (const int4_t *)s->d_lane_ops_a, hv.nops0,
                            s->d_obs, (int)s->nobs, m->d_root, (int)m->n, lds_slots,
                            s->d_loglik, s->d_status, s->d_partial, (long)s->nsites,
-                           (long)s->nblocks, s->d_Lout, s->d_Mout, hv);
+                           (long)s->nblocks, s->d_Lout, s->d_Mout, hv, 0);
         hipEvent_t ca = nullptr, cb = nullptr;
         rt_time_extra_begin(m->ctx, RT_K_COMBINE, "prune_mfma_combine", &ca, &cb);
         auto ckern = prune_mfma_combine_kernel<NT>;
@@ -1623,16 +1716,18 @@ static int launch_mfma_inst(rt_model *m, rt_sites *s)
                        m->d_Pfrag, (const int4_t *)s->d_lane_ops, (int)s->ops.size(),
                        s->d_obs, (int)s->nobs, m->d_root, (int)m->n, lds_slots,
                        s->d_loglik, s->d_status, s->d_partial, (long)s->nsites,
-                       (long)s->nblocks, s->d_Lout, s->d_Mout, hv);
+                       (long)s->nblocks, s->d_Lout, s->d_Mout, hv,
+                       (int)(s->rescale && !s->d_Lout));     // L and M are stored unscaled
     return RT_OK;
 }
 
 static int launch_mfma(rt_model *m, rt_sites *s, const char **name)
 {
     const int ks = ks_of(m->n);
-    snprintf(s->kernel_name, sizeof(s->kernel_name), "prune_mfma%s<%d,%d%s>",
+    snprintf(s->kernel_name, sizeof(s->kernel_name), "prune_mfma%s<%d,%d%s%s>",
              s->mfma_solo ? "_solo" : "", nt_of(m->n), ks,
-             s->interp_halves && !s->mfma_solo && !s->d_Lout ? ",halves" : "");
+             s->interp_halves && !s->mfma_solo && !s->d_Lout ? ",halves" : "",
+             s->rescale && !s->d_Lout ? ",rescale" : "");
     *name = s->kernel_name;
     switch (ks) {
     case 2: return launch_mfma_inst<1, 2>(m, s);
@@ -1683,7 +1778,7 @@ static int launch_generic(rt_model *m, rt_sites *s, const char **name)
     RT_LAUNCH_TIMED(m->ctx, prune_generic_kernel<NMAX>, dim3(grid), dim3(64), 0,    \
                        m->d_P, s->d_ops, (int)s->ops.size(), s->d_obs,             \
                        (int)s->nobs, n, np, m->d_root, s->d_loglik, s->d_status,   \
-                       s->d_partial, s->d_scratch, nsp, (long)s->nsites)
+                       s->d_partial, s->d_scratch, nsp, (long)s->nsites, (int)s->rescale)
     if (n <= 8) { *name = "prune_generic<8>"; RT_GEN(8); }
     else if (n <= 16) { *name = "prune_generic<16>"; RT_GEN(16); }
     else if (n <= 32) { *name = "prune_generic<32>"; RT_GEN(32); }

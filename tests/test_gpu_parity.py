@@ -1052,6 +1052,89 @@ def test_underflow_is_reported_not_hidden(ra):
     assert wst.all() and np.all(np.isneginf(ll))
 
 
+def _extended_log_likelihoods(tree, esd, leaf_idx, states, n, root_w):
+    """Felsenstein pruning in np.longdouble (x87 extended: exponent range 2^-16445) on the
+    device's own transition matrices -- what the f64 recursion would give without underflow."""
+    ld = np.longdouble
+    nsites = states.shape[0]
+    L = [None] * tree.nnodes
+    col = dict((v, k) for k, v in enumerate(leaf_idx))
+    for v in range(tree.nnodes - 1, -1, -1):
+        x = np.ones((nsites, n), dtype=ld)
+        if v in col:
+            s = states[:, col[v]]
+            obs = s != 255
+            x[obs] = 0
+            x[np.nonzero(obs)[0], s[obs]] = 1
+        for c in tree.indices[tree.indptr[v]:tree.indptr[v + 1]]:
+            x = x * (L[c] @ esd[c].astype(ld).T)
+            L[c] = None
+        L[v] = x
+    lik = L[0] @ np.asarray(root_w, dtype=ld)
+    return np.log(lik).astype(np.float64)
+
+
+@pytest.mark.parametrize('n,generic', [(2, False), (4, False), (13, False), (20, False),
+                                       (61, False), (100, False), (4, True), (20, True)])
+def test_opt_in_rescaling_recovers_likelihoods_below_the_f64_range(ra, n, generic):
+    """'rescale' (rt_ctx_set_option): the interpreter kernels multiply a site's messages by an
+    exact power of two whenever their largest entry falls below 2^-256 and carry the exponent
+    per site.  The reference has no rescaling: a 1 024-leaf tree is zero
+    probability there and, by default, here (test_underflow_is_reported_not_hidden); with the
+    option the log-likelihoods are those of an extended-precision recursion, and a batch that
+    never comes near the threshold gets the default kernels' numbers bit for bit."""
+    rng = np.random.RandomState(600 + n)
+    nleaves = 2048 if n <= 4 else 1024 if n <= 20 else 256
+    T, root, leaves = ra.synth.balanced_tree(nleaves, seed=n)
+    for a, b in T.edges():
+        T[a][b]['weight'] *= 8.0            # long branches: little signal, tiny likelihoods
+    Q = rng.uniform(0.1, 1.0, size=(n, n))
+    np.fill_diagonal(Q, 0.0)
+    Q -= np.diag(Q.sum(axis=1))
+    pi = rng.dirichlet(np.ones(n))
+    nsites = 150
+    states = rng.randint(0, n, size=(nsites, nleaves)).astype(np.uint8)
+    states[rng.uniform(size=states.shape) < 0.03] = 255
+    small = states[:, :8].copy()            # an 8-leaf problem: nowhere near the threshold
+    T8, root8, leaves8 = ra.synth.balanced_tree(8, seed=n)
+    got = {}
+    for rescale in (0, 1):
+        ra.ctx.set_option('rescale', rescale)
+        ra.ctx.set_option('force_generic', 1 if generic else None)
+        try:
+            model = ra.device.TreeModel(T, root, n)
+            model.set_root_distn(pi)
+            model.set_rates(Q_default=Q)
+            batch = model.upload_sites(leaves, states, kind='state')
+            ll, st = model.log_likelihoods(batch)
+            tot = model.fetch_totals(batch)
+            m8 = ra.device.TreeModel(T8, root8, n)
+            m8.set_root_distn(pi)
+            m8.set_rates(Q_default=Q)
+            b8 = m8.upload_sites(leaves8, small, kind='state')
+            got[rescale] = (ll, st, batch.kernel_name, tot, m8.log_likelihoods(b8)[0],
+                            b8.kernel_name)
+            if rescale:
+                esd = model.get_transitions()
+                want = _extended_log_likelihoods(
+                    model.tree, esd, [model.tree.node_to_index[v] for v in leaves], states, n, pi)
+            b8.close(); m8.close(); batch.close(); model.close()
+        finally:
+            ra.ctx.set_option('rescale', None)
+            ra.ctx.set_option('force_generic', None)
+    # default: the f64 recursion underflows, every site is reported as zero probability
+    assert np.all(np.isneginf(got[0][0])) and np.all(got[0][1] & 1)
+    ll, st, name, tot, ll8, name8 = got[1]
+    assert 'rescale' in name or name.startswith('prune_generic'), name
+    assert np.all(st == 0)
+    assert want.max() < -745.0              # log of the smallest subnormal: all below the range
+    np.testing.assert_allclose(ll, want, rtol=RTOL_LL)
+    assert tot[1] == 0 and abs(tot[0] - want.sum()) <= 1e-10 * abs(want.sum())
+    # exact powers of two: a batch that never rescales is untouched
+    assert 'jit' not in name8
+    np.testing.assert_array_equal(ll8, got[0][4])
+
+
 def test_expected_history_statistics(ra):
     """_mjp_dense.get_expected_history_statistics (:410-539) and its sparse twin
     (_mjp.py:431-595) on the device -- one Frechet block exponential per edge by
