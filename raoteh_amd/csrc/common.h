@@ -97,6 +97,7 @@ struct rt_ctx {
     size_t expm_attr_lds = 0;      // dynamic-LDS attribute already granted to expm_kernel
     size_t expm_ts_attr_lds[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ... to the Taylor kernels (per NT)
     size_t expm_split_attr_lds = 0;                           // ... to the two-workgroup form
+    size_t expm_wide_attr_lds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     double *d_expm_scratch = nullptr;   // matrices of the order > 64 Taylor kernel (grow-only)
     void *expect_cache = nullptr;       // expect_mfma.hip: model + packed batch of the last call
     hipStream_t stream2 = nullptr;      // side stream of two-kernel pruning launches (lazy)
@@ -293,6 +294,11 @@ struct rt_reduce_args {
     double *totals = nullptr;          // [3]
     double nsites = 0.0;
 };
+// expm_wide.hip: the LDS-resident Taylor kernel for 64 < n <= 128 (scratch: ctx->d_expm_scratch)
+int rt_expm_wide_launch(rt_ctx *ctx, int nt, bool split2, size_t grid, int64_t n, const double *d_Q,
+                        const int *d_qidx, const double *d_t, double *d_P, int *d_info,
+                        const int *d_step_of_node, int frag_kind, double *d_Pfrag,
+                        const rt_reduce_args &red);
 int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
                    const int32_t *d_qidx, const double *d_t, double *d_P,
                    int32_t *d_info, const int32_t *d_step_of_node, int frag_kind,

@@ -578,9 +578,10 @@ __device__ __forceinline__ void mm_blocked(const double *X, const double *Y, dou
                     for (int r = 0; r < 4; ++r) {
                         const int row = 16 * m + 4 * r + lq;
                         const int o = row * LD + col;
+                        // (explicit fma: the same contraction in every variant of the kernel)
                         double w = c1 * (R1 ? R1->v[u][v][r] : P1[o]);
-                        if (R2) w += c2 * R2->v[u][v][r];
-                        else if (P2) w += c2 * P2[o];
+                        if (R2) w = fma(c2, R2->v[u][v][r], w);
+                        else if (P2) w = fma(c2, P2[o], w);
                         // the identity only inside n x n: P1 (= A) is zero outside, so
                         // the diagonal of the padding stays as cf[3] says (0 or c0)
                         if (row == col && (double)row < cf[3]) w += c0;
@@ -634,10 +635,12 @@ __device__ __forceinline__ void mm_blocked(const double *X, const double *Y, dou
                     C[row * LD + col] = acc[u][v][r];
                     // the top block of the polynomial from the product just made (A^3) and
                     // the register copies of A and A^2: top = {c0, c1, c2, c3, n}
-                    if (top)
-                        C2[row * LD + col] = top[1] * R1->v[u][v][r] + top[2] * R2->v[u][v][r] +
-                                             top[3] * acc[u][v][r] +
-                                             ((row == col && (double)row < top[4]) ? top[0] : 0.0);
+                    if (top) {
+                        double w = top[1] * R1->v[u][v][r];
+                        w = fma(top[2], R2->v[u][v][r], w);
+                        w = fma(top[3], acc[u][v][r], w);
+                        C2[row * LD + col] = w + ((row == col && (double)row < top[4]) ? top[0] : 0.0);
+                    }
                 }
             }
     __syncthreads();
@@ -701,7 +704,7 @@ __device__ __forceinline__ void mm_half(const double *X, const double *Y, double
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * wave + 4 * r + lq;
             double w = c1 * R1.v[v][r];
-            w += c2 * R2.v[v][r];
+            w = fma(c2, R2.v[v][r], w);
             if (row == col && (double)row < nd) w += c0;
             acc[v][r] = w;
         }
@@ -1344,6 +1347,26 @@ int rt_launch_expm(rt_ctx *ctx, int64_t n, int64_t count, const double *d_Q,
                 ctx->expm_scratch_bytes = need;
             }
             scratch = ctx->d_expm_scratch;
+        }
+        // 64 < n <= 128: the LDS-resident kernel (one matrix in LDS, the rest in registers);
+        // RAOTEH_EXPM_WIDE=0: the global-scratch form.  Few matrices: two workgroups each
+        const char *wv = getenv("RAOTEH_EXPM_WIDE");
+        if (global && !(wv && atoi(wv) == 0) && !d_Pquad) {
+            bool split2 = 2 * count + extra <= (int64_t)std::max(2, ctx->num_cus);
+            if (const char *v = getenv("RAOTEH_EXPM_SPLIT")) split2 = atoi(v) != 0;
+            const size_t wgs = (size_t)count * (split2 ? 2 : 1);
+            const size_t need = wgs * ((nt + 1) / 2) * 4 * nt * 256 * 8;   // A, A^2 in D layout per workgroup
+            if (need > ctx->expm_scratch_bytes) {
+                RT_HIP(hipStreamSynchronize(ctx->stream));
+                hipFree(ctx->d_expm_scratch);
+                ctx->d_expm_scratch = nullptr;
+                ctx->expm_scratch_bytes = 0;
+                RT_HIP(hipMalloc((void **)&ctx->d_expm_scratch, need));
+                ctx->expm_scratch_bytes = need;
+            }
+            RT_TRY(rt_expm_wide_launch(ctx, nt, split2, wgs + extra, n, d_Q, d_qidx, d_t, d_P, d_info,
+                                       d_step_of_node, frag_kind, d_Pfrag, red));
+            return RT_OK;
         }
         hipEvent_t ev = nullptr;
         rt_time_begin(ctx, RT_K_EXPM, global ? "expm_taylor_ps_mfma_global" : "expm_taylor_ps_mfma",

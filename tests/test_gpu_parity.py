@@ -256,6 +256,45 @@ def test_expm_orders_above_64_through_global_scratch(ra):
     np.testing.assert_allclose(got[:n, n:], want_L, rtol=1e-10, atol=1e-13)
 
 
+@pytest.mark.parametrize('n', [65, 80, 81, 100, 112, 122, 128])
+def test_lds_resident_expm_above_64_is_bit_identical_to_the_global_form(ra, n, monkeypatch):
+    """expm_wide.hip (one matrix in LDS in B-fragment order, A operands and accumulators in
+    registers; two workgroups per matrix when the matrices are few) against the global-scratch
+    kernel it replaces: the same arithmetic per entry, so the same bits -- one workgroup per
+    matrix and two, without and with squarings, several rate matrices (the root slot of a
+    model's launch: the tree tests at n > 64)."""
+    rng = np.random.RandomState(900 + n)
+    nq = 3
+    Q = rng.exponential(size=(nq, n, n)) * (rng.uniform(size=(nq, n, n)) < 0.3)
+    for q in Q:
+        np.fill_diagonal(q, 0)
+        q -= np.diag(q.sum(axis=1))
+        q /= np.abs(np.diag(q)).max()
+    count = 11
+    t = np.concatenate([[1e-6, 0.004, 0.04, 0.12, 0.3], rng.uniform(0.3, 9.0, size=count - 5)])
+    qidx = rng.randint(0, nq, size=count)
+    out = {}
+    for wide, split in ((0, 0), (1, 0), (1, 1)):
+        monkeypatch.setenv('RAOTEH_EXPM_WIDE', str(wide))
+        monkeypatch.setenv('RAOTEH_EXPM_SPLIT', str(split))
+        out[wide, split] = ra.ctx.expm(Q, t, q_index=qidx, return_info=True)
+        ra.ctx.set_timing(True)
+        ra.ctx.expm(Q, t, q_index=qidx)
+        name = ra.ctx.kernel_time(0)[2]
+        ra.ctx.set_timing(False)
+        assert name == ('expm_taylor_ps_mfma_global' if not wide else
+                        'expm_taylor_ps_mfma_wide_split2' if split else 'expm_taylor_ps_mfma_wide')
+    monkeypatch.delenv('RAOTEH_EXPM_WIDE')
+    monkeypatch.delenv('RAOTEH_EXPM_SPLIT')
+    P0, info0 = out[0, 0]
+    assert info0[:, 1].max() >= 2 and info0[:5, 1].min() == 0 and len(set(info0[:, 0])) >= 3
+    for key in ((1, 0), (1, 1)):
+        np.testing.assert_array_equal(out[key][1], info0)
+        np.testing.assert_array_equal(out[key][0], P0)
+    k = 6
+    np.testing.assert_allclose(P0[k], orc.custom_expm(Q[qidx[k]], t[k]), rtol=1e-9, atol=1e-13)
+
+
 def test_expm_shared_q_and_errors(ra):
     Q, _ = ra.synth.hky85()
     t = np.linspace(0.01, 2.0, 50)
