@@ -500,6 +500,57 @@ def test_sum_to_one(ra):
     assert np.exp(ll).sum() == pytest.approx(1.0, rel=1e-11)
 
 
+@pytest.mark.parametrize('nprimary,parts', [(6, (0, 0, 1, 1, 2, 2)), (5, (0, 0, 0, 1, 1)),
+                                            (6, (0, 1, 2, 3, 3, 3))])
+def test_compound_tolerance_model_leaf_marginals_sum_to_one(ra, nprimary, parts):
+    """The reference's tests/test_tmjp.py:201-283 (slow there: one get_likelihood call per
+    leaf pattern): on its 6-node tree the probabilities of ALL nprimary^4 primary-state leaf
+    patterns under the compound tolerance process add up to one.  Here the patterns are one
+    batch of allowed-set masks (48 / 20 / 96 compound states: split-M, one-wave and two-word
+    kernels), every pattern also against the oracle."""
+    import itertools
+    rng = np.random.RandomState(40 + nprimary + len(set(parts)))
+    Qp = rng.exponential(size=(nprimary, nprimary))
+    np.fill_diagonal(Qp, 0.0)
+    Qp -= np.diag(Qp.sum(axis=1))
+    pd = rng.dirichlet(np.ones(nprimary))
+    primary_to_part = dict(enumerate(parts))
+    Qc, dc = ra.synth.blinking_model(Qp, pd, primary_to_part, 0.5, 1.5)    # rate_on, rate_off (:206-207)
+    n = Qc.shape[0]
+    assert n == nprimary * 2 ** len(set(parts)) and dc.sum() == pytest.approx(1.0, rel=1e-12)
+    T = nx.Graph()
+    for a, b in ((0, 1), (0, 2), (0, 3), (3, 4), (3, 5)):                  # :226-231
+        T.add_edge(a, b, weight=rng.exponential(scale=0.1))
+    leaves = [1, 2, 4, 5]
+    patterns = np.array(list(itertools.product(range(nprimary), repeat=4)))
+    words = (n + 63) // 64
+    per_state = np.zeros((nprimary, words), dtype=np.uint64)
+    for c in range(nprimary):
+        for k in ra.synth.blinking_allowed_states(c, nprimary, primary_to_part):
+            per_state[c, k // 64] |= np.uint64(1) << np.uint64(k % 64)
+    masks = per_state[patterns]                                            # [nsites][4][words]
+    ll, st = ra.mjp.get_log_likelihoods(T, 0, n, leaves, masks, kind='mask', root_distn=dc,
+                                        Q_default=Qc)
+    assert not st.any()
+    assert np.exp(ll).sum() == pytest.approx(1.0, rel=1e-11)
+    pre, idx, ptr, esd = orc.get_expm_augmented_transitions(T, 0, n, Q_default=Qc)
+    dense = np.zeros((len(patterns), 4, n))
+    for c in range(nprimary):
+        ii, kk = np.nonzero(patterns == c)
+        for a in ra.synth.blinking_allowed_states(c, nprimary, primary_to_part):
+            dense[ii, kk, a] = 1.0
+    want, wst = orc.batch_log_likelihoods(idx, ptr, esd, [pre.index(v) for v in leaves], dense, dc)
+    assert not wst.any()
+    np.testing.assert_allclose(ll, want, rtol=RTOL_LL)
+    # the reference's single-site call on a few patterns
+    for k in (0, len(patterns) // 3, len(patterns) - 1):
+        allowed = dict((v, set(range(n))) for v in T)
+        for leaf, c in zip(leaves, patterns[k]):
+            allowed[leaf] = set(ra.synth.blinking_allowed_states(c, nprimary, primary_to_part))
+        lk = ra.mjp.get_likelihood(T, allowed, 0, n, root_distn=dc, Q_default=Qc)
+        assert np.log(lk) == pytest.approx(ll[k], rel=1e-10)
+
+
 def test_kat_four_log_half(ra):
     fx = load_golden('kat_history')               # tests/test_mc.py:131-150
     T = tree_from_edges(fx['edges'])
