@@ -823,6 +823,7 @@ extern "C" int rt_sites_destroy(rt_sites *s)
     hipFree(s->d_raw_src);
     if (!s->obs_borrowed) hipFree(s->d_obs);
     hipFree(s->d_ops); hipFree(s->d_lane_ops); hipFree(s->d_lane_ops_a); hipFree(s->d_lane_ops_b); hipFree(s->d_loglik); hipFree(s->d_status);
+    hipFree(s->d_down_meta);
     if (s->model->ctx->comm_stream) hipStreamSynchronize(s->model->ctx->comm_stream);
     hipFree(s->d_partial); hipFree(s->d_partial_alt); hipFree(s->d_scratch); hipFree(s->d_half);
     hipFree(s->d_half_count);

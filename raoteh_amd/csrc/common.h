@@ -237,6 +237,9 @@ struct rt_sites {
     // (interpreter kernels only; such a batch never gets a tree-specialised kernel)
     bool rescale = false;
     int32_t *d_lane_ops_a = nullptr, *d_lane_ops_b = nullptr;
+    // expectation path (expect_mfma.hip): per step {slot of the parent's D, own slot or -1}
+    int32_t *d_down_meta = nullptr;
+    int down_slots = 0;
     int half_nops[2] = {0, 0};
     int half_rec1 = 0, half_kobs1 = 0, half_kroot = -1;
     // not owned: where the split-M interpreter kernel leaves L_v and M_v of every step

@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstring>
 #include <memory>
 #include <vector>
 
@@ -136,7 +137,146 @@ expect_down_kernel(const double *__restrict__ PfragT, int nops, const int *__res
     if (bad && site < nsites) atomicOr(&status[site], 2);
 }
 
-// W partial of one edge (= step) and one chunk of site tiles: wave ma holds row tile ma of W
+// The downward pass with the posterior marginals of the inner nodes in LDS.  The kernel above
+// reads D of the parent back from HBM at every step and fetches M, L and the A fragments of a
+// step when it gets there: 126 dependent round trips per tile (870 us at 10 000 codon sites for
+// a pass whose products take 85).  Here
+//   * D_v of an inner node lives in an LDS slot (own rows: 4 doubles per lane, read and written
+//     by the same lane, so no barrier) -- the slot the upward pass kept v's accumulator in: read
+//     backwards, the accumulator's lifetime (first child .. v's own step) is exactly D_v's
+//     (v's step .. first child), so the upward schedule's slots never collide here either;
+//   * M, L and the A fragments of the next step are requested before this step's work;
+//   * the highest slot (the deepest inner nodes: the most frequent) is four registers, so that a
+//     64-leaf balanced tree needs 5 slots + the exchange buffer = 48 KB and three workgroups
+//     share a CU: 625 tiles are then one round on 256 CUs, not two;
+//   * only U (the site sums read it) and the root's D leave the CU.
+// meta[i] = {slot of the parent's D, own slot (-1: a leaf)}; regslot: the slot kept in registers.
+template <int NT, int KS>
+__global__ void __launch_bounds__(64 * NT)
+expect_down_lds_kernel(const double *__restrict__ PfragT, int nops, const int2 *__restrict__ meta,
+                       const double *__restrict__ Larr, const double *__restrict__ Marr,
+                       double *__restrict__ Darr, double *__restrict__ Uarr,
+                       const double *__restrict__ root_w, int n, int *__restrict__ status, long nsites,
+                       long nblocks, int regslot)
+{
+    constexpr int KP = (KS + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) double down_sm[];
+    double *xb = down_sm;                          // [NT * 4 * 64]
+    double *slots = down_sm + NT * 256;            // [slot < regslot][NT][4][64]
+    // the step table in LDS (read from global at the top of every step it was a dependent
+    // round trip per step)
+    int2 *smeta = (int2 *)(slots + (size_t)regslot * NT * 256);
+    for (int i = threadIdx.x; i < nops; i += 64 * NT) smeta[i] = meta[i];
+    double regD[4] = {0.0, 0.0, 0.0, 0.0};
+    __shared__ double red[NT][16];
+    const int lane = threadIdx.x & 63;
+    const int m = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long blk = blockIdx.x;
+    const size_t tile_stride = (size_t)NT * 256;
+    auto at = [&](int step) { return ((size_t)step * nblocks + blk) * tile_stride + (m * 4) * 64 + lane; };
+    auto slot = [&](int sidx) { return slots + ((size_t)(sidx < regslot ? sidx : 0) * NT + m) * 256 + lane; };
+    bool bad = false;
+    // root: D = w L / sum_states(w L)  (_mc0_dense.py:400-489 with the prior weights)
+    {
+        const int i = nops - 1;
+        const size_t o = at(i);
+        double wl[4], s = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * m + 4 * r + (lane >> 4);
+            const double w = row < n ? (root_w ? root_w[row] : 1.0) : 0.0;
+            wl[r] = w * Larr[o + r * 64];
+            s += wl[r];
+        }
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (lane < 16) red[m][lane] = s;
+        __syncthreads();
+        double tot = 0.0;
+#pragma unroll
+        for (int mm = 0; mm < NT; ++mm) tot += red[mm][lane & 15];
+        if (!(tot > 0.0)) bad = true;
+        const int own = smeta[i].y;              // (after the barrier above: the table is there)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double d = tot > 0.0 ? wl[r] / tot : 0.0;
+            Darr[o + r * 64] = d;
+            if (own == regslot) regD[r] = d;
+            else if (own >= 0) slot(own)[r * 64] = d;
+        }
+    }
+    const double *ag = PfragT + ((size_t)m * KP * 64 + lane) * 2;
+    constexpr size_t ASTRIDE = (size_t)NT * KP * 128;
+    // what step i needs from HBM: M (every step), L and the A fragments (inner nodes)
+    double Mc[4], Lc[4], Ac[2 * KP];
+    auto fetch = [&](int i, double (&M4)[4], double (&L4)[4], double (&A)[2 * KP]) {
+        const size_t o = at(i);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) M4[r] = Marr[o + r * 64];
+        if (smeta[i].y >= 0) {                   // (uniform)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) L4[r] = Larr[o + r * 64];
+#pragma unroll
+            for (int q = 0; q < KP; ++q) {
+                const double2 v = *(const double2 *)(ag + (size_t)i * ASTRIDE + q * 128);
+                A[2 * q] = v.x;
+                A[2 * q + 1] = v.y;
+            }
+        }
+    };
+    if (nops >= 2) fetch(nops - 2, Mc, Lc, Ac);
+    for (int i = nops - 2; i >= 0; --i) {
+        const int2 mt = smeta[i];
+        double Mn[4], Ln[4], An[2 * KP];
+        if (i > 0) fetch(i - 1, Mn, Ln, An);
+        const size_t o = at(i);
+        const double *ps = slot(mt.x);
+        double u[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double dp = mt.x == regslot ? regD[r] : ps[r * 64];
+            u[r] = 0.0;
+            if (dp != 0.0) {
+                if (Mc[r] > 0.0) u[r] = dp / Mc[r];
+                else bad = true;
+            }
+            Uarr[o + r * 64] = u[r];
+        }
+        if (mt.y >= 0) {                         // an inner node: D_v = (P_v^T u) * L_v
+            __syncthreads();                     // the previous product's operands are read
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xb[(4 * m + r) * 64 + lane] = u[r];
+            __syncthreads();
+            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ac[kk], xb[kk * 64 + lane], acc, 0, 0, 0);
+            if (mt.y == regslot) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) regD[r] = acc[r] * Lc[r];
+            } else {
+                double *os = slot(mt.y);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) os[r * 64] = acc[r] * Lc[r];
+            }
+        }
+        if (i > 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { Mc[r] = Mn[r]; Lc[r] = Ln[r]; }
+#pragma unroll
+            for (int q = 0; q < 2 * KP; ++q) Ac[q] = An[q];
+        }
+    }
+    const long site = blk * 16 + (lane & 15);
+    if (bad && site < nsites) atomicOr(&status[site], 2);
+}
+
+// W partial of one edge (= step) and one chunk of site tiles: wave ma holds row tile ma of W.
+// K = the 16 sites of a tile, four per MFMA: k-lane hi of k-step ks is site 4 hi + ks, so that
+// the four k-steps' operands of a lane are 32 contiguous bytes of the D-layout arrays (state
+// 16 M + x, site t at (M * 4 + x / 4) * 64 + 16 (x % 4) + t) -- one double4 per array and row
+// tile instead of four scattered doubles, and the next tile's are requested before this tile's
+// MFMAs (the kernel was a chain of load -> wait -> MFMA: 780 us for 1.3 GB at 10 000 codon sites).
 template <int NT>
 __global__ void __launch_bounds__(64 * NT)
 expect_wsum_kernel(int nops, const double *__restrict__ Uarr, const double *__restrict__ Larr,
@@ -150,24 +290,39 @@ expect_wsum_kernel(int nops, const double *__restrict__ Uarr, const double *__re
     const long t0 = chunk * per, t1 = t0 + per < nblocks ? t0 + per : nblocks;
     const size_t tile_stride = (size_t)NT * 256;
     const int lo = lane & 15, hi = lane >> 4;
-    // element (state 16 M + x, site t) of a tile sits at (M * 4 + x / 4) * 64 + 16 (x % 4) + t
-    const int row_off = (lo >> 2) * 64 + 16 * (lo & 3);
+    const int row_off = (lo >> 2) * 64 + 16 * (lo & 3) + 4 * hi;
     double4_t acc[NT];
 #pragma unroll
     for (int mb = 0; mb < NT; ++mb) acc[mb] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    for (long tile = t0; tile < t1; ++tile) {
-        const double *Ut = Uarr + ((size_t)step * nblocks + tile) * tile_stride;
-        const double *Lt = Larr + ((size_t)step * nblocks + tile) * tile_stride;
+    if (t0 < t1) {
+        const double *Ub = Uarr + (size_t)step * nblocks * tile_stride + ma * 256 + row_off;
+        const double *Lb = Larr + (size_t)step * nblocks * tile_stride + row_off;
+        auto fetch = [&](long tile, double4_t &u, double4_t (&l)[NT], double4_t &w) {
+            u = *(const double4_t *)(Ub + (size_t)tile * tile_stride);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const long site = tile * 16 + 4 * ks + hi;
-            const double w = site < nsites ? (weights ? weights[site] : 1.0) : 0.0;
-            const double av = Ut[ma * 256 + row_off + 4 * ks + hi] * w;     // U[16 ma + lo][site]
+            for (int mb = 0; mb < NT; ++mb)
+                l[mb] = *(const double4_t *)(Lb + (size_t)tile * tile_stride + mb * 256);
+            const long site = tile * 16 + 4 * hi;
 #pragma unroll
-            for (int mb = 0; mb < NT; ++mb) {
-                const double bv = Lt[mb * 256 + row_off + 4 * ks + hi];     // L[16 mb + lo][site]
-                acc[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[mb], 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks)
+                w[ks] = site + ks < nsites ? (weights ? weights[site + ks] : 1.0) : 0.0;
+        };
+        double4_t uc, lc[NT], wc;
+        fetch(t0, uc, lc, wc);
+        for (long tile = t0; tile < t1; ++tile) {
+            double4_t un, ln[NT], wn;
+            fetch(tile + 1 < t1 ? tile + 1 : tile, un, ln, wn);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const double av = uc[ks] * wc[ks];                 // U[16 ma + lo][site] w
+#pragma unroll
+                for (int mb = 0; mb < NT; ++mb)                      // L[16 mb + lo][site]
+                    acc[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, lc[mb][ks], acc[mb], 0, 0, 0);
             }
+            uc = un;
+            wc = wn;
+#pragma unroll
+            for (int mb = 0; mb < NT; ++mb) lc[mb] = ln[mb];
         }
     }
     double *out = partial + (((size_t)step * EX_CHUNKS + chunk) * NT + ma) * NT * 256;
@@ -227,13 +382,13 @@ expect_root_kernel(int n, int NT, int root_step, const double *__restrict__ Darr
 __global__ void __launch_bounds__(256)
 expect_root_finish_kernel(int n, const double *__restrict__ rootpart, double *__restrict__ W)
 {
-    for (int e = threadIdx.x; e < n * n; e += 256) {
-        const int a = e / n, b = e - a * n;
-        double sum = 0.0;
-        if (b == 0)
-            for (int c = 0; c < EX_ROOT_CHUNKS; ++c) sum += rootpart[c * 64 + a];
-        W[e] = sum;
-    }
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * n) return;
+    const int a = e / n, b = e - a * n;
+    double sum = 0.0;
+    if (b == 0)
+        for (int c = 0; c < EX_ROOT_CHUNKS; ++c) sum += rootpart[c * 64 + a];
+    W[e] = sum;
 }
 
 struct dev_free {
@@ -314,16 +469,46 @@ int expect_device_passes(rt_ctx *ctx, rt_model *model, rt_sites *s, const double
     RT_TRY(rc);
     if (trace) hipStreamSynchronize(st);
     RT_HIP(hipMemsetAsync(d_status, 0, (size_t)nsites * 4, st));
-    hipLaunchKernelGGL((expect_down_kernel<NT, KS>), dim3((unsigned)nblocks), dim3(64 * NT), 0, st,
-                       d_PT, nops, d_parent_step, d_internal, d_L, d_M, d_D, d_U, d_root_w, (int)n,
-                       d_status, (long)nsites, nblocks);
+    // the LDS form of the downward pass when the slots of the tree fit (RAOTEH_EXPECT_DOWN=global:
+    // the first form, D through HBM)
+    if (!s->d_down_meta) {
+        std::vector<int32_t> meta((size_t)nops * 2);
+        int nslots = 0;
+        for (int i = 0; i < nops; ++i) {
+            const rt_op &op = s->ops[(size_t)i];
+            meta[(size_t)i * 2] = op.dst >= 0 ? (op.dst & 255) : 0;
+            meta[(size_t)i * 2 + 1] = op.pop;
+            if (op.dst >= 0) nslots = std::max(nslots, (op.dst & 255) + 1);
+            if (op.pop >= 0) nslots = std::max(nslots, op.pop + 1);
+        }
+        RT_HIP(hipMalloc((void **)&s->d_down_meta, meta.size() * 4));
+        RT_HIP(hipMemcpyAsync(s->d_down_meta, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, st));
+        RT_HIP(hipStreamSynchronize(st));            // (meta is a local)
+        s->down_slots = std::max(nslots, 1);
+    }
+    const int regslot = s->down_slots - 1;           // the deepest slot: registers
+    const size_t down_lds = (size_t)(1 + regslot) * NT * 256 * 8 + (size_t)nops * 8;
+    const char *dv = getenv("RAOTEH_EXPECT_DOWN");
+    if (down_lds <= 120 * 1024 && !(dv && strcmp(dv, "global") == 0)) {
+        auto kern = expect_down_lds_kernel<NT, KS>;
+        RT_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)down_lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(64 * NT), down_lds, st, d_PT, nops,
+                           (const int2 *)s->d_down_meta, d_L, d_M, d_D, d_U, d_root_w, (int)n, d_status,
+                           (long)nsites, nblocks, regslot);
+    } else {
+        hipLaunchKernelGGL((expect_down_kernel<NT, KS>), dim3((unsigned)nblocks), dim3(64 * NT), 0, st,
+                           d_PT, nops, d_parent_step, d_internal, d_L, d_M, d_D, d_U, d_root_w, (int)n,
+                           d_status, (long)nsites, nblocks);
+    }
     hipLaunchKernelGGL((expect_wsum_kernel<NT>), dim3((unsigned)(nops - 1), EX_CHUNKS), dim3(64 * NT),
                        0, st, nops, d_U, d_L, d_w, (long)nsites, nblocks, d_part);
     hipLaunchKernelGGL(expect_finish_kernel, dim3((unsigned)(nops - 1)), dim3(256), 0, st, (int)n, NT,
                        nops, d_step_node, esd_dev, d_part, d_W);
     hipLaunchKernelGGL(expect_root_kernel, dim3(EX_ROOT_CHUNKS), dim3(64), 0, st, (int)n, NT, nops - 1,
                        d_D, d_w, (long)nsites, nblocks, d_rootpart);
-    hipLaunchKernelGGL(expect_root_finish_kernel, dim3(1), dim3(256), 0, st, (int)n, d_rootpart, d_W);
+    hipLaunchKernelGGL(expect_root_finish_kernel, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, st,
+                       (int)n, d_rootpart, d_W);
     RT_HIP(hipGetLastError());
     return RT_OK;
 }
