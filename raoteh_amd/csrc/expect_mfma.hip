@@ -151,8 +151,9 @@ expect_down_kernel(const double *__restrict__ PfragT, int nops, const int *__res
 //     share a CU: 625 tiles are then one round on 256 CUs, not two;
 //   * only U (the site sums read it) and the root's D leave the CU.
 // meta[i] = {slot of the parent's D, own slot (-1: a leaf)}; regslot: the slot kept in registers.
+// (three workgroups per CU is what the slot budget above is for: the registers must allow it too)
 template <int NT, int KS>
-__global__ void __launch_bounds__(64 * NT)
+__global__ void __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(3, 3)))
 expect_down_lds_kernel(const double *__restrict__ PfragT, int nops, const int2 *__restrict__ meta,
                        const double *__restrict__ Larr, const double *__restrict__ Marr,
                        double *__restrict__ Darr, double *__restrict__ Uarr,
@@ -207,29 +208,42 @@ expect_down_lds_kernel(const double *__restrict__ PfragT, int nops, const int2 *
     }
     const double *ag = PfragT + ((size_t)m * KP * 64 + lane) * 2;
     constexpr size_t ASTRIDE = (size_t)NT * KP * 128;
-    // what step i needs from HBM: M (every step), L and the A fragments (inner nodes)
-    double Mc[4], Lc[4], Ac[2 * KP];
-    auto fetch = [&](int i, double (&M4)[4], double (&L4)[4], double (&A)[2 * KP]) {
-        const size_t o = at(i);
+    // What step i needs from memory: M (every step) and L (inner nodes) from HBM, requested
+    // two steps ahead, the A fragments (L2) one step ahead.  Named buffers, the loop unrolled,
+    // running pointers: nothing in flight is ever copied (a register copy of a
+    // pending load waits for it) and no address is computed into a borrowed register.
+    const size_t step_stride = (size_t)nblocks * tile_stride;
+    const double *pM = Marr + at(nops - 2), *pL = Larr + at(nops - 2);     // the fetch stream
+    double *pU = Uarr + at(nops - 2);                                      // the current step
+    const double *pA = ag + (size_t)(nops - 2) * ASTRIDE;
+    int fi = nops - 2;                           // next step to fetch M / L of
+    auto fetch_ml = [&](double (&M4)[4], double (&L4)[4]) {
+        if (fi >= 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) M4[r] = Marr[o + r * 64];
-        if (smeta[i].y >= 0) {                   // (uniform)
+            for (int r = 0; r < 4; ++r) M4[r] = pM[r * 64];
+            if (smeta[fi].y >= 0) {              // (uniform)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) L4[r] = Larr[o + r * 64];
+                for (int r = 0; r < 4; ++r) L4[r] = pL[r * 64];
+            }
+        }
+        pM -= step_stride;
+        pL -= step_stride;
+        fi -= 1;
+    };
+    auto fetch_a = [&](int i, double (&A)[2 * KP]) {
+        if (i >= 0 && smeta[i].y >= 0) {
 #pragma unroll
             for (int q = 0; q < KP; ++q) {
-                const double2 v = *(const double2 *)(ag + (size_t)i * ASTRIDE + q * 128);
+                const double2 v = *(const double2 *)(pA + q * 128);
                 A[2 * q] = v.x;
                 A[2 * q + 1] = v.y;
             }
         }
+        pA -= ASTRIDE;
     };
-    if (nops >= 2) fetch(nops - 2, Mc, Lc, Ac);
-    for (int i = nops - 2; i >= 0; --i) {
+    // one step: u = D_parent / M, U out, and for an inner node D = (P^T u) * L into its slot
+    auto step = [&](int i, const double (&Mc)[4], const double (&Lc)[4], const double (&Ac)[2 * KP]) {
         const int2 mt = smeta[i];
-        double Mn[4], Ln[4], An[2 * KP];
-        if (i > 0) fetch(i - 1, Mn, Ln, An);
-        const size_t o = at(i);
         const double *ps = slot(mt.x);
         double u[4];
 #pragma unroll
@@ -240,9 +254,10 @@ expect_down_lds_kernel(const double *__restrict__ PfragT, int nops, const int2 *
                 if (Mc[r] > 0.0) u[r] = dp / Mc[r];
                 else bad = true;
             }
-            Uarr[o + r * 64] = u[r];
+            pU[r * 64] = u[r];
         }
-        if (mt.y >= 0) {                         // an inner node: D_v = (P_v^T u) * L_v
+        pU -= step_stride;
+        if (mt.y >= 0) {
             __syncthreads();                     // the previous product's operands are read
 #pragma unroll
             for (int r = 0; r < 4; ++r) xb[(4 * m + r) * 64 + lane] = u[r];
@@ -260,76 +275,173 @@ expect_down_lds_kernel(const double *__restrict__ PfragT, int nops, const int2 *
                 for (int r = 0; r < 4; ++r) os[r * 64] = acc[r] * Lc[r];
             }
         }
-        if (i > 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { Mc[r] = Mn[r]; Lc[r] = Ln[r]; }
-#pragma unroll
-            for (int q = 0; q < 2 * KP; ++q) Ac[q] = An[q];
-        }
+    };
+    // (three M / L buffers = two steps ahead, two A buffers, unrolled by six: with four buffers
+    // the kernel needs 188 registers -- two workgroups per CU, 625 tiles in two rounds)
+    double M0[4], L0[4], M1[4], L1[4], M2[4], L2[4], A0[2 * KP], A1[2 * KP];
+    fetch_ml(M0, L0);
+    fetch_ml(M1, L1);
+    fetch_a(nops - 2, A0);
+    for (int i = nops - 2; i >= 0; i -= 6) {
+        fetch_ml(M2, L2);
+        fetch_a(i - 1, A1);
+        step(i, M0, L0, A0);
+        if (i - 1 < 0) break;
+        fetch_ml(M0, L0);
+        fetch_a(i - 2, A0);
+        step(i - 1, M1, L1, A1);
+        if (i - 2 < 0) break;
+        fetch_ml(M1, L1);
+        fetch_a(i - 3, A1);
+        step(i - 2, M2, L2, A0);
+        if (i - 3 < 0) break;
+        fetch_ml(M2, L2);
+        fetch_a(i - 4, A0);
+        step(i - 3, M0, L0, A1);
+        if (i - 4 < 0) break;
+        fetch_ml(M0, L0);
+        fetch_a(i - 5, A1);
+        step(i - 4, M1, L1, A0);
+        if (i - 5 < 0) break;
+        fetch_ml(M1, L1);
+        fetch_a(i - 6, A0);
+        step(i - 5, M2, L2, A1);
     }
     const long site = blk * 16 + (lane & 15);
     if (bad && site < nsites) atomicOr(&status[site], 2);
 }
 
-// W partial of one edge (= step) and one chunk of site tiles: wave ma holds row tile ma of W.
-// K = the 16 sites of a tile, four per MFMA: k-lane hi of k-step ks is site 4 hi + ks, so that
-// the four k-steps' operands of a lane are 32 contiguous bytes of the D-layout arrays (state
-// 16 M + x, site t at (M * 4 + x / 4) * 64 + 16 (x % 4) + t) -- one double4 per array and row
-// tile instead of four scattered doubles, and the next tile's are requested before this tile's
-// MFMAs (the kernel was a chain of load -> wait -> MFMA: 780 us for 1.3 GB at 10 000 codon sites).
-template <int NT>
+// W partial of one edge (= step) and one chunk of site tiles.  K = the 16 sites of a tile, four
+// per MFMA: k-lane hi of k-step ks is site 4 hi + ks, so that the four k-steps' operands of a lane
+// are 32 contiguous bytes of the D-layout arrays (state 16 M + x, site t at (M * 4 + x / 4) * 64 +
+// 16 (x % 4) + t): one double4 per array and row tile.
+//
+// The waves of a workgroup take the chunk's tiles in turn, and each computes ALL NT x NT tile
+// pairs of W for its tiles: a tile's U and L are then read once per workgroup, not once per wave
+// (L was), a tile is 4 NT^2 MFMAs long, and a wave's next tile is requested two tiles ahead with
+// nothing else to wait for.  (History: four scattered doubles per operand and load -> wait -> MFMA
+// 780 us at 10 000 codon sites; contiguous operands 369; a wave per row tile with deeper prefetch
+// no better -- 2 waves per SIMD at 184 registers, 38 % of the pipe, 44 % of HBM, the waves waiting
+// 91 % of their cycles.)  The partials of the waves are added through LDS in wave order.
+//
+// Fetching: three named buffers, the loop unrolled by three, running pointers, 32-bit counters.
+// Rotating buffers through register copies makes every copy wait for the newest loads; an
+// address computed into a register a pending load still owns, or a 64-bit loop test that borrows
+// one, drains the queue; a conditional load makes the compiler drain it at the back edge.  A
+// fetch past the chunk's last tile reads the next tiles or steps of the same scratch block -- U
+// is followed by the partials, L by M -- and is never used.
+template <int NT, bool WEIGHTS>
 __global__ void __launch_bounds__(64 * NT)
 expect_wsum_kernel(int nops, const double *__restrict__ Uarr, const double *__restrict__ Larr,
                    const double *__restrict__ weights, long nsites, long nblocks,
                    double *__restrict__ partial)
 {
+    __shared__ double redw[NT * NT * 256];
     const int lane = threadIdx.x & 63;
-    const int ma = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int step = blockIdx.x, chunk = blockIdx.y;
-    const long per = (nblocks + EX_CHUNKS - 1) / EX_CHUNKS;
-    const long t0 = chunk * per, t1 = t0 + per < nblocks ? t0 + per : nblocks;
+    const int nb = (int)nblocks;
+    const int per = (nb + EX_CHUNKS - 1) / EX_CHUNKS;
+    const int t0 = chunk * per, t1 = t0 + per < nb ? t0 + per : nb;
     const size_t tile_stride = (size_t)NT * 256;
     const int lo = lane & 15, hi = lane >> 4;
     const int row_off = (lo >> 2) * 64 + 16 * (lo & 3) + 4 * hi;
-    double4_t acc[NT];
+    double4_t acc[NT][NT];
 #pragma unroll
-    for (int mb = 0; mb < NT; ++mb) acc[mb] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    if (t0 < t1) {
-        const double *Ub = Uarr + (size_t)step * nblocks * tile_stride + ma * 256 + row_off;
-        const double *Lb = Larr + (size_t)step * nblocks * tile_stride + row_off;
-        auto fetch = [&](long tile, double4_t &u, double4_t (&l)[NT], double4_t &w) {
-            u = *(const double4_t *)(Ub + (size_t)tile * tile_stride);
+    for (int ma = 0; ma < NT; ++ma)
 #pragma unroll
-            for (int mb = 0; mb < NT; ++mb)
-                l[mb] = *(const double4_t *)(Lb + (size_t)tile * tile_stride + mb * 256);
-            const long site = tile * 16 + 4 * hi;
+        for (int mb = 0; mb < NT; ++mb) acc[ma][mb] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    const int first = t0 + wv;                   // this wave's tiles: first, first + NT, ...
+    if (first < t1) {
+        const size_t base = ((size_t)step * nblocks + first) * tile_stride + row_off;
+        const double *pu = Uarr + base, *pl = Larr + base;
+        int ftile = first;
+        auto fetch = [&](double4_t (&u)[NT], double4_t (&l)[NT], double4_t &w) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                w[ks] = site + ks < nsites ? (weights ? weights[site + ks] : 1.0) : 0.0;
-        };
-        double4_t uc, lc[NT], wc;
-        fetch(t0, uc, lc, wc);
-        for (long tile = t0; tile < t1; ++tile) {
-            double4_t un, ln[NT], wn;
-            fetch(tile + 1 < t1 ? tile + 1 : tile, un, ln, wn);
+            for (int mm = 0; mm < NT; ++mm) {
+                u[mm] = *(const double4_t *)(pu + mm * 256);
+                l[mm] = *(const double4_t *)(pl + mm * 256);
+            }
+            const long site = (long)ftile * 16 + 4 * hi;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const double av = uc[ks] * wc[ks];                 // U[16 ma + lo][site] w
-#pragma unroll
-                for (int mb = 0; mb < NT; ++mb)                      // L[16 mb + lo][site]
-                    acc[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, lc[mb][ks], acc[mb], 0, 0, 0);
+                const long sc = site + ks < nsites ? site + ks : nsites - 1;
+                const double wgt = WEIGHTS ? weights[sc] : 1.0;
+                w[ks] = site + ks < nsites ? wgt : 0.0;
             }
-            uc = un;
-            wc = wn;
+            pu += NT * tile_stride;
+            pl += NT * tile_stride;
+            ftile += NT;
+        };
+        auto compute = [&](const double4_t (&u)[NT], const double4_t (&l)[NT], const double4_t &w) {
 #pragma unroll
-            for (int mb = 0; mb < NT; ++mb) lc[mb] = ln[mb];
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int ma = 0; ma < NT; ++ma) {
+                    const double av = u[ma][ks] * w[ks];           // U[16 ma + lo][site] w
+#pragma unroll
+                    for (int mb = 0; mb < NT; ++mb)                  // L[16 mb + lo][site]
+                        acc[ma][mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, l[mb][ks], acc[ma][mb],
+                                                                           0, 0, 0);
+                }
+        };
+#define RT_WSUM_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+        double4_t uA[NT], lA[NT], wA, uB[NT], lB[NT], wB, uC[NT], lC[NT], wC;
+        fetch(uA, lA, wA);
+        fetch(uB, lB, wB);
+        RT_WSUM_FENCE();
+        for (int tile = first; tile < t1; tile += 3 * NT) {
+            fetch(uC, lC, wC);
+            RT_WSUM_FENCE();
+            compute(uA, lA, wA);
+            RT_WSUM_FENCE();
+            if (tile + NT < t1) {
+                fetch(uA, lA, wA);
+                RT_WSUM_FENCE();
+                compute(uB, lB, wB);
+                RT_WSUM_FENCE();
+            }
+            if (tile + 2 * NT < t1) {
+                fetch(uB, lB, wB);
+                RT_WSUM_FENCE();
+                compute(uC, lC, wC);
+                RT_WSUM_FENCE();
+            }
+        }
+#undef RT_WSUM_FENCE
+    }
+    // wave 0 += wave 1, 2, ... in that order
+    for (int w = 1; w < NT; ++w) {
+        __syncthreads();
+        if (wv == w) {
+#pragma unroll
+            for (int ma = 0; ma < NT; ++ma)
+#pragma unroll
+                for (int mb = 0; mb < NT; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        redw[((ma * NT + mb) * 4 + r) * 64 + lane] = acc[ma][mb][r];
+        }
+        __syncthreads();
+        if (wv == 0) {
+#pragma unroll
+            for (int ma = 0; ma < NT; ++ma)
+#pragma unroll
+                for (int mb = 0; mb < NT; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[ma][mb][r] += redw[((ma * NT + mb) * 4 + r) * 64 + lane];
         }
     }
-    double *out = partial + (((size_t)step * EX_CHUNKS + chunk) * NT + ma) * NT * 256;
+    if (wv == 0) {
+        double *out = partial + ((size_t)step * EX_CHUNKS + chunk) * NT * NT * 256;
 #pragma unroll
-    for (int mb = 0; mb < NT; ++mb)
+        for (int ma = 0; ma < NT; ++ma)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[(mb * 4 + r) * 64 + lane] = acc[mb][r];
+            for (int mb = 0; mb < NT; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[((ma * NT + mb) * 4 + r) * 64 + lane] = acc[ma][mb][r];
+    }
 }
 
 // chunks summed in order, structural zeros of P masked, reference order [node][a][b]
@@ -501,8 +613,12 @@ int expect_device_passes(rt_ctx *ctx, rt_model *model, rt_sites *s, const double
                            d_PT, nops, d_parent_step, d_internal, d_L, d_M, d_D, d_U, d_root_w, (int)n,
                            d_status, (long)nsites, nblocks);
     }
-    hipLaunchKernelGGL((expect_wsum_kernel<NT>), dim3((unsigned)(nops - 1), EX_CHUNKS), dim3(64 * NT),
-                       0, st, nops, d_U, d_L, d_w, (long)nsites, nblocks, d_part);
+    if (d_w)
+        hipLaunchKernelGGL((expect_wsum_kernel<NT, true>), dim3((unsigned)(nops - 1), EX_CHUNKS),
+                           dim3(64 * NT), 0, st, nops, d_U, d_L, d_w, (long)nsites, nblocks, d_part);
+    else
+        hipLaunchKernelGGL((expect_wsum_kernel<NT, false>), dim3((unsigned)(nops - 1), EX_CHUNKS),
+                           dim3(64 * NT), 0, st, nops, d_U, d_L, d_w, (long)nsites, nblocks, d_part);
     hipLaunchKernelGGL(expect_finish_kernel, dim3((unsigned)(nops - 1)), dim3(256), 0, st, (int)n, NT,
                        nops, d_step_node, esd_dev, d_part, d_W);
     hipLaunchKernelGGL(expect_root_kernel, dim3(EX_ROOT_CHUNKS), dim3(64), 0, st, (int)n, NT, nops - 1,
