@@ -37,6 +37,13 @@ frechet_assemble_kernel(int n, const double *__restrict__ Q, const int *__restri
     }
     double sc = smax[0];
     if (!(sc > 0.0) || !(sc < 1e308 * 10.0)) sc = 1.0;
+    // ... and a further 2^-17 (exact): the corner block is linear in W, so its size is ours to
+    // choose, and at max |entry| = 1 its column sums (up to n) decided the number of squarings
+    // of the whole block -- seven at 61 states where t Q alone needs none (the series for the
+    // corner has the tail of exp's one degree down, times |W|: its relative accuracy does not
+    // depend on the scale).  With column sums <= 2^-11 the order comes from t Q.
+    sc = ldexp(sc, 17);
+    if (!(sc < 1e308 * 10.0)) sc = ldexp(sc, -17);
     if (threadIdx.x == 0) scale[e] = sc;
     const double te = t[e], inv = 1.0 / sc;
     double *B = blocks + (long)e * m * m;
@@ -62,6 +69,8 @@ frechet_contract_kernel(int n, int nedges, const double *__restrict__ Q,
     if (k >= nn) return;
     const int c = k / n, d = k - c * n;
     double acc = 0.0, dw = 0.0;
+    // (unrolled: the loads of eight edges in flight; the additions keep their order)
+#pragma unroll 8
     for (int e = 0; e < nedges; ++e) {
         const double q = Q[(long)qidx[e] * nn + k];
         const double Mcd = E[(long)e * m * m + (long)c * m + (n + d)] * scale[e];
