@@ -220,8 +220,16 @@ def run_workload(name, ctx, ctl, rank, world, reduce_kind, steps, warmup, args,
         if cfg['obs_kind'] != 'state':
             raise SystemExit('--encoding state: the leaves of this workload are allowed-state '
                              'sets, not states')
-        batch0 = model.upload_sites(cfg['leaves'], cfg['leaf_states'].astype(np.uint8),
-                                    kind='state')
+        # C4 is defined on dense leaf vectors: the states are only how the million sites cross
+        # PCIe, so the kernel multiplies at the leaves as a dense upload's would (the kernels
+        # that gather columns of P for observed states are next_rows.leaf_states_step_c3)
+        if name == 'c4':
+            ctx.set_option('leaf_state_kernels', 0)
+        try:
+            batch0 = model.upload_sites(cfg['leaves'], cfg['leaf_states'].astype(np.uint8),
+                                        kind='state')
+        finally:
+            ctx.set_option('leaf_state_kernels', None)
     else:
         dense = synth.leaf_likelihoods(cfg)
         batch0 = model.upload_sites(cfg['leaves'], dense, kind='dense')

@@ -743,6 +743,9 @@ static std::atomic<int> g_jit_async{1};
 // 1: batches created from now on rescale their messages by powers of two (interpreter kernels
 // only; prune.hip, rescale_exponent): trees of a thousand leaves whose likelihood underflows f64
 static std::atomic<int> g_rescale{0};
+// 1: a batch of observed STATES at the leaves (split-M family) may get a kernel whose leaf steps
+// gather columns of P instead of multiplying; 0: always the dense resident layout's products
+static std::atomic<int> g_leaf_state_kernels{1};
 
 static int parse_option(const char *key, int64_t value, int *which, int *out)
 {
@@ -757,6 +760,7 @@ static int parse_option(const char *key, int64_t value, int *which, int *out)
     }
     if (strcmp(key, "jit_async") == 0) { *which = 3; *out = value != 0; return RT_OK; }
     if (strcmp(key, "rescale") == 0) { *which = 4; *out = value != 0; return RT_OK; }
+    if (strcmp(key, "leaf_state_kernels") == 0) { *which = 5; *out = value != 0; return RT_OK; }
     rt_set_error("unknown option %s", key);
     return RT_ERR_INVALID;
 }
@@ -766,7 +770,7 @@ extern "C" int rt_set_option(const char *key, int64_t value)
     int which = 0, v = 0;
     RT_TRY(parse_option(key, value, &which, &v));
     (which == 0 ? g_force_generic : which == 1 ? g_jit : which == 2 ? g_jit_block_sites
-     : which == 3 ? g_jit_async : g_rescale).store(v);
+     : which == 3 ? g_jit_async : which == 4 ? g_rescale : g_leaf_state_kernels).store(v);
     return RT_OK;
 }
 
@@ -782,7 +786,7 @@ extern "C" int rt_ctx_set_option(rt_ctx *ctx, const char *key, int64_t value)
     }
     (which == 0 ? ctx->opt_force_generic : which == 1 ? ctx->opt_jit
      : which == 2 ? ctx->opt_jit_block_sites : which == 3 ? ctx->opt_jit_async
-                                              : ctx->opt_rescale) = v;
+     : which == 4 ? ctx->opt_rescale : ctx->opt_leaf_state_kernels) = v;
     return RT_OK;
 }
 
@@ -800,6 +804,11 @@ static int opt_rescale(const rt_ctx *c)
 {
     if (const char *v = getenv("RAOTEH_RESCALE")) return atoi(v) != 0;
     return c->opt_rescale != RT_OPT_UNSET ? c->opt_rescale : g_rescale.load();
+}
+static int opt_leaf_state_kernels(const rt_ctx *c)
+{
+    return c->opt_leaf_state_kernels != RT_OPT_UNSET ? c->opt_leaf_state_kernels
+                                                     : g_leaf_state_kernels.load();
 }
 static int opt_jit_block_sites(const rt_ctx *c)
 {
@@ -1576,7 +1585,8 @@ static int sites_create_impl(rt_model *m, int64_t nsites, int kind, int64_t nobs
     // observed STATES, all at leaves, none unobserved, split-M family: the kernel's leaf steps
     // may gather columns of P (jit.hip, `sparse`); the dense image stays (interpreter kernel)
     if (kind == RT_OBS_STATE && s->layout == RT_LAYOUT_MFMA && !s->mfma_solo && !generic && nobs > 0 &&
-        !s->rescale && !getenv("RAOTEH_JIT_NO_SPARSE") && (!ov || ov->sparse)) {
+        !s->rescale && opt_leaf_state_kernels(m->ctx) && !getenv("RAOTEH_JIT_NO_SPARSE") &&
+        (!ov || ov->sparse)) {
         bool ok = true;
         for (const rt_op &op : s->ops)
             if (op.obs >= 0 && !(op.pop < 0 && op.dst >= 0)) ok = false;

@@ -88,6 +88,7 @@ struct rt_ctx {
     int opt_jit_block_sites = -2;
     int opt_jit_async = -2;
     int opt_rescale = -2;
+    int opt_leaf_state_kernels = -2;
     // The batch whose per-wave partial sums still await their fixed-order reduction.
     // rt_step defers it: the reduction of step j rides as one extra workgroup of step
     // j + 1's expm launch (two launches per step instead of three: on config 2 the two

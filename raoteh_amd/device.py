@@ -101,7 +101,7 @@ class Context(object):
 
     def set_option(self, key, value):
         """Per-context option (rt_ctx_set_option): 'jit' (-1 automatic / 0 / 1),
-        'force_generic', 'jit_block_sites', 'jit_async', 'rescale' (power-of-two rescaling
+        'force_generic', 'jit_block_sites', 'jit_async', 'leaf_state_kernels', 'rescale' (power-of-two rescaling
         of the messages of batches uploaded from now on: trees whose likelihood underflows
         f64); value None = back to the process default."""
         _lib.check(_lib.lib().rt_ctx_set_option(

@@ -1076,6 +1076,20 @@ def test_leaf_state_kernels_gather_columns_bit_identically(ra, n, monkeypatch):
                 b2 = model.upload_sites(more, st2, kind='state')
                 model.log_likelihoods(b2)
                 assert 'leaf-states' not in b2.kernel_name
+            # switched off (what the benchmark's C4, defined on dense vectors, asks for): the
+            # products at the leaves, the same numbers
+            ra.ctx.set_option('leaf_state_kernels', 0)
+            try:
+                b3 = model.upload_sites(obs_nodes, states, kind='state')
+            finally:
+                ra.ctx.set_option('leaf_state_kernels', None)
+            ll3, st3 = model.log_likelihoods(b3)
+            assert 'leaf-states' not in b3.kernel_name and b3.kernel_name.startswith('prune_tree_jit')
+            b4 = model.upload_sites(obs_nodes, states, kind='state')
+            ll4, st4 = model.log_likelihoods(b4)
+            assert 'leaf-states' in b4.kernel_name
+            np.testing.assert_array_equal(ll3, ll4)
+            np.testing.assert_array_equal(st3, st4)
         finally:
             ra.lib.check(set_option(b'jit', -1))
     # in the background: interpreter first, the column-gathering kernel after the switch
