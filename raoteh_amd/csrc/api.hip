@@ -1120,7 +1120,8 @@ static int sites_halves_setup(rt_sites *s)
     s->jit_halves = true;          // sites_alloc allocates d_half
     // (the pipelined generator folds the combine step into the pruning kernel; the serial
     // generator, RAOTEH_JIT_SPLIT=serial, has no halves form)
-    s->jit_fold = rt_jit_fold_enabled();
+    // (... and the leaf-state form keeps the two kernels)
+    s->jit_fold = rt_jit_fold_enabled() && !s->jit_sparse;
     return RT_OK;
 }
 
@@ -1132,6 +1133,7 @@ struct jit_override {
     bool fuse = false;        // lane family: the kernel can compute its own transitions
     bool no_solo = false;     // n <= 32: the split-M interpreter kernel, not the one-wave one
     bool sparse = false;      // split-M family: leaf steps gather columns of P (leaf states)
+    bool pipe = false;        // ... from the pipelined generator (leaves as factors)
 };
 
 // Background compile for an MFMA-family batch: candidates the cache already knows as
@@ -1145,6 +1147,7 @@ static bool sites_jit_start_async(rt_sites *s, const std::vector<rt_sites::jit_c
     std::vector<std::string> srcs;
     for (const auto &c : cands) {
         std::string src = make(c);
+        if (src.empty()) continue;                    // (this form does not exist for this tree)
         const int known = rt_jit_cached(s->model->ctx, src);
         if (known < 0 && todo.empty()) continue;      // spilled or failed verification earlier
         if (known > 0 && todo.empty()) return false;  // in the cache: no job needed
@@ -1168,12 +1171,15 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
         const std::string src =
             !mfma ? rt_jit_lane_source(s->ops, n, K, ov->D, ov->LA, ov->S, ov->WG, ov->compact,
                                        ov->fuse)
+            : split && ov->sparse && ov->pipe
+                ? rt_jit_mfma_split_pipelined_source(s->ops, n, K, ov->T, ov->D, ov->LA, ov->halves, true)
             : split && ov->sparse ? rt_jit_mfma_split_source(s->ops, n, K, ov->T, ov->D, ov->LA, true)
             : split ? split_source(s->ops, n, K, ov->T, ov->D, ov->LA, ov->halves)
                     : rt_jit_mfma_source(s->ops, n, K, ov->T, ov->D, ov->LA, ov->quad);
         RT_TRY(rt_jit_get(s->model->ctx, src, &s->jit_fn, mfma));
         s->jit_sparse = split && ov->sparse;
-        if (split && ov->halves && !ov->sparse) RT_TRY(sites_halves_setup(s));
+        s->jit_pipe = split && ov->sparse && ov->pipe;
+        if (split && ov->halves && (!ov->sparse || ov->pipe)) RT_TRY(sites_halves_setup(s));
         s->jit_quad = mfma && !split && ov->quad;
         s->jit_prefetch = ov->D;
         s->jit_lookahead = ov->LA;
@@ -1241,18 +1247,38 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
                 int Ts = (ntiles >= 2048 && !wide) ? 2 : 1;
                 if (const char *v = getenv("RAOTEH_JIT_TILES")) Ts = std::min(2, std::max(1, atoi(v)));
                 std::vector<rt_sites::jit_cand> cands;
-                for (int t = Ts; t >= 1; --t) cands.push_back({t, false, false, true});
+                // first the pipelined generator with the leaves as factors of their parents'
+                // expressions (n <= 64; the dense kernels' tiling: root halves at T, at one tile,
+                // the whole tree), then the serial generator; RAOTEH_JIT_SPARSE=serial: only that
+                const char *sv = getenv("RAOTEH_JIT_SPARSE");
+                if (!wide && !(sv && strcmp(sv, "serial") == 0)) {
+                    for (int t = T, h = halves;;) {
+                        cands.push_back({t, h != 0, false, true, true});
+                        if (h && t > 1) t = 1;
+                        else if (h) h = 0;
+                        else if (t > 1) --t;
+                        else break;
+                    }
+                }
+                for (int t = Ts; t >= 1; --t) cands.push_back({t, false, false, true, false});
                 auto make = [&](const rt_sites::jit_cand &c) {
-                    return rt_jit_mfma_split_source(s->ops, (int)s->model->n, (int)s->nobs, c.T, D, LA, true);
+                    return c.pipe ? rt_jit_mfma_split_pipelined_source(s->ops, (int)s->model->n, (int)s->nobs,
+                                                                       c.T, D, LA, c.halves, true)
+                                  : rt_jit_mfma_split_source(s->ops, (int)s->model->n, (int)s->nobs, c.T, D,
+                                                             LA, true);
                 };
                 if (!forced && opt_jit_async(s->model->ctx) && sites_jit_start_async(s, cands, make))
                     return RT_OK;
                 for (const auto &c : cands) {
-                    rc = rt_jit_get(s->model->ctx, make(c), &s->jit_fn, true, &s->jit_compile_s);
+                    const std::string src = make(c);
+                    if (src.empty()) continue;
+                    rc = rt_jit_get(s->model->ctx, src, &s->jit_fn, true, &s->jit_compile_s);
                     if (rc == RT_OK) {
                         s->jit_tiles = c.T;
                         s->jit_waves = (int)((s->model->n + 15) / 16);
                         s->jit_sparse = true;
+                        s->jit_pipe = c.pipe;
+                        if (c.halves) RT_TRY(sites_halves_setup(s));
                         return RT_OK;
                     }
                     if (rc != RT_ERR_UNSUPPORTED) break;
@@ -1503,6 +1529,10 @@ extern "C" int rt_jit_source(int64_t nnodes, const int64_t *idx, const int64_t *
                              getenv("RAOTEH_JIT_FUSE_EXPM") && atoi(getenv("RAOTEH_JIT_FUSE_EXPM")) != 0)
         : n <= 32 ? rt_jit_mfma_source(m.ops, (int)n, (int)nobs, std::min(T, 4), (int)prefetch, 1,
                                        !(getenv("RAOTEH_JIT_QUAD") && atoi(getenv("RAOTEH_JIT_QUAD")) == 0))
+                  : getenv("RAOTEH_JIT_SOURCE_SPARSE") && strcmp(getenv("RAOTEH_JIT_SOURCE_SPARSE"), "pipe") == 0
+                        ? rt_jit_mfma_split_pipelined_source(
+                              m.ops, (int)n, (int)nobs, T, 2, 1,
+                              getenv("RAOTEH_JIT_HALVES") && atoi(getenv("RAOTEH_JIT_HALVES")), true)
                   : getenv("RAOTEH_JIT_SOURCE_SPARSE")
                         ? rt_jit_mfma_split_source(m.ops, (int)n, (int)nobs, std::min(T, 2), 2, 1, true)
                   : split_source(m.ops, (int)n, (int)nobs,
@@ -1629,6 +1659,12 @@ static int sites_create_impl(rt_model *m, int64_t nsites, int kind, int64_t nobs
         !getenv("RAOTEH_JIT_NO_VERIFY")) {
         const int vrc = verify_jit_kernel(s, kind);
         rt_jit_set_verified(m->ctx, s->jit_fn, vrc == RT_OK);
+        // (RAOTEH_JIT_VERIFY_STRICT=1, soak runs: a rejected kernel is a generator or compiler
+        // defect to look at, not something to fall back from silently)
+        if (vrc != RT_OK && getenv("RAOTEH_JIT_VERIFY_STRICT")) {
+            fprintf(stderr, "[raoteh_amd] probe verification rejected %s\n", s->kernel_name);
+            rc = RT_ERR_INVALID;
+        }
         if (vrc != RT_OK) {
             rt_jit_ref(m->ctx, s->jit_fn, -1);
             s->jit_fn = nullptr;
@@ -1638,6 +1674,7 @@ static int sites_create_impl(rt_model *m, int64_t nsites, int kind, int64_t nobs
             s->compact_states = 0;
             s->jit_quad = false;
             s->jit_sparse = false;
+            s->jit_pipe = false;
             s->jit_halves = false;
             s->jit_fold = false;
             s->jit_combine = nullptr;
@@ -1753,6 +1790,7 @@ static int verify_jit_kernel(rt_sites *s, int kind)
     same.halves = s->jit_halves;
     same.fuse = s->jit_fused;
     same.sparse = s->jit_sparse;
+    same.pipe = s->jit_pipe;
     if (rc == RT_OK)
         rc = sites_create_impl(tm, np, pkind, K, obs_nodes.data(), data, &interp, &si);
     if (rc == RT_OK)
@@ -1907,6 +1945,7 @@ int rt_sites_jit_poll(rt_sites *s, bool wait)
     s->jit_fn = fn;
     s->jit_tiles = c.T;
     s->jit_sparse = split && c.sparse;
+    s->jit_pipe = split && c.sparse && c.pipe;
     s->jit_quad = !split && c.quad;
     if (split) s->jit_waves = (int)((m->n + 15) / 16);
     int src = RT_OK;
@@ -1930,6 +1969,7 @@ int rt_sites_jit_poll(rt_sites *s, bool wait)
         s->jit_tiles = 1;
         s->jit_quad = false;
         s->jit_sparse = false;
+        s->jit_pipe = false;
         s->jit_halves = false;
         s->jit_fold = false;
         s->jit_combine = nullptr;
@@ -1992,6 +2032,7 @@ extern "C" int rt_sites_clone(rt_sites *src, rt_sites **out)
     s->jit_compile_s = src->jit_compile_s;
     s->sparse_ok = src->sparse_ok;
     s->jit_sparse = src->jit_sparse;
+    s->jit_pipe = src->jit_pipe;
     int rc = sites_alloc(s, src->d_scratch != nullptr);
     if (rc == RT_OK && s->d_leafw && src->d_leafw &&
         hipMemcpyAsync(s->d_leafw, src->d_leafw, (size_t)s->nblocks * ((s->nobs + 3) / 4) * 16 * 4,

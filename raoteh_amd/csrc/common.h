@@ -253,7 +253,7 @@ struct rt_sites {
     // background compile of the tree-specialised kernel (MFMA family): the batch runs the
     // interpreter kernel until the job is done and rt_sites_jit_poll swaps the kernel in
     std::shared_ptr<rt_jit_job> jit_job;
-    struct jit_cand { int T; bool halves; bool quad; bool sparse = false; };
+    struct jit_cand { int T; bool halves; bool quad; bool sparse = false; bool pipe = false; };
     std::vector<jit_cand> jit_cands;        // what each candidate source of the job was built with
     std::vector<std::string> jit_srcs;
     int jit_kind = 0;                       // observation kind of the batch (probe batches)
@@ -269,6 +269,7 @@ struct rt_sites {
     // word) for the tree-specialised kernel whose leaf steps gather columns of P (jit.hip)
     bool sparse_ok = false;
     bool jit_sparse = false;
+    bool jit_pipe = false;                  // ... from the pipelined generator (leaves as factors)
     unsigned *d_leafw = nullptr;
     // rt_expect_step: per-site multiplicities on the device (null: ones), and the batch's
     // split-M interpreter twin -- its own program, partial sums and per-site outputs over the
@@ -347,7 +348,8 @@ std::string rt_jit_mfma_split_source(const std::vector<rt_op> &ops, int n, int K
                                      int LA, bool sparse = false);
 bool rt_jit_fold_enabled();
 std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, int n, int K, int T,
-                                               int D, int LA, bool halves = false);
+                                               int D, int LA, bool halves = false,
+                                               bool sparse = false);
 // steps of the two root programs the halves form would run (0, 0: the root has < 2 children)
 void rt_jit_root_halves(const std::vector<rt_op> &ops, int *stepsA, int *stepsB);
 // the cut itself: A = the subtrees of all children of the root but the last, B = the last

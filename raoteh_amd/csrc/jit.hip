@@ -1167,18 +1167,21 @@ std::string rt_jit_mfma_split_source(const std::vector<rt_op> &ops, int n, int K
                 o << "    const unsigned lw" << w << "_" << t << " = leafw[((size_t)(tile" << t
                   << " < nblocks ? tile" << t << " : nblocks - 1) * " << KW << " + " << w
                   << ") * 16 + (lane & 15)];\n";
-        for (int r = 0; r < 4; ++r)
-            o << "    const int prow" << r << " = (16 * m + " << 4 * r << " + (lane >> 4)) * " << n << ";\n";
+        o << "    const double *pfm = Pfrag + (m * " << KP * 128 << " + (lane >> 4) * 2);\n";
     }
-    // the four entries of this lane of column `state` of P_node (zero in the padded rows)
+    // the four entries of this lane of column `state` of P_node, from the step's A-fragment
+    // record (zero in the padded rows): the four row-lanes of a site share a 64-byte sector
     auto emit_gather = [&](int i) {
         const rt_op &op = ops[(size_t)i];
         for (int t = 0; t < T; ++t) {
             o << "    const int st" << i << "_" << t << " = (int)((lw" << (op.obs >> 2) << "_" << t
               << " >> " << 8 * (op.obs & 3) << ") & 255u);\n";
+            o << "    const double *pf" << i << "_" << t << " = pfm + " << (long)i * NT * KP * 128 << " + (st"
+              << i << "_" << t << " >> 3) * 128 + (st" << i << "_" << t << " & 3) * 32 + ((st" << i << "_"
+              << t << " >> 2) & 1);\n";
             for (int r = 0; r < 4; ++r)
-                o << "    const double pc" << i << "_" << t << "_" << r << " = rowok" << r << " ? Pesd["
-                  << (long)op.node * n * n << " + prow" << r << " + st" << i << "_" << t << "] : 0.0;\n";
+                o << "    const double pc" << i << "_" << t << "_" << r << " = pf" << i << "_" << t << "["
+                  << 8 * r << "];\n";
         }
     };
     if (!sparse)
@@ -1478,6 +1481,68 @@ bool split_at_root(const std::vector<rt_op> &ops, std::vector<rt_op> *A, std::ve
     return true;
 }
 
+// Observed states at the leaves (the batch's `sparse_ok`): a leaf's message is a column of its
+// transition matrix, so a leaf is not a step of the pipeline at all.  The leaves are taken out of
+// the schedule and become factors of their parents' expressions, in the order the accumulator
+// was folded in (the same product, bit for bit):
+//   lead[node of k]   the leaves folded into k's parent's accumulator since the previous matrix
+//                     sibling: fold(k) becomes  a = ((a * pc1) * pc2 ...) * c_k  (or, first into
+//                     the slot,  a = (pc1 * pc2 ...) * c_k);
+//   trail[node of p]  the leaves after p's last matrix child: x(p) = ((a * pc1) * pc2) ...; a
+//                     node all of whose children are leaves pops nothing.
+struct leaf_ref {
+    int node, obs;
+};
+struct sparse_plan {
+    std::vector<std::vector<leaf_ref>> lead, trail;     // by node
+};
+
+bool sparse_reduce(const std::vector<rt_op> &ops, std::vector<rt_op> *out, sparse_plan *plan)
+{
+    const int nrec = (int)ops.size();
+    int maxnode = 0;
+    for (const rt_op &op : ops) maxnode = std::max(maxnode, (int)op.node);
+    plan->lead.resize(std::max(plan->lead.size(), (size_t)maxnode + 1));
+    plan->trail.resize(std::max(plan->trail.size(), (size_t)maxnode + 1));
+    auto is_leaf = [&](const rt_op &op) { return op.pop < 0 && op.obs >= 0 && op.dst >= 0; };
+    std::vector<std::vector<int>> pending(256);
+    std::vector<int> pop_eff((size_t)nrec, -1);
+    for (int i = 0; i < nrec; ++i) {
+        const rt_op &op = ops[(size_t)i];
+        if (op.obs >= 0 && !is_leaf(op)) return false;         // an observed inner node
+        pop_eff[(size_t)i] = op.pop;
+        if (op.pop >= 0) {
+            std::vector<leaf_ref> run;
+            bool matrix_child = false;
+            for (int c : pending[(size_t)op.pop]) {
+                const rt_op &ch = ops[(size_t)c];
+                if (is_leaf(ch)) {
+                    run.push_back({(int)ch.node, (int)ch.obs});
+                } else {
+                    plan->lead[(size_t)ch.node] = run;
+                    run.clear();
+                    matrix_child = true;
+                }
+            }
+            plan->trail[(size_t)op.node] = run;
+            if (!matrix_child) pop_eff[(size_t)i] = -1;
+            pending[(size_t)op.pop].clear();
+        }
+        if (op.dst >= 0) {
+            if (op.dst >> 8) pending[(size_t)(op.dst & 255)].clear();
+            pending[(size_t)(op.dst & 255)].push_back(i);
+        }
+    }
+    out->clear();
+    for (int i = 0; i < nrec; ++i) {
+        if (is_leaf(ops[(size_t)i])) continue;
+        rt_op r = ops[(size_t)i];
+        r.pop = pop_eff[(size_t)i];
+        out->push_back(r);
+    }
+    return !out->empty();
+}
+
 }  // namespace
 
 bool rt_split_at_root(const std::vector<rt_op> &ops, std::vector<rt_op> *A, std::vector<rt_op> *B)
@@ -1519,10 +1584,10 @@ bool rt_jit_fold_enabled()
 }
 
 std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, int n, int K, int T,
-                                               int D, int LA, bool halves)
+                                               int D, int LA, bool halves, bool sparse)
 {
     (void)LA;
-    const bool fold = halves && rt_jit_fold_enabled();
+    const bool fold = halves && !sparse && rt_jit_fold_enabled();
     // x of a step is published one step early, so its leaf vector must be in registers a
     // step earlier than in the serial kernel: at least two leaves ahead
     D = std::max(D, 2);
@@ -1544,21 +1609,49 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
     // step in the shadow, and 16 more live registers in a kernel that already keeps 250
     // values in AGPRs; at T = 1 and T = 2 the register budget no longer holds (scratch: the
     // kernel is rejected and the interpreter runs).
-    const bool lastk = (n % 4 == 1) && KS >= 4 && getenv("RAOTEH_JIT_LASTK") &&
+    const bool lastk = (n % 4 == 1) && KS >= 4 && !sparse && getenv("RAOTEH_JIT_LASTK") &&
                        atoi(getenv("RAOTEH_JIT_LASTK")) != 0;
     const int KSM = lastk ? KS - 1 : KS;      // k-steps on the matrix pipe
     int nslots = 1;
     std::vector<std::vector<pipe_step>> programs;
+    // (sparse: leaves as factors, see sparse_reduce; one plan per program -- the root's step
+    // belongs to both root programs, with different children)
+    std::vector<sparse_plan> plans(2);
+    size_t cur_prog = 0;
+    // gathers of the leaves a step names are requested this many steps ahead
+    int GA = 2;
+    if (const char *v = getenv("RAOTEH_JIT_GATHER_AHEAD")) GA = std::max(1, std::min(4, atoi(v)));
     if (halves) {
         std::vector<rt_op> opsA, opsB;
         if (!split_at_root(ops, &opsA, &opsB)) return std::string();
+        if (sparse) {
+            std::vector<rt_op> ra, rb;
+            if (!sparse_reduce(opsA, &ra, &plans[0]) || !sparse_reduce(opsB, &rb, &plans[1]))
+                return std::string();
+            opsA.swap(ra);
+            opsB.swap(rb);
+        }
         int sa = 1, sb = 1;
         programs.push_back(pipeline_order(opsA, &sa));
         programs.push_back(pipeline_order(opsB, &sb));
         nslots = std::max(sa, sb);
+    } else if (sparse) {
+        std::vector<rt_op> red;
+        if (!sparse_reduce(ops, &red, &plans[0])) return std::string();
+        programs.push_back(pipeline_order(red, &nslots));
     } else {
         programs.push_back(pipeline_order(ops, &nslots));
     }
+    auto lead_of = [&](const rt_op &op) -> const std::vector<leaf_ref> & {
+        static const std::vector<leaf_ref> none;
+        const sparse_plan &plan = plans[cur_prog];
+        return sparse && (size_t)op.node < plan.lead.size() ? plan.lead[(size_t)op.node] : none;
+    };
+    auto trail_of = [&](const rt_op &op) -> const std::vector<leaf_ref> & {
+        static const std::vector<leaf_ref> none;
+        const sparse_plan &plan = plans[cur_prog];
+        return sparse && (size_t)op.node < plan.trail.size() ? plan.trail[(size_t)op.node] : none;
+    };
     int nrec_max = 0, nrec_all = 0, nlate = 0;
     for (const auto &pr : programs) {
         nrec_max = std::max(nrec_max, (int)pr.size());
@@ -1570,7 +1663,7 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
     // targets it (that would make step i late)
     std::ostringstream o;
     o << "// generated by raoteh_amd/csrc/jit.hip (split-M MFMA family, pipelined"
-      << (halves ? ", root halves" : "") << "): " << nrec_all
+      << (halves ? ", root halves" : "") << (sparse ? ", leaf states" : "") << "): " << nrec_all
       << " steps (" << nlate << " serial), " << n << " states, " << K << " observed nodes, " << T
       << " tiles per workgroup of " << NT << " waves, " << nslots << " accumulator slots, prefetch "
       << D << " leaves\n";
@@ -1597,7 +1690,9 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
          "             int *__restrict__ status, double *__restrict__ partial,\n"
          "             long nsites, long nblocks"
       << (halves ? ", double *__restrict__ halfbuf" : "")
-      << (fold ? ", int *__restrict__ counters" : "") << ")\n{\n";
+      << (fold ? ", int *__restrict__ counters" : "")
+      << (sparse ? ", const unsigned *__restrict__ leafw, const double *__restrict__ Pesd" : "")
+      << ")\n{\n";
     // two OBJECTS, not one array of two: step i reads xb<i & 1> while x of step i + 1 is
     // written to the other one, and only for distinct objects does the compiler know that
     // an LDS read may be hoisted above an earlier LDS write (with one array every read of
@@ -1634,6 +1729,8 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
                 o << "    double a" << sl << "_" << t << "_" << r << " = 1.0;\n";
     }
     o << "    const rt_d2 zero2 = {0.0, 0.0};\n";
+    if (sparse)      // this wave's row tile of every A-fragment record, at this lane's row-lane
+        o << "    const double *pfm = Pfrag + (m * " << KP * 128 << " + (lane >> 4) * 2);\n";
     // the root step: x of the root -> weighted sum over the states (_mc0_dense.py:184-209,
     // as prune_mfma_kernel); xp = name prefix of the root's x values (xp_<tile>_<row>)
     auto emit_root_reduce = [&](std::ostream &os, const std::string &xp) {
@@ -1694,6 +1791,7 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
         for (size_t i = 0; i < ops.size(); ++i) rec_of_node[(size_t)ops[i].node] = (int)i;
     }
     for (size_t prog = 0; prog < programs.size(); ++prog) {
+    cur_prog = prog;
     const std::vector<pipe_step> &st = programs[prog];
     const int nrec = (int)st.size();
     if (halves) o << (prog == 0 ? "    if (half == 0) {\n" : "    } else {\n");
@@ -1730,23 +1828,69 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
             os << "    const double pc" << k << "_" << r << " = __shfl(A" << k << "_" << ((KS - 1) >> 1)
                << (((KS - 1) & 1) ? ".y" : ".x") << ", " << 4 * r << " + (lane >> 4), 64);\n";
     };
+    // (sparse) the state words of the leaves, four leaves a word, loaded where first needed in
+    // this program; then this lane's four entries of column `state` of the leaf's P (zero in the
+    // padded rows): pc<leaf node>_<tile>_<row>
+    const int KW = (K + 3) / 4;
+    std::vector<char> word_seen((size_t)std::max(KW, 1), 0), leaf_seen;
+    auto emit_gather = [&](std::ostream &os, const leaf_ref &lf) {
+        if ((size_t)lf.node >= leaf_seen.size()) leaf_seen.resize((size_t)lf.node + 1, 0);
+        if (leaf_seen[(size_t)lf.node]) return;
+        leaf_seen[(size_t)lf.node] = 1;
+        const int w = lf.obs >> 2;
+        if (!word_seen[(size_t)w]) {
+            word_seen[(size_t)w] = 1;
+            for (int t = 0; t < T; ++t)
+                os << "    const unsigned lw" << prog << "_" << w << "_" << t << " = leafw[((size_t)(tile" << t
+                   << " < nblocks ? tile" << t << " : nblocks - 1) * " << KW << " + " << w
+                   << ") * 16 + (lane & 15)];\n";
+        }
+        // Column `state` of P from the leaf's A-fragment record (Pfrag[rec][m][q][lane][e2] =
+        // P[16 m + (lane & 15)][4 (2 q + e2) + (lane >> 4)], zero in the padding): the four
+        // row-lanes of a site then read one 64-byte sector together, where the row-major P costs
+        // a sector per lane -- the gathers, not the products, bounded the first version.
+        const int rec = rec_of_node[(size_t)lf.node];
+        for (int t = 0; t < T; ++t) {
+            os << "    const int st" << lf.node << "_" << t << " = (int)((lw" << prog << "_" << w << "_" << t
+               << " >> " << 8 * (lf.obs & 3) << ") & 255u);\n";
+            os << "    const double *pf" << lf.node << "_" << t << " = pfm + " << (long)rec * NT * KP * 128
+               << " + (st" << lf.node << "_" << t << " >> 3) * 128 + (st" << lf.node << "_" << t
+               << " & 3) * 32 + ((st" << lf.node << "_" << t << " >> 2) & 1);\n";
+            for (int r = 0; r < 4; ++r)
+                os << "    const double pc" << lf.node << "_" << t << "_" << r << " = pf" << lf.node << "_" << t
+                   << "[" << 8 * r << "];\n";
+        }
+    };
+    auto emit_gathers_of = [&](std::ostream &os, int k) {       // everything issue step k names
+        if (!sparse || k < 0 || k >= nrec) return;
+        for (const leaf_ref &lf : lead_of(st[(size_t)k].op)) emit_gather(os, lf);
+        for (const leaf_ref &lf : trail_of(st[(size_t)k].op)) emit_gather(os, lf);
+    };
     // own rows of x for issue step k
     auto emit_x = [&](std::ostream &os, int k) {
         const rt_op &op = st[(size_t)k].op;
+        const std::vector<leaf_ref> &tr = trail_of(op);
         for (int t = 0; t < T; ++t)
             for (int r = 0; r < 4; ++r) {
                 std::ostringstream obs_r;
                 if (op.obs >= 0)
                     obs_r << "o" << op.obs << "_" << t << "_" << (r >> 1) << ((r & 1) ? ".y" : ".x");
                 os << "    const double x" << k << "_" << t << "_" << r << " = ";
+                bool any = false;
                 if (op.pop >= 0) {
                     os << "a" << op.pop << "_" << t << "_" << r;
                     if (op.obs >= 0) os << " * " << obs_r.str();
+                    any = true;
                 } else if (op.obs >= 0) {
                     os << obs_r.str();
-                } else {
-                    os << "1.0";
+                    any = true;
                 }
+                // (left to right: the order the leaves were folded into the accumulator)
+                for (const leaf_ref &lf : tr) {
+                    os << (any ? " * " : "") << "pc" << lf.node << "_" << t << "_" << r;
+                    any = true;
+                }
+                if (!any) os << "1.0";
                 os << ";\n";
             }
     };
@@ -1769,12 +1913,26 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
                     os << "    c" << k << "_" << t << "[" << r << "] = fma(pc" << k << "_" << r << ", xl" << k
                        << "_" << t << ", c" << k << "_" << t << "[" << r << "]);\n";
             }
+        const std::vector<leaf_ref> &ld = lead_of(op);
         for (int t = 0; t < T; ++t)
-            for (int r = 0; r < 4; ++r)
-                os << "    a" << d << "_" << t << "_" << r << (first ? " = " : " *= ") << "c" << k << "_"
-                   << t << "[" << r << "];\n";
+            for (int r = 0; r < 4; ++r) {
+                os << "    a" << d << "_" << t << "_" << r << " = ";
+                // (the leaves folded since the previous matrix sibling, then this result: the
+                // accumulator's own order)
+                bool any = false;
+                if (!first) {
+                    os << "a" << d << "_" << t << "_" << r;
+                    any = true;
+                }
+                for (const leaf_ref &lf : ld) {
+                    os << (any ? " * " : "") << "pc" << lf.node << "_" << t << "_" << r;
+                    any = true;
+                }
+                os << (any ? " * " : "") << "c" << k << "_" << t << "[" << r << "];\n";
+            }
     };
     // ---- prologue -----------------------------------------------------------------------
+    for (int k = 0; k < GA; ++k) emit_gathers_of(o, k);
     for (int k = 0; k < std::min(D, (int)obs_order.size()); ++k) emit_obs_load(o, obs_order[(size_t)k]);
     if (nrec > 0 && st[0].op.dst >= 0) { emit_a_load(o, 0); emit_pcol(o, 0); }
     o << "    {\n";
@@ -1806,11 +1964,24 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
                     o << "    {\n    double *hb = halfbuf + ((size_t)tile" << t << " * 2 + " << prog
                       << ") * " << XT << " + (4 * m) * 64 + lane;\n";
                     for (int r = 0; r < 4; ++r) {
-                        if (fold)
+                        if (fold) {
                             o << "    __hip_atomic_store(&hb[" << r * 64 << "], a" << op.pop << "_" << t
                               << "_" << r << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n";
-                        else
-                            o << "    hb[" << r * 64 << "] = a" << op.pop << "_" << t << "_" << r << ";\n";
+                        } else {
+                            // (sparse: the root's leaf children of this program are factors)
+                            o << "    hb[" << r * 64 << "] = ";
+                            bool any = false;
+                            if (op.pop >= 0) {
+                                o << "a" << op.pop << "_" << t << "_" << r;
+                                any = true;
+                            }
+                            for (const leaf_ref &lf : trail_of(op)) {
+                                o << (any ? " * " : "") << "pc" << lf.node << "_" << t << "_" << r;
+                                any = true;
+                            }
+                            if (!any) o << "1.0";
+                            o << ";\n";
+                        }
                     }
                     o << "    }\n";
                 }
@@ -1837,6 +2008,7 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
             if (rank + D < (int)obs_order.size()) emit_obs_load(sh, obs_order[(size_t)(rank + D)]);
         }
         if (i + 1 < nrec && st[(size_t)(i + 1)].op.dst >= 0) emit_a_load(sh, i + 1);
+        emit_gathers_of(sh, i + GA);
         if (fold_pending) { emit_fold(sh, i - 1); fold_pending = false; }
         if (have_next && !next_root && !next_late) emit_publish(sh, i + 1);
         // (behind everything else: the fragment it reads was requested at the top of this shadow)
@@ -2483,8 +2655,11 @@ int rt_launch_prune_jit(rt_model *m, rt_sites *s, const rt_fuse_args *fuse)
         double *half = s->d_half;
         const double *chalf = s->d_half;
         int *counters = s->d_half_count;
-        void *hargs[] = {&Pord, &obs, &root_w, &loglik, &status, &partial, &nsites, &nblocks, &half,
-                         &counters};
+        void *hargs_dense[] = {&Pord, &obs, &root_w, &loglik, &status, &partial, &nsites, &nblocks, &half,
+                               &counters};
+        void *hargs_sparse[] = {&Pord, &obs, &root_w, &loglik, &status, &partial, &nsites, &nblocks,
+                                &half, &leafw, &Pesd};
+        void **hargs = s->jit_sparse ? hargs_sparse : hargs_dense;
         if (s->jit_fold) {
             // one kernel: the second workgroup of every pair finishes the pair's tiles
             const unsigned tpb = 64u * (unsigned)s->jit_waves;

@@ -1874,7 +1874,9 @@ int rt_launch_prune(rt_model *m, rt_sites *s, bool defer_reduce, bool fuse_expm)
             else
             snprintf(jit_name, sizeof(s->kernel_name), "prune_tree_jit_mfma%s<%d,T%d%s>",
                      s->jit_quad ? "4x4" : "", (int)m->n, s->jit_tiles,
-                     s->jit_sparse ? ",leaf-states" : s->jit_halves ? ",halves" : "");
+                     s->jit_sparse && s->jit_halves ? ",halves,leaf-states"
+                     : s->jit_sparse ? (s->jit_pipe ? ",pipelined,leaf-states" : ",leaf-states")
+                     : s->jit_halves ? ",halves" : "");
         name = jit_name;
     } else if (s->layout == RT_LAYOUT_LANE) {
         switch ((int)m->n) {

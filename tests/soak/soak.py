@@ -68,6 +68,15 @@ def main():
                 states = rng.randint(0, 1 << n, size=(nsites, len(obs_nodes))).astype(np.uint64)
                 dense = ((states[..., None] >> np.arange(n, dtype=np.uint64)) & 1
                          ).astype(np.float64)
+        if n > 32 and rng.uniform() < 0.4:
+            # observed states at every leaf and nowhere else: the kernels whose leaves are
+            # gathered columns of P (serial and pipelined generators, root halves)
+            obs_nodes = list(leaves)
+            states = rng.randint(0, n, size=(nsites, len(obs_nodes))).astype(np.uint8)
+            dense = np.zeros((nsites, len(obs_nodes), n))
+            ii, kk = np.indices(states.shape)
+            dense[ii, kk, states] = 1.0
+            skind = 'state'
         pre, idx, ptr, esd = orc.get_esd_transitions(T, root, n)
         oidx = [pre.index(v) for v in obs_nodes]
         # the oracle on a bounded sample of the sites
@@ -103,10 +112,17 @@ def main():
                     os.environ['RAOTEH_JIT_FOLD'] = '1' if (cases + tiles) % 2 else '0'
                 _lib.check(set_option(b'jit_block_sites', bs if n <= 4 else 0))
             try:
-                if jit and states is not None:
-                    batch = model.upload_sites(obs_nodes, states, kind=skind)
-                else:
-                    batch = model.upload_sites(obs_nodes, dense, kind='dense')
+                try:
+                    if jit and states is not None:
+                        batch = model.upload_sites(obs_nodes, states, kind=skind)
+                    else:
+                        batch = model.upload_sites(obs_nodes, dense, kind='dense')
+                except Exception:
+                    print('UPLOAD FAILED', dict(case=cases, n=n, nnodes=nnodes, nsites=nsites,
+                                                variant=(jit, tiles, bs, halves), kind=skind,
+                                                root=root, obs_nodes=obs_nodes,
+                                                edges=list(nx.bfs_edges(T, root))))
+                    raise
                 ll, st = model.log_likelihoods(batch)
                 tot = model.fetch_totals(batch)
                 out.append((ll, st, tot, ctx.kernel_time(1)[2], (jit, tiles, bs, halves)))
