@@ -330,11 +330,17 @@ expect_down_lds_kernel(const double *__restrict__ PfragT, int nops, const int2 *
 // one, drains the queue; a conditional load makes the compiler drain it at the back edge.  A
 // fetch past the chunk's last tile reads the next tiles or steps of the same scratch block -- U
 // is followed by the partials, L by M -- and is never used.
+// L of an observed leaf is not in Larr (the upward pass does not store it): it is the leaf's
+// observation vector in the batch's resident image, obs[tile][k][pair q][lane][2] = the B-operand
+// pairs of states 8 q .. 8 q + 7 (leaf_k[step] = the leaf's stream position k, or -1).  State
+// 16 mb + lo of sites 4 hi .. 4 hi + 3 are four doubles at stride 2 there: eight consecutive
+// doubles are loaded and the ones of this state's k-step parity picked.
 template <int NT, bool WEIGHTS>
 __global__ void __launch_bounds__(64 * NT)
 expect_wsum_kernel(int nops, const double *__restrict__ Uarr, const double *__restrict__ Larr,
                    const double *__restrict__ weights, long nsites, long nblocks,
-                   double *__restrict__ partial)
+                   double *__restrict__ partial, const int *__restrict__ leaf_k,
+                   const double *__restrict__ obs, int K, int KP)
 {
     __shared__ double redw[NT * NT * 256];
     const int lane = threadIdx.x & 63;
@@ -385,27 +391,103 @@ expect_wsum_kernel(int nops, const double *__restrict__ Uarr, const double *__re
                                                                            0, 0, 0);
                 }
         };
-#define RT_WSUM_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-        double4_t uA[NT], lA[NT], wA, uB[NT], lB[NT], wB, uC[NT], lC[NT], wC;
-        fetch(uA, lA, wA);
-        fetch(uB, lB, wB);
-        RT_WSUM_FENCE();
-        for (int tile = first; tile < t1; tile += 3 * NT) {
-            fetch(uC, lC, wC);
-            RT_WSUM_FENCE();
-            compute(uA, lA, wA);
-            RT_WSUM_FENCE();
-            if (tile + NT < t1) {
-                fetch(uA, lA, wA);
-                RT_WSUM_FENCE();
-                compute(uB, lB, wB);
-                RT_WSUM_FENCE();
+        // ---- the same for an observed leaf: L from the observation image
+        const int lk = leaf_k[step];                 // (uniform)
+        const int par = (lo >> 2) & 1;               // which double of a pair this state is
+        const double *po = obs + ((size_t)first * K + (lk >= 0 ? lk : 0)) * KP * 128 +
+                           (size_t)(lo >> 3) * 128 + ((lo & 3) * 16 + 4 * hi) * 2;
+        const size_t obs_stride = (size_t)NT * K * KP * 128;
+        auto fetch_leaf = [&](double4_t (&u)[NT], double4_t (&l0)[NT], double4_t (&l1)[NT], double4_t &w) {
+#pragma unroll
+            for (int mm = 0; mm < NT; ++mm) {
+                u[mm] = *(const double4_t *)(pu + mm * 256);
+                // pair q = 2 mm + (lo >> 3); beyond the last pair: padding (zeros, selected below)
+                const bool ok = 2 * mm + (lo >> 3) < KP;
+                const double *p = po + (ok ? 2 * mm * 128 : 0);
+                l0[mm] = *(const double4_t *)p;
+                l1[mm] = *(const double4_t *)(p + 4);
             }
-            if (tile + 2 * NT < t1) {
-                fetch(uB, lB, wB);
+            const long site = (long)ftile * 16 + 4 * hi;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const long sc = site + ks < nsites ? site + ks : nsites - 1;
+                const double wgt = WEIGHTS ? weights[sc] : 1.0;
+                w[ks] = site + ks < nsites ? wgt : 0.0;
+            }
+            pu += NT * tile_stride;
+            if (ftile + NT < nb) po += obs_stride;     // (the image ends with the last tile)
+            ftile += NT;
+        };
+        auto compute_leaf = [&](const double4_t (&u)[NT], const double4_t (&l0)[NT],
+                                const double4_t (&l1)[NT], const double4_t &w) {
+            // the eight doubles are sites 4 hi .. 4 hi + 3 as pairs (even, odd k-step of the
+            // pair): site ks of this state = element 2 ks + par
+            double lv[NT][4];
+#pragma unroll
+            for (int mb = 0; mb < NT; ++mb) {
+                const bool ok = 2 * mb + (lo >> 3) < KP;
+                lv[mb][0] = ok ? (par ? l0[mb][1] : l0[mb][0]) : 0.0;
+                lv[mb][1] = ok ? (par ? l0[mb][3] : l0[mb][2]) : 0.0;
+                lv[mb][2] = ok ? (par ? l1[mb][1] : l1[mb][0]) : 0.0;
+                lv[mb][3] = ok ? (par ? l1[mb][3] : l1[mb][2]) : 0.0;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int ma = 0; ma < NT; ++ma) {
+                    const double av = u[ma][ks] * w[ks];
+#pragma unroll
+                    for (int mb = 0; mb < NT; ++mb)
+                        acc[ma][mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, lv[mb][ks], acc[ma][mb],
+                                                                           0, 0, 0);
+                }
+        };
+#define RT_WSUM_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+        if (lk < 0) {
+            double4_t uA[NT], lA[NT], wA, uB[NT], lB[NT], wB, uC[NT], lC[NT], wC;
+            fetch(uA, lA, wA);
+            fetch(uB, lB, wB);
+            RT_WSUM_FENCE();
+            for (int tile = first; tile < t1; tile += 3 * NT) {
+                fetch(uC, lC, wC);
                 RT_WSUM_FENCE();
-                compute(uC, lC, wC);
+                compute(uA, lA, wA);
                 RT_WSUM_FENCE();
+                if (tile + NT < t1) {
+                    fetch(uA, lA, wA);
+                    RT_WSUM_FENCE();
+                    compute(uB, lB, wB);
+                    RT_WSUM_FENCE();
+                }
+                if (tile + 2 * NT < t1) {
+                    fetch(uB, lB, wB);
+                    RT_WSUM_FENCE();
+                    compute(uC, lC, wC);
+                    RT_WSUM_FENCE();
+                }
+            }
+        } else {
+            double4_t uA[NT], pA[NT], qA[NT], wA, uB[NT], pB[NT], qB[NT], wB, uC[NT], pC[NT], qC[NT], wC;
+            fetch_leaf(uA, pA, qA, wA);
+            fetch_leaf(uB, pB, qB, wB);
+            RT_WSUM_FENCE();
+            for (int tile = first; tile < t1; tile += 3 * NT) {
+                fetch_leaf(uC, pC, qC, wC);
+                RT_WSUM_FENCE();
+                compute_leaf(uA, pA, qA, wA);
+                RT_WSUM_FENCE();
+                if (tile + NT < t1) {
+                    fetch_leaf(uA, pA, qA, wA);
+                    RT_WSUM_FENCE();
+                    compute_leaf(uB, pB, qB, wB);
+                    RT_WSUM_FENCE();
+                }
+                if (tile + 2 * NT < t1) {
+                    fetch_leaf(uB, pB, qB, wB);
+                    RT_WSUM_FENCE();
+                    compute_leaf(uC, pC, qC, wC);
+                    RT_WSUM_FENCE();
+                }
             }
         }
 #undef RT_WSUM_FENCE
@@ -584,12 +666,14 @@ int expect_device_passes(rt_ctx *ctx, rt_model *model, rt_sites *s, const double
     // the LDS form of the downward pass when the slots of the tree fit (RAOTEH_EXPECT_DOWN=global:
     // the first form, D through HBM)
     if (!s->d_down_meta) {
-        std::vector<int32_t> meta((size_t)nops * 2);
+        // [nops] {parent slot, own slot} then [nops] the stream position of an observed leaf (-1)
+        std::vector<int32_t> meta((size_t)nops * 3);
         int nslots = 0;
         for (int i = 0; i < nops; ++i) {
             const rt_op &op = s->ops[(size_t)i];
             meta[(size_t)i * 2] = op.dst >= 0 ? (op.dst & 255) : 0;
             meta[(size_t)i * 2 + 1] = op.pop;
+            meta[(size_t)nops * 2 + i] = (op.pop < 0 && op.obs >= 0) ? op.obs : -1;
             if (op.dst >= 0) nslots = std::max(nslots, (op.dst & 255) + 1);
             if (op.pop >= 0) nslots = std::max(nslots, op.pop + 1);
         }
@@ -613,12 +697,16 @@ int expect_device_passes(rt_ctx *ctx, rt_model *model, rt_sites *s, const double
                            d_PT, nops, d_parent_step, d_internal, d_L, d_M, d_D, d_U, d_root_w, (int)n,
                            d_status, (long)nsites, nblocks);
     }
+    const int *d_leaf_k = s->d_down_meta + (size_t)nops * 2;
+    const int KPo = (KS + 1) / 2;
     if (d_w)
         hipLaunchKernelGGL((expect_wsum_kernel<NT, true>), dim3((unsigned)(nops - 1), EX_CHUNKS),
-                           dim3(64 * NT), 0, st, nops, d_U, d_L, d_w, (long)nsites, nblocks, d_part);
+                           dim3(64 * NT), 0, st, nops, d_U, d_L, d_w, (long)nsites, nblocks, d_part,
+                           d_leaf_k, (const double *)s->d_obs, (int)s->nobs, KPo);
     else
         hipLaunchKernelGGL((expect_wsum_kernel<NT, false>), dim3((unsigned)(nops - 1), EX_CHUNKS),
-                           dim3(64 * NT), 0, st, nops, d_U, d_L, d_w, (long)nsites, nblocks, d_part);
+                           dim3(64 * NT), 0, st, nops, d_U, d_L, d_w, (long)nsites, nblocks, d_part,
+                           d_leaf_k, (const double *)s->d_obs, (int)s->nobs, KPo);
     hipLaunchKernelGGL(expect_finish_kernel, dim3((unsigned)(nops - 1)), dim3(256), 0, st, (int)n, NT,
                        nops, d_step_node, esd_dev, d_part, d_W);
     hipLaunchKernelGGL(expect_root_kernel, dim3(EX_ROOT_CHUNKS), dim3(64), 0, st, (int)n, NT, nops - 1,

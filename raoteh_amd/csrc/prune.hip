@@ -759,7 +759,9 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
             for (int r = 0; r < 4; ++r) x[r] = (flags & LOP_OBS) ? on[r] : 1.0;
         }
         if (flags & LOP_OBS) knext += 1;
-        if (STORE && live) {
+        // (L of an observed leaf is its observation vector, which is resident already: the site
+        // sums read it from there, expect_mfma.hip -- a quarter of this pass's stores)
+        if (STORE && live && ((flags & LOP_INTERNAL) || !(flags & LOP_OBS))) {
             double *lo = Lout + ((size_t)i * nblocks16 + gt) * (NT * 256) + (m * 4) * 64 + lane;
 #pragma unroll
             for (int r = 0; r < 4; ++r) lo[r * 64] = x[r];
