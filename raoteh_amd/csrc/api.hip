@@ -1007,7 +1007,8 @@ static int sites_alloc(rt_sites *s, bool generic)
         e = hipMalloc((void **)&s->d_half,       // (padded to whole groups of <= 8 tiles)
                       (size_t)(s->nblocks + 8) * 2 * ((n + 15) / 16) * 4 * 64 * 8);
     if (e == hipSuccess && s->sparse_ok)
-        e = hipMalloc((void **)&s->d_leafw, (size_t)s->nblocks * ((s->nobs + 3) / 4) * 16 * 4 + 64);
+        e = hipMalloc((void **)&s->d_leafw,
+                      (size_t)s->nblocks * (s->sparse_pairs ? (s->nobs + 1) / 2 : (s->nobs + 3) / 4) * 16 * 4 + 64);
     if (e == hipSuccess && s->jit_halves) {
         e = hipMalloc((void **)&s->d_half_count, (size_t)(s->nblocks + 8) * 4);
         if (e == hipSuccess) e = hipMemset(s->d_half_count, 0, (size_t)(s->nblocks + 8) * 4);
@@ -1172,8 +1173,10 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
             !mfma ? rt_jit_lane_source(s->ops, n, K, ov->D, ov->LA, ov->S, ov->WG, ov->compact,
                                        ov->fuse)
             : split && ov->sparse && ov->pipe
-                ? rt_jit_mfma_split_pipelined_source(s->ops, n, K, ov->T, ov->D, ov->LA, ov->halves, true)
-            : split && ov->sparse ? rt_jit_mfma_split_source(s->ops, n, K, ov->T, ov->D, ov->LA, true)
+                ? rt_jit_mfma_split_pipelined_source(s->ops, n, K, ov->T, ov->D, ov->LA, ov->halves,
+                                                     s->sparse_pairs ? 2 : 1)
+            : split && ov->sparse ? rt_jit_mfma_split_source(s->ops, n, K, ov->T, ov->D, ov->LA,
+                                                             s->sparse_pairs ? 2 : 1)
             : split ? split_source(s->ops, n, K, ov->T, ov->D, ov->LA, ov->halves)
                     : rt_jit_mfma_source(s->ops, n, K, ov->T, ov->D, ov->LA, ov->quad);
         RT_TRY(rt_jit_get(s->model->ctx, src, &s->jit_fn, mfma));
@@ -1251,7 +1254,7 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
                 // expressions (n <= 64; the dense kernels' tiling: root halves at T, at one tile,
                 // the whole tree), then the serial generator; RAOTEH_JIT_SPARSE=serial: only that
                 const char *sv = getenv("RAOTEH_JIT_SPARSE");
-                if (!wide && !(sv && strcmp(sv, "serial") == 0)) {
+                if (!(sv && strcmp(sv, "serial") == 0)) {
                     for (int t = T, h = halves;;) {
                         cands.push_back({t, h != 0, false, true, true});
                         if (h && t > 1) t = 1;
@@ -1261,11 +1264,12 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
                     }
                 }
                 for (int t = Ts; t >= 1; --t) cands.push_back({t, false, false, true, false});
+                const int smode = s->sparse_pairs ? 2 : 1;
                 auto make = [&](const rt_sites::jit_cand &c) {
                     return c.pipe ? rt_jit_mfma_split_pipelined_source(s->ops, (int)s->model->n, (int)s->nobs,
-                                                                       c.T, D, LA, c.halves, true)
+                                                                       c.T, D, LA, c.halves, smode)
                                   : rt_jit_mfma_split_source(s->ops, (int)s->model->n, (int)s->nobs, c.T, D,
-                                                             LA, true);
+                                                             LA, smode);
                 };
                 if (!forced && opt_jit_async(s->model->ctx) && sites_jit_start_async(s, cands, make))
                     return RT_OK;
@@ -1529,12 +1533,13 @@ extern "C" int rt_jit_source(int64_t nnodes, const int64_t *idx, const int64_t *
                              getenv("RAOTEH_JIT_FUSE_EXPM") && atoi(getenv("RAOTEH_JIT_FUSE_EXPM")) != 0)
         : n <= 32 ? rt_jit_mfma_source(m.ops, (int)n, (int)nobs, std::min(T, 4), (int)prefetch, 1,
                                        !(getenv("RAOTEH_JIT_QUAD") && atoi(getenv("RAOTEH_JIT_QUAD")) == 0))
-                  : getenv("RAOTEH_JIT_SOURCE_SPARSE") && strcmp(getenv("RAOTEH_JIT_SOURCE_SPARSE"), "pipe") == 0
+                  : getenv("RAOTEH_JIT_SOURCE_SPARSE") && strncmp(getenv("RAOTEH_JIT_SOURCE_SPARSE"), "pipe", 4) == 0
                         ? rt_jit_mfma_split_pipelined_source(
                               m.ops, (int)n, (int)nobs, T, 2, 1,
-                              getenv("RAOTEH_JIT_HALVES") && atoi(getenv("RAOTEH_JIT_HALVES")), true)
+                              getenv("RAOTEH_JIT_HALVES") && atoi(getenv("RAOTEH_JIT_HALVES")),
+                              strcmp(getenv("RAOTEH_JIT_SOURCE_SPARSE"), "pipe2") == 0 ? 2 : 1)
                   : getenv("RAOTEH_JIT_SOURCE_SPARSE")
-                        ? rt_jit_mfma_split_source(m.ops, (int)n, (int)nobs, std::min(T, 2), 2, 1, true)
+                        ? rt_jit_mfma_split_source(m.ops, (int)n, (int)nobs, std::min(T, 2), 2, 1, 1)
                   : split_source(m.ops, (int)n, (int)nobs,
                                  getenv("RAOTEH_JIT_HALVES") && atoi(getenv("RAOTEH_JIT_HALVES"))
                                      ? T : std::min(T, 3), (int)prefetch, 1,
@@ -1624,6 +1629,30 @@ static int sites_create_impl(rt_model *m, int64_t nsites, int kind, int64_t nobs
         const size_t count = (size_t)nsites * (size_t)nobs;
         for (size_t i = 0; ok && i < count; ++i) ok = bytes[i] < m->n;
         s->sparse_ok = ok;
+    }
+    // ... and allowed SETS of one or two states at every leaf (the compound models: a codon in
+    // either class of the switching model, liwen.py:682): the leaf's message is one column of P
+    // or the sum of two
+    if (kind == RT_OBS_MASK && s->layout == RT_LAYOUT_MFMA && !s->mfma_solo && !generic && nobs > 0 &&
+        !s->rescale && opt_leaf_state_kernels(m->ctx) && !getenv("RAOTEH_JIT_NO_SPARSE") &&
+        (!ov || ov->sparse)) {
+        bool ok = true;
+        for (const rt_op &op : s->ops)
+            if (op.obs >= 0 && !(op.pop < 0 && op.dst >= 0)) ok = false;
+        const uint64_t *words = (const uint64_t *)data;
+        const size_t nw = (size_t)((m->n + 63) / 64);
+        const size_t count = (size_t)nsites * (size_t)nobs;
+        const uint64_t top = (m->n & 63) ? ((1ull << (m->n & 63)) - 1) : ~0ull;
+        for (size_t i = 0; ok && i < count; ++i) {
+            int bits = 0;
+            for (size_t w = 0; w < nw; ++w) {
+                const uint64_t v = words[i * nw + w] & (w + 1 == nw ? top : ~0ull);
+                bits += __builtin_popcountll(v);
+            }
+            ok = bits == 1 || bits == 2;
+        }
+        s->sparse_ok = ok;
+        s->sparse_pairs = ok;
     }
     int rc = sites_jit(s, generic || s->rescale, kind, ov);    // before the layout is fixed: block_sites
     // a freshly compiled kernel is checked against the interpreter kernel on a probe batch
@@ -1745,7 +1774,8 @@ static int verify_jit_kernel(rt_sites *s, int kind)
     for (int64_t v = 0; v < N; ++v)
         if (s->node_obs[(size_t)v] >= 0) obs_nodes[(size_t)s->node_obs[(size_t)v]] = v;
     // observations of the kind the kernel was specialised for (compact kernels read bytes)
-    const int pkind = (s->compact_states == 1 || s->jit_sparse) ? RT_OBS_STATE
+    const int pkind = s->jit_sparse && s->sparse_pairs ? RT_OBS_MASK
+                    : (s->compact_states == 1 || s->jit_sparse) ? RT_OBS_STATE
                     : s->compact_states == 2 ? RT_OBS_MASK : RT_OBS_DENSE;
     (void)kind;
     std::vector<double> dense;
@@ -1767,6 +1797,16 @@ static int verify_jit_kernel(rt_sites *s, int kind)
             v = (u < 0.15 && !s->jit_sparse) ? 255 : (unsigned char)((int)(next() * n) % (int)n);
         }
         data = states.data();
+    } else if (s->jit_sparse && s->sparse_pairs) {
+        // one or two allowed states per leaf (what the pair-gathering kernels take)
+        const size_t nw = (size_t)((n + 63) / 64);
+        masks.assign((size_t)np * K * nw, 0);
+        for (size_t i = 0; i < (size_t)np * K; ++i) {
+            const int a1 = (int)(next() * n) % (int)n, b1 = (int)(next() * n) % (int)n;
+            masks[i * nw + (size_t)(a1 >> 6)] |= 1ull << (a1 & 63);
+            if (next() < 0.8) masks[i * nw + (size_t)(b1 >> 6)] |= 1ull << (b1 & 63);
+        }
+        data = masks.data();
     } else {
         masks.resize((size_t)np * K);
         for (uint64_t &v : masks) v = 1 + (uint64_t)(next() * ((1ull << n) - 1));
@@ -2031,6 +2071,7 @@ extern "C" int rt_sites_clone(rt_sites *src, rt_sites **out)
     s->jit_kind = src->jit_kind;
     s->jit_compile_s = src->jit_compile_s;
     s->sparse_ok = src->sparse_ok;
+    s->sparse_pairs = src->sparse_pairs;
     s->jit_sparse = src->jit_sparse;
     s->jit_pipe = src->jit_pipe;
     int rc = sites_alloc(s, src->d_scratch != nullptr);

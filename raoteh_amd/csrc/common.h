@@ -268,6 +268,7 @@ struct rt_sites {
     // batch keeps the state bytes (leafw[tile][ceil(K/4)][16 sites], four stream positions per
     // word) for the tree-specialised kernel whose leaf steps gather columns of P (jit.hip)
     bool sparse_ok = false;
+    bool sparse_pairs = false;       // ... as allowed sets of one or two states (RT_OBS_MASK): 16 bits per leaf
     bool jit_sparse = false;
     bool jit_pipe = false;                  // ... from the pipelined generator (leaves as factors)
     unsigned *d_leafw = nullptr;
@@ -344,12 +345,13 @@ std::string rt_jit_lane_source(const std::vector<rt_op> &ops, int n, int K, int 
                                int S, int WG, int compact = 0, bool fuse = false);
 std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int T, int D, int LA,
                                bool quad = false);
+// (sparse: 0 dense leaf vectors, 1 one observed state per leaf, 2 one or two allowed states)
 std::string rt_jit_mfma_split_source(const std::vector<rt_op> &ops, int n, int K, int T, int D,
-                                     int LA, bool sparse = false);
+                                     int LA, int sparse = 0);
 bool rt_jit_fold_enabled();
 std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, int n, int K, int T,
                                                int D, int LA, bool halves = false,
-                                               bool sparse = false);
+                                               int sparse = 0);
 // steps of the two root programs the halves form would run (0, 0: the root has < 2 children)
 void rt_jit_root_halves(const std::vector<rt_op> &ops, int *stepsA, int *stepsB);
 // the cut itself: A = the subtrees of all children of the root but the last, B = the last

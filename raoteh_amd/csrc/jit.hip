@@ -1074,7 +1074,7 @@ std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int 
 // leafw[tile][ceil(K/4)][16 sites].  Only for batches whose observed nodes are all leaves and
 // whose states are all observed (api.hip).
 std::string rt_jit_mfma_split_source(const std::vector<rt_op> &ops, int n, int K, int T, int D,
-                                     int LA, bool sparse)
+                                     int LA, int sparse)
 {
     const int NT = (n + 15) / 16;
     const int KS = (n + 3) / 4;
@@ -1087,7 +1087,8 @@ std::string rt_jit_mfma_split_source(const std::vector<rt_op> &ops, int n, int K
         if (op.dst >= 0) nslots = std::max(nslots, (op.dst & 255) + 1);
     }
     std::ostringstream o;
-    o << "// generated by raoteh_amd/csrc/jit.hip (split-M MFMA family" << (sparse ? ", leaf states" : "")
+    o << "// generated by raoteh_amd/csrc/jit.hip (split-M MFMA family"
+      << (sparse == 2 ? ", leaf state pairs" : sparse ? ", leaf states" : "")
       << "): " << nrec << " steps, "
       << n << " states, " << K << " observed nodes, " << T << " tiles per workgroup of " << NT
       << " waves, prefetch " << D << " leaves / " << LA << " P records\n";
@@ -1160,8 +1161,9 @@ std::string rt_jit_mfma_split_source(const std::vector<rt_op> &ops, int n, int K
         return sparse && op.pop < 0 && op.obs >= 0 && op.dst >= 0;
     };
     if (sparse) {
-        // the state bytes of every leaf of the workgroup's tiles, four per word
-        const int KW = (K + 3) / 4;
+        // the state bytes of every leaf of the workgroup's tiles, four per word (two per word
+        // for allowed sets of one or two states: 16 bits per leaf)
+        const int KW = sparse == 2 ? (K + 1) / 2 : (K + 3) / 4;
         for (int t = 0; t < T; ++t)
             for (int w = 0; w < KW; ++w)
                 o << "    const unsigned lw" << w << "_" << t << " = leafw[((size_t)(tile" << t
@@ -1173,15 +1175,32 @@ std::string rt_jit_mfma_split_source(const std::vector<rt_op> &ops, int n, int K
     // record (zero in the padded rows): the four row-lanes of a site share a 64-byte sector
     auto emit_gather = [&](int i) {
         const rt_op &op = ops[(size_t)i];
+        const int w = sparse == 2 ? op.obs >> 1 : op.obs >> 2;
+        const int sh = sparse == 2 ? 16 * (op.obs & 1) : 8 * (op.obs & 3);
         for (int t = 0; t < T; ++t) {
-            o << "    const int st" << i << "_" << t << " = (int)((lw" << (op.obs >> 2) << "_" << t
-              << " >> " << 8 * (op.obs & 3) << ") & 255u);\n";
+            o << "    const int st" << i << "_" << t << " = (int)((lw" << w << "_" << t
+              << " >> " << sh << ") & 255u);\n";
             o << "    const double *pf" << i << "_" << t << " = pfm + " << (long)i * NT * KP * 128 << " + (st"
               << i << "_" << t << " >> 3) * 128 + (st" << i << "_" << t << " & 3) * 32 + ((st" << i << "_"
               << t << " >> 2) & 1);\n";
-            for (int r = 0; r < 4; ++r)
+            if (sparse == 2) {
+                // the second allowed state (255: none -- the first column again, not added)
+                o << "    const int sq" << i << "_" << t << " = (int)((lw" << w << "_" << t << " >> " << sh + 8
+                  << ") & 255u);\n";
+                o << "    const int sr" << i << "_" << t << " = sq" << i << "_" << t << " == 255 ? st" << i << "_"
+                  << t << " : sq" << i << "_" << t << ";\n";
+                o << "    const double *pg" << i << "_" << t << " = pfm + " << (long)i * NT * KP * 128 << " + (sr"
+                  << i << "_" << t << " >> 3) * 128 + (sr" << i << "_" << t << " & 3) * 32 + ((sr" << i << "_"
+                  << t << " >> 2) & 1);\n";
+            }
+            for (int r = 0; r < 4; ++r) {
                 o << "    const double pc" << i << "_" << t << "_" << r << " = pf" << i << "_" << t << "["
-                  << 8 * r << "];\n";
+                  << 8 * r << "]";
+                if (sparse == 2)
+                    o << " + (sq" << i << "_" << t << " == 255 ? 0.0 : pg" << i << "_" << t << "[" << 8 * r
+                      << "])";
+                o << ";\n";
+            }
         }
     };
     if (!sparse)
@@ -1584,7 +1603,7 @@ bool rt_jit_fold_enabled()
 }
 
 std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, int n, int K, int T,
-                                               int D, int LA, bool halves, bool sparse)
+                                               int D, int LA, bool halves, int sparse)
 {
     (void)LA;
     const bool fold = halves && !sparse && rt_jit_fold_enabled();
@@ -1663,7 +1682,8 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
     // targets it (that would make step i late)
     std::ostringstream o;
     o << "// generated by raoteh_amd/csrc/jit.hip (split-M MFMA family, pipelined"
-      << (halves ? ", root halves" : "") << (sparse ? ", leaf states" : "") << "): " << nrec_all
+      << (halves ? ", root halves" : "") << (sparse == 2 ? ", leaf state pairs" : sparse ? ", leaf states" : "")
+      << "): " << nrec_all
       << " steps (" << nlate << " serial), " << n << " states, " << K << " observed nodes, " << T
       << " tiles per workgroup of " << NT << " waves, " << nslots << " accumulator slots, prefetch "
       << D << " leaves\n";
@@ -1831,13 +1851,14 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
     // (sparse) the state words of the leaves, four leaves a word, loaded where first needed in
     // this program; then this lane's four entries of column `state` of the leaf's P (zero in the
     // padded rows): pc<leaf node>_<tile>_<row>
-    const int KW = (K + 3) / 4;
+    const int KW = sparse == 2 ? (K + 1) / 2 : (K + 3) / 4;
     std::vector<char> word_seen((size_t)std::max(KW, 1), 0), leaf_seen;
     auto emit_gather = [&](std::ostream &os, const leaf_ref &lf) {
         if ((size_t)lf.node >= leaf_seen.size()) leaf_seen.resize((size_t)lf.node + 1, 0);
         if (leaf_seen[(size_t)lf.node]) return;
         leaf_seen[(size_t)lf.node] = 1;
-        const int w = lf.obs >> 2;
+        const int w = sparse == 2 ? lf.obs >> 1 : lf.obs >> 2;
+        const int shf = sparse == 2 ? 16 * (lf.obs & 1) : 8 * (lf.obs & 3);
         if (!word_seen[(size_t)w]) {
             word_seen[(size_t)w] = 1;
             for (int t = 0; t < T; ++t)
@@ -1852,13 +1873,28 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
         const int rec = rec_of_node[(size_t)lf.node];
         for (int t = 0; t < T; ++t) {
             os << "    const int st" << lf.node << "_" << t << " = (int)((lw" << prog << "_" << w << "_" << t
-               << " >> " << 8 * (lf.obs & 3) << ") & 255u);\n";
+               << " >> " << shf << ") & 255u);\n";
             os << "    const double *pf" << lf.node << "_" << t << " = pfm + " << (long)rec * NT * KP * 128
                << " + (st" << lf.node << "_" << t << " >> 3) * 128 + (st" << lf.node << "_" << t
                << " & 3) * 32 + ((st" << lf.node << "_" << t << " >> 2) & 1);\n";
-            for (int r = 0; r < 4; ++r)
+            if (sparse == 2) {
+                // the second allowed state (255: none -- the first column again, not added)
+                os << "    const int sq" << lf.node << "_" << t << " = (int)((lw" << prog << "_" << w << "_" << t
+                   << " >> " << shf + 8 << ") & 255u);\n";
+                os << "    const int sr" << lf.node << "_" << t << " = sq" << lf.node << "_" << t
+                   << " == 255 ? st" << lf.node << "_" << t << " : sq" << lf.node << "_" << t << ";\n";
+                os << "    const double *pg" << lf.node << "_" << t << " = pfm + " << (long)rec * NT * KP * 128
+                   << " + (sr" << lf.node << "_" << t << " >> 3) * 128 + (sr" << lf.node << "_" << t
+                   << " & 3) * 32 + ((sr" << lf.node << "_" << t << " >> 2) & 1);\n";
+            }
+            for (int r = 0; r < 4; ++r) {
                 os << "    const double pc" << lf.node << "_" << t << "_" << r << " = pf" << lf.node << "_" << t
-                   << "[" << 8 * r << "];\n";
+                   << "[" << 8 * r << "]";
+                if (sparse == 2)
+                    os << " + (sq" << lf.node << "_" << t << " == 255 ? 0.0 : pg" << lf.node << "_" << t << "["
+                       << 8 * r << "])";
+                os << ";\n";
+            }
         }
     };
     auto emit_gathers_of = [&](std::ostream &os, int k) {       // everything issue step k names

@@ -1435,6 +1435,44 @@ __global__ void pack_leaf_words_kernel(const unsigned char *__restrict__ data,
     }
 }
 
+// ... and as allowed sets of one or two states (masks): 16 bits per leaf, the lower state in the
+// low byte, the other one (255: none) in the high byte; word w holds stream positions 2w, 2w+1
+__global__ void pack_leaf_pairs_kernel(const unsigned long long *__restrict__ data,
+                                       const int *__restrict__ src_of_k, long nsites, long nobs,
+                                       int K, int nwords, long nblocks16, unsigned *__restrict__ out)
+{
+    const int KW = (K + 1) / 2;
+    const size_t total = (size_t)nblocks16 * KW * 16;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(e & 15);
+        const size_t r = e >> 4;
+        const int w = (int)(r % KW);
+        const long site = (long)(r / KW) * 16 + lane;
+        unsigned word = 0;
+        for (int j = 0; j < 2; ++j) {
+            const int k = 2 * w + j;
+            unsigned a = 0, b = 255;
+            if (k < K && site < nsites) {
+                const unsigned long long *mk = data + ((size_t)site * nobs + src_of_k[k]) * nwords;
+                int found = 0;
+                for (int q = 0; q < nwords; ++q) {
+                    unsigned long long v = mk[q];
+                    while (v && found < 2) {
+                        const int bit = __ffsll((long long)v) - 1;
+                        if (found == 0) a = (unsigned)(64 * q + bit);
+                        else b = (unsigned)(64 * q + bit);
+                        ++found;
+                        v &= v - 1;
+                    }
+                }
+            }
+            word |= ((a & 255u) | ((b & 255u) << 8)) << (16 * j);
+        }
+        out[e] = word;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -1496,6 +1534,10 @@ int rt_sites_pack_device(rt_sites *s, int kind, const void *d_in, const int *d_s
                 hipLaunchKernelGGL(pack_leaf_words_kernel, dim3(1024), dim3(256), 0, st,
                                    (const unsigned char *)d_in, d_src, (long)s->nsites, (long)K, K,
                                    (long)s->nblocks, s->d_leafw);
+            if (s->d_leafw && kind == RT_OBS_MASK && s->sparse_pairs)
+                hipLaunchKernelGGL(pack_leaf_pairs_kernel, dim3(1024), dim3(256), 0, st,
+                                   (const unsigned long long *)d_in, d_src, (long)s->nsites, (long)K, K,
+                                   (int)((n + 63) / 64), (long)s->nblocks, s->d_leafw);
         }
         RT_HIP(hipGetLastError());
     }

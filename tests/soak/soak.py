@@ -77,6 +77,19 @@ def main():
             ii, kk = np.indices(states.shape)
             dense[ii, kk, states] = 1.0
             skind = 'state'
+            if rng.uniform() < 0.5:
+                # ... or allowed sets of one or two states per leaf, as masks
+                other = rng.randint(0, n, size=states.shape)
+                other[rng.uniform(size=states.shape) < 0.3] = -1
+                words = (n + 63) // 64
+                masks = np.zeros(states.shape + (words,), dtype=np.uint64)
+                for arr in (states.astype(np.int64), other):
+                    ok = arr >= 0
+                    np.bitwise_or.at(masks, (ii[ok], kk[ok], arr[ok] // 64),
+                                     np.uint64(1) << (arr[ok] % 64).astype(np.uint64))
+                    dense[ii[ok], kk[ok], arr[ok]] = 1.0
+                states = masks if words > 1 else masks[..., 0]
+                skind = 'mask'
         pre, idx, ptr, esd = orc.get_esd_transitions(T, root, n)
         oidx = [pre.index(v) for v in obs_nodes]
         # the oracle on a bounded sample of the sites
