@@ -264,7 +264,6 @@ expm_taylor_wide_kernel(int n, const double *__restrict__ Q, const int *__restri
     const int half = SPLIT ? (int)(blockIdx.x & 1) : 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lr = lane & 15, lq = lane >> 4;
     const int nn = n * n;
     const int KSn = (n + 3) / 4, NTn = (n + 15) / 16;
     double *Pb = P + (long)b * nn;
