@@ -2076,7 +2076,8 @@ extern "C" int rt_sites_clone(rt_sites *src, rt_sites **out)
     s->jit_pipe = src->jit_pipe;
     int rc = sites_alloc(s, src->d_scratch != nullptr);
     if (rc == RT_OK && s->d_leafw && src->d_leafw &&
-        hipMemcpyAsync(s->d_leafw, src->d_leafw, (size_t)s->nblocks * ((s->nobs + 3) / 4) * 16 * 4,
+        hipMemcpyAsync(s->d_leafw, src->d_leafw,
+                       (size_t)s->nblocks * (s->sparse_pairs ? (s->nobs + 1) / 2 : (s->nobs + 3) / 4) * 16 * 4,
                        hipMemcpyDeviceToDevice, src->model->ctx->stream) != hipSuccess)
         rc = RT_ERR_HIP;
     if (rc == RT_OK && s->obs_bytes > 0) {

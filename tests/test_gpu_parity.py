@@ -1145,6 +1145,10 @@ def test_leaf_sets_of_one_or_two_states_are_gathered_columns(ra, n):
         try:
             bm = model.upload_sites(obs_nodes, masks, kind='mask')
             out[jit] = model.log_likelihoods(bm) + (bm.kernel_name,)
+            if jit:                               # a clone carries the leaf words too
+                twin = bm.clone()
+                np.testing.assert_array_equal(model.log_likelihoods(twin)[0], out[jit][0])
+                assert 'leaf-states' in twin.kernel_name
         finally:
             ra.lib.check(set_option(b'jit', -1))
     assert 'leaf-states' in out[1][2] and 'leaf-states' not in out[0][2], (out[0][2], out[1][2])
