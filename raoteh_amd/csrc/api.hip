@@ -1178,9 +1178,10 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
             : split && ov->sparse ? rt_jit_mfma_split_source(s->ops, n, K, ov->T, ov->D, ov->LA,
                                                              s->sparse_pairs ? 2 : 1)
             : split ? split_source(s->ops, n, K, ov->T, ov->D, ov->LA, ov->halves)
-                    : rt_jit_mfma_source(s->ops, n, K, ov->T, ov->D, ov->LA, ov->quad);
+                    : rt_jit_mfma_source(s->ops, n, K, ov->T, ov->D, ov->LA, ov->quad,
+                                         ov->sparse ? (s->sparse_pairs ? 2 : 1) : 0);
         RT_TRY(rt_jit_get(s->model->ctx, src, &s->jit_fn, mfma));
-        s->jit_sparse = split && ov->sparse;
+        s->jit_sparse = mfma && ov->sparse;
         s->jit_pipe = split && ov->sparse && ov->pipe;
         if (split && ov->halves && (!ov->sparse || ov->pipe)) RT_TRY(sites_halves_setup(s));
         s->jit_quad = mfma && !split && ov->quad;
@@ -1393,13 +1394,33 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
                 }
             }
         }
+        // observed states (or allowed sets of one or two) at every leaf, 4x4x4 form: the leaf
+        // steps read their columns from the parked blocks (first in the list; then the dense forms)
+        const int smode = s->sparse_ok && quad ? (s->sparse_pairs ? 2 : 1) : 0;
         if (!forced && opt_jit_async(s->model->ctx)) {
             std::vector<rt_sites::jit_cand> cands;
+            if (smode)
+                for (int t = T; t >= 1; --t) cands.push_back({t, false, quad, true});
             for (int t = T; t >= 1; --t) cands.push_back({t, false, quad});
             if (sites_jit_start_async(s, cands, [&](const rt_sites::jit_cand &c) {
-                    return rt_jit_mfma_source(s->ops, (int)s->model->n, (int)s->nobs, c.T, D, LA, c.quad);
+                    return rt_jit_mfma_source(s->ops, (int)s->model->n, (int)s->nobs, c.T, D, LA, c.quad,
+                                              c.sparse ? smode : 0);
                 }))
                 return RT_OK;
+        }
+        if (smode) {
+            for (int t = T; t >= 1 && rc == RT_ERR_UNSUPPORTED; --t) {
+                const std::string src = rt_jit_mfma_source(s->ops, (int)s->model->n, (int)s->nobs, t, D, LA,
+                                                           quad, smode);
+                rc = rt_jit_get(s->model->ctx, src, &s->jit_fn, true, &s->jit_compile_s);
+                if (rc == RT_OK) {
+                    s->jit_quad = quad;
+                    s->jit_tiles = t;
+                    s->jit_sparse = true;
+                    return RT_OK;
+                }
+            }
+            rc = RT_ERR_UNSUPPORTED;           // spilled at every T: the dense forms
         }
         for (; T >= 1 && rc == RT_ERR_UNSUPPORTED; --T) {         // fewer tiles if it spills
             const std::string src =
@@ -1532,7 +1553,9 @@ extern "C" int rt_jit_source(int64_t nnodes, const int64_t *idx, const int64_t *
                              getenv("RAOTEH_JIT_SOURCE_STATES") != nullptr,
                              getenv("RAOTEH_JIT_FUSE_EXPM") && atoi(getenv("RAOTEH_JIT_FUSE_EXPM")) != 0)
         : n <= 32 ? rt_jit_mfma_source(m.ops, (int)n, (int)nobs, std::min(T, 4), (int)prefetch, 1,
-                                       !(getenv("RAOTEH_JIT_QUAD") && atoi(getenv("RAOTEH_JIT_QUAD")) == 0))
+                                       !(getenv("RAOTEH_JIT_QUAD") && atoi(getenv("RAOTEH_JIT_QUAD")) == 0),
+                                       !getenv("RAOTEH_JIT_SOURCE_SPARSE") ? 0
+                                       : strcmp(getenv("RAOTEH_JIT_SOURCE_SPARSE"), "2") == 0 ? 2 : 1)
                   : getenv("RAOTEH_JIT_SOURCE_SPARSE") && strncmp(getenv("RAOTEH_JIT_SOURCE_SPARSE"), "pipe", 4) == 0
                         ? rt_jit_mfma_split_pipelined_source(
                               m.ops, (int)n, (int)nobs, T, 2, 1,
@@ -1619,7 +1642,8 @@ static int sites_create_impl(rt_model *m, int64_t nsites, int kind, int64_t nobs
     else s->lane_ring = s->lane_dma ? 0 : 8;      // 0: rt_launch_prune picks what fits
     // observed STATES, all at leaves, none unobserved, split-M family: the kernel's leaf steps
     // may gather columns of P (jit.hip, `sparse`); the dense image stays (interpreter kernel)
-    if (kind == RT_OBS_STATE && s->layout == RT_LAYOUT_MFMA && !s->mfma_solo && !generic && nobs > 0 &&
+    if (kind == RT_OBS_STATE && s->layout == RT_LAYOUT_MFMA && (!s->mfma_solo || m->d_Pquad) && !generic &&
+        nobs > 0 &&
         !s->rescale && opt_leaf_state_kernels(m->ctx) && !getenv("RAOTEH_JIT_NO_SPARSE") &&
         (!ov || ov->sparse)) {
         bool ok = true;
@@ -1633,7 +1657,8 @@ static int sites_create_impl(rt_model *m, int64_t nsites, int kind, int64_t nobs
     // ... and allowed SETS of one or two states at every leaf (the compound models: a codon in
     // either class of the switching model, liwen.py:682): the leaf's message is one column of P
     // or the sum of two
-    if (kind == RT_OBS_MASK && s->layout == RT_LAYOUT_MFMA && !s->mfma_solo && !generic && nobs > 0 &&
+    if (kind == RT_OBS_MASK && s->layout == RT_LAYOUT_MFMA && (!s->mfma_solo || m->d_Pquad) && !generic &&
+        nobs > 0 &&
         !s->rescale && opt_leaf_state_kernels(m->ctx) && !getenv("RAOTEH_JIT_NO_SPARSE") &&
         (!ov || ov->sparse)) {
         bool ok = true;
@@ -1984,7 +2009,7 @@ int rt_sites_jit_poll(rt_sites *s, bool wait)
     const bool split = m->n > 32 || !s->mfma_solo;
     s->jit_fn = fn;
     s->jit_tiles = c.T;
-    s->jit_sparse = split && c.sparse;
+    s->jit_sparse = c.sparse;
     s->jit_pipe = split && c.sparse && c.pipe;
     s->jit_quad = !split && c.quad;
     if (split) s->jit_waves = (int)((m->n + 15) / 16);

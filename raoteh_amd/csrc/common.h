@@ -344,7 +344,7 @@ struct rt_fuse_args {
 std::string rt_jit_lane_source(const std::vector<rt_op> &ops, int n, int K, int D, int LA,
                                int S, int WG, int compact = 0, bool fuse = false);
 std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int T, int D, int LA,
-                               bool quad = false);
+                               bool quad = false, int sparse = 0);
 // (sparse: 0 dense leaf vectors, 1 one observed state per leaf, 2 one or two allowed states)
 std::string rt_jit_mfma_split_source(const std::vector<rt_op> &ops, int n, int K, int T, int D,
                                      int LA, int sparse = 0);

@@ -745,9 +745,16 @@ static std::string rt_jit_mfma_quad_pp_source(const std::vector<rt_op> &ops, int
     return o.str();
 }
 
+// sparse (quad form only; 1: one observed state per leaf, 2: allowed sets of one or two states;
+// the batch's `sparse_ok`): a leaf's message is a column of its transition matrix or the sum of
+// two, and the 4 x 4 blocks of that matrix are parked in this wave's LDS buffer anyway -- a leaf
+// step reads its KS entries per lane and tile from there (qa[(j KS + state / 4) 16 + (state & 3) 4
+// + (lane >> 4)]) instead of running KS^2 block MFMAs, and its leaf vector never crosses HBM:
+// protein and compound-model alignments (20 states observed at every leaf, C5's allowed pairs).
 std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int T, int D, int LA,
-                               bool quad)
+                               bool quad, int sparse)
 {
+    if (sparse && !quad) return std::string();
     // RAOTEH_JIT_PINGPONG=1: two tile groups in turn (T even).  Not the default: measured
     // no faster (C5, T = 4: 69.8 us against 67.4; T = 2 on 2 048 tiles: 44.8 against 40.4)
     {
@@ -767,6 +774,7 @@ std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int 
     }
     std::ostringstream o;
     o << "// generated by raoteh_amd/csrc/jit.hip (MFMA family" << (quad ? ", 4x4x4 blocks" : "")
+      << (sparse == 2 ? ", leaf state pairs" : sparse ? ", leaf states" : "")
       << "): " << nrec << " steps, " << n
       << " states, " << K << " observed nodes, " << T << " tiles per wave, prefetch " << D
       << " leaves / " << LA << " P records\n";
@@ -792,7 +800,9 @@ std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int 
          "rt_jit_prune(const double *__restrict__ Pfrag, const rt_d2 *__restrict__ obs,\n"
          "             const double *__restrict__ root_w, double *__restrict__ loglik,\n"
          "             int *__restrict__ status, double *__restrict__ partial,\n"
-         "             long nsites, long nblocks, long first_tile, long stride)\n{\n"
+         "             long nsites, long nblocks, long first_tile, long stride"
+      << (sparse ? ", const unsigned *__restrict__ leafw, const double *__restrict__ Pesd" : "")
+      << ")\n{\n"
          "    if (blockIdx.x % stride) return;      // a sparse launch: every stride-th workgroup works\n";
     o << "    const int lane = threadIdx.x;\n";
     if (trace)      // the constant 100 MHz clock next to the shader clock: the core frequency
@@ -882,13 +892,34 @@ std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int 
                     o << "    const rt_d2 A" << i << "_" << m << "_" << q << " = ag[" << at << "];\n";
             }
     };
+    auto is_sparse_leaf = [&](const rt_op &op) {
+        return sparse && op.pop < 0 && op.obs >= 0 && op.dst >= 0;
+    };
+    // (sparse) the state words: four leaves a word (pairs: two), requested WA leaves ahead
+    const int per_word = sparse == 2 ? 2 : 4;
+    const int KW = (K + per_word - 1) / per_word;
+    const int WA = 6;
+    std::vector<char> word_seen((size_t)std::max(KW, 1), 0);
+    auto emit_words_upto = [&](int k) {          // the words of stream positions <= k
+        if (!sparse) return;
+        for (int w = 0; w <= std::min(k, K - 1) / per_word; ++w) {
+            if (word_seen[(size_t)w]) continue;
+            word_seen[(size_t)w] = 1;
+            for (int t = 0; t < T; ++t)
+                o << "    const unsigned lw" << w << "_" << t << " = leafw[((size_t)(tile" << t
+                  << " < nblocks ? tile" << t << " : nblocks - 1) * " << KW << " + " << w
+                  << ") * 16 + (lane & 15)];\n";
+        }
+    };
     // quad form: the blocks of step i + LA are parked at the end of step i and fetched PD
     // steps before that (RAOTEH_JIT_PARKDELAY, default 1: with the fetch at the top of the
     // same step the park waited on it at every step -- an L2 round trip is longer than
     // one chain of 2 x 25 block MFMAs)
     const char *pd_env = getenv("RAOTEH_JIT_PARKDELAY");
     const int PD = quad ? (pd_env ? std::max(0, atoi(pd_env)) : 1) : 0;
-    for (int k = 0; k < std::min(D, K); ++k) emit_obs_load(k);
+    if (!sparse)
+        for (int k = 0; k < std::min(D, K); ++k) emit_obs_load(k);
+    emit_words_upto(WA);
     for (int i = 0; i < std::min(LA + PD, nrec); ++i)
         if (ops[(size_t)i].dst >= 0) emit_a_load(i);
 
@@ -915,8 +946,44 @@ std::string rt_jit_mfma_source(const std::vector<rt_op> &ops, int n, int K, int 
             o << "    __builtin_amdgcn_sched_barrier(0);\n";
         stamp(i, 0);
         if (i + LA + PD < nrec && ops[(size_t)(i + LA + PD)].dst >= 0) emit_a_load(i + LA + PD);
-        if (op.obs >= 0 && op.obs + D < K) emit_obs_load(op.obs + D);
+        if (!sparse && op.obs >= 0 && op.obs + D < K) emit_obs_load(op.obs + D);
+        if (sparse && op.obs >= 0) emit_words_upto(op.obs + WA);
         if (op.dst >= 0) dep = "a" + std::to_string(op.dst & 255) + "_0_0";
+        if (is_sparse_leaf(op)) {
+            // ---- a leaf with observed state(s): columns of P from the parked blocks
+            o << "    {   // step " << i << ": leaf " << op.node << " (column" << (sparse == 2 ? "s" : "")
+              << " of P)\n";
+            const int w = op.obs / per_word;
+            const int sh = sparse == 2 ? 16 * (op.obs & 1) : 8 * (op.obs & 3);
+            const int d = op.dst & 255;
+            const bool first = (op.dst >> 8) != 0;
+            for (int t = 0; t < T; ++t) {
+                o << "    const int st" << t << " = (int)((lw" << w << "_" << t << " >> " << sh << ") & 255u);\n";
+                o << "    const double *qp" << t << " = qa" << (i & 1) << " + (st" << t << " >> 2) * 16 + (st"
+                  << t << " & 3) * 4 + (lane >> 4);\n";
+                if (sparse == 2) {
+                    o << "    const int sq" << t << " = (int)((lw" << w << "_" << t << " >> " << sh + 8
+                      << ") & 255u);\n";
+                    o << "    const int sr" << t << " = sq" << t << " == 255 ? st" << t << " : sq" << t << ";\n";
+                    o << "    const double *qq" << t << " = qa" << (i & 1) << " + (sr" << t << " >> 2) * 16 + (sr"
+                      << t << " & 3) * 4 + (lane >> 4);\n";
+                }
+                for (int j = 0; j < KS; ++j) {
+                    o << "    const double pc" << t << "_" << j << " = qp" << t << "[" << j * KS * 16 << "]";
+                    if (sparse == 2)
+                        o << " + (sq" << t << " == 255 ? 0.0 : qq" << t << "[" << j * KS * 16 << "])";
+                    o << ";\n";
+                }
+            }
+            // the next step's blocks (fetched at the top of this step) go to the other buffer
+            if (i + LA < nrec && ops[(size_t)(i + LA)].dst >= 0) emit_q_park(i + LA);
+            for (int t = 0; t < T; ++t)
+                for (int j = 0; j < KS; ++j)
+                    o << "    a" << d << "_" << t << "_" << j << (first ? " = " : " *= ") << "pc" << t << "_"
+                      << j << ";\n";
+            o << "    }\n";
+            continue;
+        }
         o << "    {   // step " << i << ": node " << op.node << "\n";
         for (int t = 0; t < T; ++t) {
             for (int j = 0; j < KS; ++j) {
@@ -2651,7 +2718,11 @@ int rt_launch_prune_jit(rt_model *m, rt_sites *s, const rt_fuse_args *fuse)
                           &stride1};
     void *args_sparse[] = {&Pord, &obs, &root_w, &loglik, &status, &partial, &nsites, &nblocks, &leafw,
                            &Pesd};
-    void **args = s->jit_sparse ? args_sparse : args_dense;
+    // (the one-wave family's leaf-state kernels: its own two arguments, then these)
+    void *args_solo_sparse[] = {&Pord, &obs, &root_w, &loglik, &status, &partial, &nsites, &nblocks,
+                                &tile0, &stride1, &leafw, &Pesd};
+    const bool solo_family = m->n <= 32 && s->mfma_solo;
+    void **args = s->jit_sparse ? (solo_family ? args_solo_sparse : args_sparse) : args_dense;
     if (s->jit_fn2) {
         // main kernel: jit_split_tiles tiles, jit_tiles per wave (one wave per SIMD); the rest
         // one tile per wave on the side stream, at the same time.  The timing events, when

@@ -68,9 +68,9 @@ def main():
                 states = rng.randint(0, 1 << n, size=(nsites, len(obs_nodes))).astype(np.uint64)
                 dense = ((states[..., None] >> np.arange(n, dtype=np.uint64)) & 1
                          ).astype(np.float64)
-        if n > 32 and rng.uniform() < 0.4:
+        if n > 4 and rng.uniform() < 0.4:
             # observed states at every leaf and nowhere else: the kernels whose leaves are
-            # gathered columns of P (serial and pipelined generators, root halves)
+            # gathered columns of P (one-wave 4x4x4 form; serial and pipelined split-M generators)
             obs_nodes = list(leaves)
             states = rng.randint(0, n, size=(nsites, len(obs_nodes))).astype(np.uint8)
             dense = np.zeros((nsites, len(obs_nodes), n))

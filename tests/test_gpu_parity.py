@@ -1112,7 +1112,7 @@ def test_leaf_state_kernels_gather_columns_bit_identically(ra, n, monkeypatch):
     ctx.close()
 
 
-@pytest.mark.parametrize('n', [40, 61, 96, 122])
+@pytest.mark.parametrize('n', [5, 12, 20, 24, 40, 61, 96, 122])
 def test_leaf_sets_of_one_or_two_states_are_gathered_columns(ra, n):
     """Allowed sets of one or two states at every leaf (the compound models: a codon in either
     class of the switching model, liwen.py:682) uploaded as masks: the specialised kernels add two
@@ -1161,6 +1161,21 @@ def test_leaf_sets_of_one_or_two_states_are_gathered_columns(ra, n):
     finally:
         ra.lib.check(set_option(b'jit', -1))
     np.testing.assert_array_equal(out[1][0], lld)
+    # the same with one observed state per leaf (n <= 32: the one-wave 4x4x4 kernels read the
+    # columns from the blocks they park in LDS; above: test_leaf_state_kernels_...)
+    if n <= 32:
+        st1 = a.astype(np.uint8)
+        res = {}
+        for jit in (0, 1):
+            ra.lib.check(set_option(b'jit', jit))
+            try:
+                bs = model.upload_sites(obs_nodes, st1, kind='state')
+                res[jit] = model.log_likelihoods(bs) + (bs.kernel_name,)
+            finally:
+                ra.lib.check(set_option(b'jit', -1))
+        assert 'leaf-states' in res[1][2] and '4x4' in res[1][2], res[1][2]
+        np.testing.assert_array_equal(res[1][0], res[0][0])
+        np.testing.assert_array_equal(res[1][1], res[0][1])
     # a set of three states somewhere: the dense kernels
     m3 = masks.copy()
     m3[0, 0, 0] = np.uint64(7)
