@@ -573,51 +573,53 @@ def measure_next_rows(ctx):
         bs.close()
         bd.close()
         model.close()
-        # c6 (allowed sets {c, 61 + c} at the leaves) uploaded as masks: a leaf's message is the
-        # sum of two gathered columns of P
-        cfg6 = synth.make_config('c6', nsites=10000)
-        T6, root6, n6 = cfg6['T'], cfg6['root'], cfg6['nstates']
-        model = _device.TreeModel(T6, root6, n6, ctx=ctx)
-        model.set_rates(Q_default=cfg6['Q_default'])
-        model.set_root_distn(cfg6['root_distn'])
-        words6 = (n6 + 63) // 64
-        table6 = np.zeros((len(cfg6['leaf_allowed']), words6), dtype=np.uint64)
-        for c6i, ss in enumerate(cfg6['leaf_allowed']):
-            for k6 in ss:
-                table6[c6i, k6 // 64] |= np.uint64(1) << np.uint64(k6 % 64)
-        bm = model.upload_sites(cfg6['leaves'], table6[cfg6['leaf_states']], kind='mask')
-        bm.wait_for_kernel()
-        for _ in range(5):
-            model.step(bm)
-        ctx.sync()
-        ctx.reset_timing()
-        ctx.set_timing(4)
-        times = []
-        for _ in range(5):
-            ctx.sync()
-            t0 = time.perf_counter()
-            for _ in range(10):
+        # c6 (allowed sets {c, 61 + c} at the leaves) and C5 (two compound states per observed
+        # primary state) uploaded as masks: a leaf's message is the sum of two columns of P
+        for wname, wsites in (('c6', 10000), ('c5', 50000)):
+            cfgm = synth.make_config(wname, nsites=wsites)
+            Tm, rootm, nm = cfgm['T'], cfgm['root'], cfgm['nstates']
+            model = _device.TreeModel(Tm, rootm, nm, ctx=ctx)
+            model.set_rates(Q_default=cfgm['Q_default'])
+            model.set_root_distn(cfgm['root_distn'])
+            wordsm = (nm + 63) // 64
+            tablem = np.zeros((len(cfgm['leaf_allowed']), wordsm), dtype=np.uint64)
+            for ci, ss in enumerate(cfgm['leaf_allowed']):
+                for km in ss:
+                    tablem[ci, km // 64] |= np.uint64(1) << np.uint64(km % 64)
+            mk = tablem[cfgm['leaf_states']]
+            bm = model.upload_sites(cfgm['leaves'], mk if wordsm > 1 else mk[..., 0], kind='mask')
+            bm.wait_for_kernel()
+            for _ in range(5):
                 model.step(bm)
             ctx.sync()
-            times.append((time.perf_counter() - t0) / 10)
-        kms, kcnt, kname = ctx.kernel_time(_l.RT_K_PRUNE)
-        ctx.set_timing(0)
-        dt6 = float(np.median(times))
-        nedges6 = T6.number_of_edges()
-        inner6 = sum(1 for v in T6 if T6.degree(v) > 1 and v != root6)
-        flops6 = 10000 * (2.0 * n6 * n6 * inner6 + n6 * nedges6 + 2.0 * n6)
-        out['leaf_sets_step_c6'] = dict(
-            sites=10000, ms_per_step=dt6 * 1e3, sites_per_s=10000 / dt6, kernel=bm.kernel_name,
-            avg_kernel_us=kms / max(kcnt, 1) * 1e3,
-            roofline=dict(bound='mfma', achieved=flops6 / (kms / max(kcnt, 1) * 1e-3) / 1e12, peak=peak,
-                          unit='TFLOP/s', frac=flops6 / (kms / max(kcnt, 1) * 1e-3) / 1e12 / peak,
-                          algorithmic_flops_per_launch=flops6,
-                          note='products at the %d inner edges only: a leaf edge is two column gathers'
-                               % inner6),
-            what='one step of the c6 batch uploaded as allowed-set masks (one or two states per '
-                 'leaf): NOT the encoding of workloads.c6 (dense 0/1 vectors)')
-        bm.close()
-        model.close()
+            ctx.reset_timing()
+            ctx.set_timing(4)
+            times = []
+            for _ in range(5):
+                ctx.sync()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    model.step(bm)
+                ctx.sync()
+                times.append((time.perf_counter() - t0) / 20)
+            kms, kcnt, kname = ctx.kernel_time(_l.RT_K_PRUNE)
+            ctx.set_timing(0)
+            dtm = float(np.median(times))
+            nedgesm = Tm.number_of_edges()
+            innerm = sum(1 for v in Tm if Tm.degree(v) > 1 and v != rootm)
+            flopsm = wsites * (2.0 * nm * nm * innerm + nm * nedgesm + 2.0 * nm)
+            out['leaf_sets_step_%s' % wname] = dict(
+                sites=wsites, ms_per_step=dtm * 1e3, sites_per_s=wsites / dtm, kernel=bm.kernel_name,
+                avg_kernel_us=kms / max(kcnt, 1) * 1e3,
+                roofline=dict(bound='mfma', achieved=flopsm / (kms / max(kcnt, 1) * 1e-3) / 1e12, peak=peak,
+                              unit='TFLOP/s', frac=flopsm / (kms / max(kcnt, 1) * 1e-3) / 1e12 / peak,
+                              algorithmic_flops_per_launch=flopsm,
+                              note='products at the %d inner edges only: a leaf edge is two column gathers'
+                                   % innerm),
+                what='one step of the %s batch uploaded as allowed-set masks (one or two states per '
+                     'leaf): NOT the encoding of workloads.%s (dense 0/1 vectors)' % (wname, wname))
+            bm.close()
+            model.close()
         # the same statistics on a RESIDENT batch (rt_expect_step): nothing marshalled or
         # uploaded per call; arithmetic of a call = upward pass + downward pass (products at
         # the internal nodes) + per-edge site sums, each 2 n^2 flops per edge and site, + one

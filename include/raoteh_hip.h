@@ -320,7 +320,7 @@ int rt_build_schedule(int64_t nnodes, const int64_t *tree_csr_indices,
  * threshold gets the default kernels' numbers bit for bit (powers of two are exact).
  * Likelihood evaluation only (rt_prune / rt_step): expectations stay unscaled.             */
 /* "leaf_state_kernels" (1 default / 0): a batch uploaded as observed states at the leaves
- * (RT_OBS_STATE, every leaf observed, 33..128 states) may run a tree-specialised kernel whose
+ * (RT_OBS_STATE, every leaf observed, 5..128 states) may run a tree-specialised kernel whose
  * leaf steps gather a column of P instead of multiplying P by the one-hot vector -- the same
  * numbers bit for bit, about half the products; likewise RT_OBS_MASK batches whose leaves all
  * have one or two allowed states (two columns added); 0 keeps the products (what a dense upload
