@@ -409,7 +409,7 @@ extern "C" int rt_model_destroy(rt_model *m)
     rt_expect_lane_release(m);
     hipStreamSynchronize(m->ctx->stream);
     hipFree(m->d_indices); hipFree(m->d_indptr); hipFree(m->d_ops); hipFree(m->d_P);
-    hipFree(m->d_Pfrag); hipFree(m->d_Pquad); hipFree(m->d_root); hipFree(m->d_Q); hipFree(m->d_spec); hipFree(m->d_qidx);
+    hipFree(m->d_Pfrag); hipFree(m->d_Pquad); hipFree(m->d_Pcol); hipFree(m->d_root); hipFree(m->d_Q); hipFree(m->d_spec); hipFree(m->d_qidx);
     hipFree(m->d_t); hipFree(m->d_info); hipFree(m->d_step_of_node);
     hipFree(m->d_qidx_step); hipFree(m->d_t_step);
     delete m;
@@ -534,14 +534,14 @@ static int model_run_expm(rt_model *m)
                                   m->d_Pquad));
         m->have_P = true;
         m->frag_dirty = false;
-        return RT_OK;
+        return rt_model_pack_pcol(m);
     }
     RT_TRY(rt_launch_expm(m->ctx, m->n, m->nnodes, m->d_Q, m->d_qidx, m->d_t, m->d_P,
                           m->d_info, m->d_step_of_node, m->n <= 4 ? 0 : 1, m->d_Pfrag,
                           carry ? &red : nullptr, m->d_Pquad));
     m->have_P = true;
     m->frag_dirty = false;
-    return RT_OK;
+    return rt_model_pack_pcol(m);
 }
 
 extern "C" int rt_model_set_rates(rt_model *m, const double *Q, int64_t nq,
@@ -1679,6 +1679,8 @@ static int sites_create_impl(rt_model *m, int64_t nsites, int kind, int64_t nobs
         s->sparse_ok = ok;
         s->sparse_pairs = ok;
     }
+    // (the split-M leaf-state kernels read the columns from the model's leaf-column table)
+    if (s->sparse_ok && !s->mfma_solo) RT_TRY(rt_model_need_pcol(m));
     int rc = sites_jit(s, generic || s->rescale, kind, ov);    // before the layout is fixed: block_sites
     // a freshly compiled kernel is checked against the interpreter kernel on a probe batch
     // before any user batch may launch it; if it fails this batch runs the interpreter

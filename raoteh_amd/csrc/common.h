@@ -146,6 +146,11 @@ struct rt_model {
     // four blocks of that instruction share A: 4 rows x 16 sites per instruction, so 20
     // states cost 5 x 5 instructions of 16 cycles instead of 2 x 5 of 64)
     double *d_Pquad = nullptr;
+    // leaf-column table for the split-M leaf-state kernels (jit.hip, `sparse`): column s of the
+    // step's P with the four rows a lane owns adjacent, Pcol[rec][s][m][lane >> 4][r] =
+    // P[16 m + 4 r + (lane >> 4)][s]; allocated when the first such batch is created, rewritten
+    // whenever the transition matrices change
+    double *d_Pcol = nullptr;
     double *d_root = nullptr;       // [n] root weights (ones if unset)
     // rt_model_set_rates_spectral: A [n][n], B [n][n], lam [n], D [n] of the decomposition
     // (spectral.hip); while `spectral` is set the transitions are rebuilt from these
@@ -332,6 +337,8 @@ int rt_flush_reduce(rt_ctx *ctx);
             hipLaunchKernelGGL(kern, grid, block, lds, (ctx)->stream, __VA_ARGS__);     \
     } while (0)
 int rt_launch_pfrag(rt_model *m);
+int rt_model_pack_pcol(rt_model *m);            // (no-op without d_Pcol)
+int rt_model_need_pcol(rt_model *m);            // allocate + fill from the current d_P
 // fuse_expm: the pruning launch computes the transitions from the resident rates itself
 // (batches with jit_fused only) and carries the pending reduction
 int rt_launch_prune(rt_model *m, rt_sites *s, bool defer_reduce = false, bool fuse_expm = false);

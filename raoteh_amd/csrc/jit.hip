@@ -1236,7 +1236,7 @@ std::string rt_jit_mfma_split_source(const std::vector<rt_op> &ops, int n, int K
                 o << "    const unsigned lw" << w << "_" << t << " = leafw[((size_t)(tile" << t
                   << " < nblocks ? tile" << t << " : nblocks - 1) * " << KW << " + " << w
                   << ") * 16 + (lane & 15)];\n";
-        o << "    const double *pfm = Pfrag + (m * " << KP * 128 << " + (lane >> 4) * 2);\n";
+        o << "    const rt_d4 *pcm = (const rt_d4 *)Pesd + (4 * m + (lane >> 4));\n";
     }
     // the four entries of this lane of column `state` of P_node, from the step's A-fragment
     // record (zero in the padded rows): the four row-lanes of a site share a 64-byte sector
@@ -1247,24 +1247,22 @@ std::string rt_jit_mfma_split_source(const std::vector<rt_op> &ops, int n, int K
         for (int t = 0; t < T; ++t) {
             o << "    const int st" << i << "_" << t << " = (int)((lw" << w << "_" << t
               << " >> " << sh << ") & 255u);\n";
-            o << "    const double *pf" << i << "_" << t << " = pfm + " << (long)i * NT * KP * 128 << " + (st"
-              << i << "_" << t << " >> 3) * 128 + (st" << i << "_" << t << " & 3) * 32 + ((st" << i << "_"
-              << t << " >> 2) & 1);\n";
+            o << "    const rt_d4 pf" << i << "_" << t << " = pcm[(" << (long)i * n << " + st" << i << "_" << t
+              << ") * " << 4 * NT << "];\n";
             if (sparse == 2) {
                 // the second allowed state (255: none -- the first column again, not added)
                 o << "    const int sq" << i << "_" << t << " = (int)((lw" << w << "_" << t << " >> " << sh + 8
                   << ") & 255u);\n";
                 o << "    const int sr" << i << "_" << t << " = sq" << i << "_" << t << " == 255 ? st" << i << "_"
                   << t << " : sq" << i << "_" << t << ";\n";
-                o << "    const double *pg" << i << "_" << t << " = pfm + " << (long)i * NT * KP * 128 << " + (sr"
-                  << i << "_" << t << " >> 3) * 128 + (sr" << i << "_" << t << " & 3) * 32 + ((sr" << i << "_"
-                  << t << " >> 2) & 1);\n";
+                o << "    const rt_d4 pg" << i << "_" << t << " = pcm[(" << (long)i * n << " + sr" << i << "_" << t
+                  << ") * " << 4 * NT << "];\n";
             }
             for (int r = 0; r < 4; ++r) {
                 o << "    const double pc" << i << "_" << t << "_" << r << " = pf" << i << "_" << t << "["
-                  << 8 * r << "]";
+                  << r << "]";
                 if (sparse == 2)
-                    o << " + (sq" << i << "_" << t << " == 255 ? 0.0 : pg" << i << "_" << t << "[" << 8 * r
+                    o << " + (sq" << i << "_" << t << " == 255 ? 0.0 : pg" << i << "_" << t << "[" << r
                       << "])";
                 o << ";\n";
             }
@@ -1816,8 +1814,10 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
                 o << "    double a" << sl << "_" << t << "_" << r << " = 1.0;\n";
     }
     o << "    const rt_d2 zero2 = {0.0, 0.0};\n";
-    if (sparse)      // this wave's row tile of every A-fragment record, at this lane's row-lane
-        o << "    const double *pfm = Pfrag + (m * " << KP * 128 << " + (lane >> 4) * 2);\n";
+    // (sparse) the leaf-column table (rt_model::d_Pcol, passed as Pesd): column s of step rec at
+    // [(rec n + s) RN + 16 m + 4 (lane >> 4) + r] -- this lane's four rows are one 32-byte load
+    if (sparse)
+        o << "    const rt_d4 *pcm = (const rt_d4 *)Pesd + (4 * m + (lane >> 4));\n";
     // the root step: x of the root -> weighted sum over the states (_mc0_dense.py:184-209,
     // as prune_mfma_kernel); xp = name prefix of the root's x values (xp_<tile>_<row>)
     auto emit_root_reduce = [&](std::ostream &os, const std::string &xp) {
@@ -1941,25 +1941,23 @@ std::string rt_jit_mfma_split_pipelined_source(const std::vector<rt_op> &ops, in
         for (int t = 0; t < T; ++t) {
             os << "    const int st" << lf.node << "_" << t << " = (int)((lw" << prog << "_" << w << "_" << t
                << " >> " << shf << ") & 255u);\n";
-            os << "    const double *pf" << lf.node << "_" << t << " = pfm + " << (long)rec * NT * KP * 128
-               << " + (st" << lf.node << "_" << t << " >> 3) * 128 + (st" << lf.node << "_" << t
-               << " & 3) * 32 + ((st" << lf.node << "_" << t << " >> 2) & 1);\n";
+            os << "    const rt_d4 pf" << lf.node << "_" << t << " = pcm[(" << (long)rec * n << " + st" << lf.node
+               << "_" << t << ") * " << 4 * NT << "];\n";
             if (sparse == 2) {
                 // the second allowed state (255: none -- the first column again, not added)
                 os << "    const int sq" << lf.node << "_" << t << " = (int)((lw" << prog << "_" << w << "_" << t
                    << " >> " << shf + 8 << ") & 255u);\n";
                 os << "    const int sr" << lf.node << "_" << t << " = sq" << lf.node << "_" << t
                    << " == 255 ? st" << lf.node << "_" << t << " : sq" << lf.node << "_" << t << ";\n";
-                os << "    const double *pg" << lf.node << "_" << t << " = pfm + " << (long)rec * NT * KP * 128
-                   << " + (sr" << lf.node << "_" << t << " >> 3) * 128 + (sr" << lf.node << "_" << t
-                   << " & 3) * 32 + ((sr" << lf.node << "_" << t << " >> 2) & 1);\n";
+                os << "    const rt_d4 pg" << lf.node << "_" << t << " = pcm[(" << (long)rec * n << " + sr" << lf.node
+                   << "_" << t << ") * " << 4 * NT << "];\n";
             }
             for (int r = 0; r < 4; ++r) {
                 os << "    const double pc" << lf.node << "_" << t << "_" << r << " = pf" << lf.node << "_" << t
-                   << "[" << 8 * r << "]";
+                   << "[" << r << "]";
                 if (sparse == 2)
                     os << " + (sq" << lf.node << "_" << t << " == 255 ? 0.0 : pg" << lf.node << "_" << t << "["
-                       << 8 * r << "])";
+                       << r << "])";
                 os << ";\n";
             }
         }
@@ -2713,7 +2711,7 @@ int rt_launch_prune_jit(rt_model *m, rt_sites *s, const rt_fuse_args *fuse)
     // the column-gathering split-M kernels declare the leaf-state words and the transition
     // matrices in the reference's order in those two places
     const unsigned *leafw = s->d_leafw;
-    const double *Pesd = m->d_P;
+    const double *Pesd = (s->jit_sparse && !(m->n <= 32 && s->mfma_solo) && m->d_Pcol) ? m->d_Pcol : m->d_P;
     void *args_dense[] = {&Pord, &obs, &root_w, &loglik, &status, &partial, &nsites, &nblocks, &tile0,
                           &stride1};
     void *args_sparse[] = {&Pord, &obs, &root_w, &loglik, &status, &partial, &nsites, &nblocks, &leafw,

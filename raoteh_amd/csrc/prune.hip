@@ -1480,6 +1480,40 @@ __global__ void pack_leaf_pairs_kernel(const unsigned long long *__restrict__ da
 static int ks_of(int64_t n) { return (int)((n + 3) / 4); }
 static int nt_of(int64_t n) { return (int)((n + 15) / 16); }
 
+// leaf-column table (rt_model::d_Pcol): Pcol[step][s][m][q][r] = P[node][16 m + 4 r + q][s]
+__global__ void pack_pcol_kernel(const double *__restrict__ P, const rt_op *__restrict__ ops,
+                                 int nops, int n, int NT, double *__restrict__ out)
+{
+    const int i = blockIdx.x;
+    const rt_op op = ops[i];
+    const int RN = 16 * NT;
+    const long total = (long)n * RN;
+    for (long e = threadIdx.x; e < total; e += blockDim.x) {
+        const int s = (int)(e / RN), x = (int)(e - (long)s * RN);
+        const int row = 16 * (x >> 4) + 4 * (x & 3) + ((x >> 2) & 3);
+        out[(long)i * total + e] =
+            (op.dst >= 0 && row < n) ? P[(long)op.node * n * n + (long)row * n + s] : 0.0;
+    }
+}
+
+int rt_model_pack_pcol(rt_model *m)
+{
+    if (!m->d_Pcol || m->n <= 4) return RT_OK;
+    hipLaunchKernelGGL(pack_pcol_kernel, dim3((unsigned)m->ops.size()), dim3(256), 0, m->ctx->stream,
+                       m->d_P, m->d_ops, (int)m->ops.size(), (int)m->n, (int)((m->n + 15) / 16),
+                       m->d_Pcol);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_model_need_pcol(rt_model *m)
+{
+    if (m->d_Pcol || m->n <= 4) return RT_OK;
+    const size_t rn = (size_t)16 * ((m->n + 15) / 16);
+    RT_HIP(hipMalloc((void **)&m->d_Pcol, m->ops.size() * (size_t)m->n * rn * 8));
+    return m->have_P ? rt_model_pack_pcol(m) : RT_OK;
+}
+
 int rt_launch_pfrag(rt_model *m)
 {
     if (!m->frag_dirty) return RT_OK;
@@ -1497,6 +1531,7 @@ int rt_launch_pfrag(rt_model *m)
                                m->d_ops, nops, n, ks_of(n), m->d_Pquad);
     }
     RT_HIP(hipGetLastError());
+    RT_TRY(rt_model_pack_pcol(m));
     m->frag_dirty = false;
     return RT_OK;
 }
