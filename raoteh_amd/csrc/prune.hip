@@ -1480,19 +1480,43 @@ __global__ void pack_leaf_pairs_kernel(const unsigned long long *__restrict__ da
 static int ks_of(int64_t n) { return (int)((n + 3) / 4); }
 static int nt_of(int64_t n) { return (int)((n + 15) / 16); }
 
-// leaf-column table (rt_model::d_Pcol): Pcol[step][s][m][q][r] = P[node][16 m + 4 r + q][s]
-__global__ void pack_pcol_kernel(const double *__restrict__ P, const rt_op *__restrict__ ops,
-                                 int nops, int n, int NT, double *__restrict__ out)
+// leaf-column table (rt_model::d_Pcol): Pcol[step][s][m][q][r] = P[node][16 m + 4 r + q][s].
+// A transpose: 32 columns at a time through LDS, so that both the reads of P (rows) and the
+// writes of the table (columns) are contiguous runs (strided on one side it cost 9.8 us per
+// step of the 61-state model).
+__global__ void __launch_bounds__(256)
+pack_pcol_kernel(const double *__restrict__ P, const rt_op *__restrict__ ops, int nops, int n,
+                 int NT, double *__restrict__ out)
 {
+    __shared__ double tile[128][33];
     const int i = blockIdx.x;
     const rt_op op = ops[i];
+    if (op.pop >= 0 || op.dst < 0) return;      // only the leaves' records are ever read
     const int RN = 16 * NT;
-    const long total = (long)n * RN;
-    for (long e = threadIdx.x; e < total; e += blockDim.x) {
-        const int s = (int)(e / RN), x = (int)(e - (long)s * RN);
-        const int row = 16 * (x >> 4) + 4 * (x & 3) + ((x >> 2) & 3);
-        out[(long)i * total + e] =
-            (op.dst >= 0 && row < n) ? P[(long)op.node * n * n + (long)row * n + s] : 0.0;
+    const double *Pn = P + (long)op.node * n * n;
+    double *o = out + (long)i * n * RN;
+    const bool live = op.dst >= 0;
+    for (int c0 = 0; c0 < n; c0 += 32) {
+        // (all of a thread's loads of the chunk in flight together: n <= 128 rows are at most 16)
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = threadIdx.x + 256 * u;
+            const int row = e >> 5, c = e & 31;
+            v[u] = (live && row < n && c0 + c < n) ? Pn[(long)row * n + c0 + c] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = threadIdx.x + 256 * u;
+            if ((e >> 5) < n) tile[e >> 5][e & 31] = v[u];
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 32 * RN; e += 256) {
+            const int c = e / RN, x = e - c * RN;
+            const int row = 16 * (x >> 4) + 4 * (x & 3) + ((x >> 2) & 3);
+            if (c0 + c < n) o[(long)(c0 + c) * RN + x] = row < n ? tile[row][c] : 0.0;
+        }
+        __syncthreads();
     }
 }
 
