@@ -186,6 +186,17 @@ def test_spectral_reconstruction_matches_the_reference_qtop(ra):
         twin.set_root_distn(w)
         ll2, st2 = twin.log_likelihoods(twin.upload_sites(leaves, states, kind='state'))
         np.testing.assert_array_equal(ll, ll2)
+        # a tree-specialised kernel on the same batch (for n > 4 one whose leaves are gathered
+        # columns: the model's leaf-column table must follow the spectral rebuild too)
+        ra.lib.check(ra.lib.lib().rt_set_option(b'jit', 1))
+        try:
+            bj = model.upload_sites(leaves, states, kind='state')
+            model.step(bj)
+            llj, _ = model.fetch_log_likelihoods(bj)
+            assert 'jit' in bj.kernel_name
+        finally:
+            ra.lib.check(ra.lib.lib().rt_set_option(b'jit', -1))
+        np.testing.assert_array_equal(llj, ll)
         if 'P_expm' in c and n > 4:
             # ... and against expm of the same rate matrix (Q = S diag(D) = A diag(lam) B)
             Q = (A * lam[None, :]) @ B
