@@ -659,7 +659,7 @@ struct rt_interp_halves {
 // waves; 4 < NT <= 8, i.e. 64 < n <= 128 states: one tile of NT waves)
 __host__ __device__ constexpr int rt_split_waves(int NT) { return NT == 3 ? 3 : (NT < 4 ? 4 : NT); }
 
-template <int NT, int KS, bool STORE>
+template <int NT, int KS, bool STORE, bool SPARSE = false>
 __global__ void __launch_bounds__(rt_split_waves(NT) * 64)
 prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
                   const int4_t *__restrict__ prog, int nops,   // LOP_* program
@@ -668,8 +668,15 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
                   double *__restrict__ loglik, int *__restrict__ status,
                   double *__restrict__ partial, long nsites, long nblocks16,
                   double *__restrict__ Lout, double *__restrict__ Mout, rt_interp_halves hv,
-                  int rescale)
+                  int rescale, const unsigned *__restrict__ leafw, const double *__restrict__ Pcol,
+                  int sparse_mode)
 {
+    // (a compile-time switch: as a run-time one the leaf path cost the dense instance 35 %)
+    const int sparse = SPARSE ? sparse_mode : 0;
+    // sparse (1: one observed state per leaf, 2: allowed sets of one or two; batches whose
+    // `sparse_ok` holds): a leaf step is a gathered column of P (or two, added) from the model's
+    // leaf-column table instead of an x exchange and KS MFMAs -- what the tree-specialised
+    // kernels do (jit.hip), for the trees that have none: more than 600 steps, or not compiled yet.
     // Lout / Mout (optional): own rows of L_v and of the message M_v = P_v L_v of every step,
     // [step][tile][m][r][lane] -- what the downward pass and the site sums of the expectation
     // path read back (csrc/expect_mfma.hip)
@@ -722,7 +729,7 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
         an[2 * q] = v.x;
         an[2 * q + 1] = v.y;
     }
-    if (knext < K) {
+    if (!SPARSE && knext < K) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int q = 2 * m + h;
@@ -738,8 +745,45 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
     double cur[4] = {1.0, 1.0, 1.0, 1.0};      // register-cached top accumulator
     int escale = 0;               // rescaling: exponent tally of this lane's site (lane & 15)
 
+    // ---- sparse leaves: the state words (two in flight) and the gathered column of the NEXT
+    // leaf step, requested when the step before it starts its products
+    const int per_word = sparse == 2 ? 2 : 4;
+    const int KW = (K + per_word - 1) / per_word;
+    const unsigned *lwp = SPARSE ? leafw + (size_t)blk * KW * 16 + (lane & 15) : nullptr;
+    const double4_t *pcm = (const double4_t *)Pcol + (4 * m + (lane >> 4));
+    int lwidx = SPARSE ? kobs0 / per_word : 0;
+    unsigned lwcur = 0, lwnext = 0;
+    if constexpr (SPARSE) {
+        lwcur = lwp[(size_t)lwidx * 16];
+        lwnext = lwp[(size_t)(lwidx + 1 < KW ? lwidx + 1 : lwidx) * 16];
+    }
+    double4_t pcn = {0.0, 0.0, 0.0, 0.0}, pcq = {0.0, 0.0, 0.0, 0.0};
+    bool pair_on = false;
+    // the column(s) of the leaf whose step is program index `step`, stream position kpos
+    auto gather = [&](int step, int kpos) {
+        const int wq = kpos / per_word;
+        if (wq != lwidx) {                       // (uniform) the next word becomes the current one
+            lwcur = lwnext;
+            lwidx = wq;
+            lwnext = lwp[(size_t)(wq + 1 < KW ? wq + 1 : wq) * 16];
+        }
+        const int sh = sparse == 2 ? 16 * (kpos & 1) : 8 * (kpos & 3);
+        const int sa = (int)((lwcur >> sh) & 255u);
+        pcn = pcm[((size_t)(rec0 + step) * n + sa) * (4 * NT)];
+        if (sparse == 2) {
+            const int sb = (int)((lwcur >> (sh + 8)) & 255u);
+            pair_on = sb != 255;
+            pcq = pcm[((size_t)(rec0 + step) * n + (sb != 255 ? sb : sa)) * (4 * NT)];
+        }
+    };
+    auto is_sleaf = [&](int f) { return SPARSE && !(f & LOP_INTERNAL) && (f & LOP_OBS); };
+    if constexpr (SPARSE) {
+        if (is_sleaf(op.x)) gather(0, kobs0);
+    }
+
     for (int i = 0; i < nops; ++i) {
         const int flags = op.x;
+        const bool sleaf = SPARSE && is_sleaf(flags);      // (uniform)
         // own rows of L_v = (accumulator of v) * (observation at v)
         double x[4];
         if (flags & LOP_INTERNAL) {
@@ -797,20 +841,33 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
             }
             break;
         }
-        __syncthreads();      // every wave is done reading the previous step's x
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xb[((4 * m + r) * 64) + lane] = x[r];
-
         double a[2 * KP];
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+        if (SPARSE && sleaf) {
+            // the message of this leaf: its column(s), requested one step ago (one rounding for
+            // two columns, as the chain of the matrix pipe adds two non-zero terms)
+            acc = pcn;
+            if (sparse == 2 && pair_on) {
 #pragma unroll
-        for (int j = 0; j < 2 * KP; ++j) a[j] = an[j];
-
-        __syncthreads();      // x of every wave of the tile is in LDS
+                for (int r = 0; r < 4; ++r) acc[r] = pcn[r] + pcq[r];
+            }
+        } else {
+            __syncthreads();      // every wave is done reading the previous step's x
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xb[((4 * m + r) * 64) + lane] = x[r];
+#pragma unroll
+            for (int j = 0; j < 2 * KP; ++j) a[j] = an[j];
+            __syncthreads();      // x of every wave of the tile is in LDS
+        }
 
         // start everything the next step needs
         const int inext = (i + 1 < nops) ? i + 1 : i;
         const int4_t opn = prog_c[inext];
-        if (!(opn.x & LOP_ROOT)) {
+        if (SPARSE && is_sleaf(opn.x)) {
+            if constexpr (SPARSE) {
+                if (inext != i) gather(inext, knext);
+            }
+        } else if (!(opn.x & LOP_ROOT)) {
 #pragma unroll
             for (int q = 0; q < KP; ++q) {
                 const double2 v = *(const double2 *)(ag + (size_t)inext * ASTRIDE + q * 128);
@@ -818,7 +875,7 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
                 an[2 * q + 1] = v.y;
             }
         }
-        if ((flags & LOP_OBS) && knext < K) {
+        if (!SPARSE && (flags & LOP_OBS) && knext < K) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int q = 2 * m + h;
@@ -829,13 +886,14 @@ prune_mfma_kernel(const double *__restrict__ Pfrag,  // [nops][NT][KP][64][2]
             }
         }
 
-        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+        if (!sleaf) {
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            const double b = xb[kk * 64 + lane];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], b, acc, 0, 0, 0);
+            for (int kk = 0; kk < KS; ++kk) {
+                const double b = xb[kk * 64 + lane];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], b, acc, 0, 0, 0);
+            }
         }
-        if (rescale) {
+        if (rescale && !sleaf) {
             // every wave of the tile sees all of x as its B operands: the site's largest
             // entry, the same number in every lane of the site and in every wave
             double xmax = 0.0;
@@ -1781,9 +1839,18 @@ static int launch_mfma_inst(rt_model *m, rt_sites *s)
     const int lds = (TILES * NT * 4 * 64 + TILES * NT * 16) * 8 + WAVES * lds_slots * 2048;
     const unsigned grid = (unsigned)((s->nblocks + TILES - 1) / TILES);
     // the instance with the two stores only when somebody asked for L and M (expect_mfma.hip)
-    auto kern = s->d_Lout ? prune_mfma_kernel<NT, KS, true> : prune_mfma_kernel<NT, KS, false>;
+    // observed states / small allowed sets at every leaf: the leaf steps gather (the model's
+    // leaf-column table exists once such a batch does); above 32 states only (below, the
+    // one-wave kernels run)
+    const bool isp = NT > 2 && s->sparse_ok && s->d_leafw && m->d_Pcol && !s->d_Lout && !s->rescale &&
+                     !getenv("RAOTEH_INTERP_NO_SPARSE");
+    auto kern = s->d_Lout ? prune_mfma_kernel<NT, KS, true>
+                : isp ? prune_mfma_kernel<NT, KS, false, (NT > 2)> : prune_mfma_kernel<NT, KS, false>;
     RT_HIP(hipFuncSetAttribute((const void *)kern,
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const unsigned *ilw = isp ? s->d_leafw : nullptr;
+    const double *ipc = isp ? m->d_Pcol : nullptr;
+    const int ism = isp ? (s->sparse_pairs ? 2 : 1) : 0;
     rt_interp_halves hv;
     if (s->interp_halves && !s->d_Lout) {
         // the two root programs as even / odd workgroups, then the combine kernel
@@ -1797,7 +1864,7 @@ static int launch_mfma_inst(rt_model *m, rt_sites *s)
                            m->d_Pfrag, (const int4_t *)s->d_lane_ops_a, hv.nops0,
                            s->d_obs, (int)s->nobs, m->d_root, (int)m->n, lds_slots,
                            s->d_loglik, s->d_status, s->d_partial, (long)s->nsites,
-                           (long)s->nblocks, s->d_Lout, s->d_Mout, hv, 0);
+                           (long)s->nblocks, s->d_Lout, s->d_Mout, hv, 0, ilw, ipc, ism);
         hipEvent_t ca = nullptr, cb = nullptr;
         rt_time_extra_begin(m->ctx, RT_K_COMBINE, "prune_mfma_combine", &ca, &cb);
         auto ckern = prune_mfma_combine_kernel<NT>;
@@ -1820,7 +1887,8 @@ static int launch_mfma_inst(rt_model *m, rt_sites *s)
                        s->d_obs, (int)s->nobs, m->d_root, (int)m->n, lds_slots,
                        s->d_loglik, s->d_status, s->d_partial, (long)s->nsites,
                        (long)s->nblocks, s->d_Lout, s->d_Mout, hv,
-                       (int)(s->rescale && !s->d_Lout));     // L and M are stored unscaled
+                       (int)(s->rescale && !s->d_Lout),      // L and M are stored unscaled
+                       ilw, ipc, ism);
     return RT_OK;
 }
 
@@ -1830,7 +1898,9 @@ static int launch_mfma(rt_model *m, rt_sites *s, const char **name)
     snprintf(s->kernel_name, sizeof(s->kernel_name), "prune_mfma%s<%d,%d%s%s>",
              s->mfma_solo ? "_solo" : "", nt_of(m->n), ks,
              s->interp_halves && !s->mfma_solo && !s->d_Lout ? ",halves" : "",
-             s->rescale && !s->d_Lout ? ",rescale" : "");
+             s->rescale && !s->d_Lout ? ",rescale"
+             : (m->n > 32 && s->sparse_ok && !s->mfma_solo && s->d_leafw && m->d_Pcol && !s->d_Lout &&
+                !getenv("RAOTEH_INTERP_NO_SPARSE")) ? ",leaf-states" : "");
     *name = s->kernel_name;
     switch (ks) {
     case 2: return launch_mfma_inst<1, 2>(m, s);

@@ -1162,7 +1162,10 @@ def test_leaf_sets_of_one_or_two_states_are_gathered_columns(ra, n):
                 assert 'leaf-states' in twin.kernel_name
         finally:
             ra.lib.check(set_option(b'jit', -1))
-    assert 'leaf-states' in out[1][2] and 'leaf-states' not in out[0][2], (out[0][2], out[1][2])
+    # (above 32 states the interpreter kernel gathers at the leaves too; the dense upload below
+    # runs the products)
+    assert 'leaf-states' in out[1][2] and 'jit' in out[1][2] and out[0][2].startswith('prune_mfma'), \
+        (out[0][2], out[1][2])
     np.testing.assert_array_equal(out[1][0], out[0][0])
     np.testing.assert_array_equal(out[1][1], out[0][1])
     ra.lib.check(set_option(b'jit', 0))
