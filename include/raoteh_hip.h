@@ -309,7 +309,10 @@ int rt_build_schedule(int64_t nnodes, const int64_t *tree_csr_indices,
  * cache directory: RAOTEH_JIT_CACHE_DIR, default ~/.cache/raoteh_amd/jit; RAOTEH_JIT_CACHE=0
  * disables it) while the batch runs the interpreter kernel; a later rt_prune / rt_step swaps
  * the kernel in once it is there and has passed the probe verification.  rt_sites_jit_wait
- * blocks until that has happened (or failed: the batch then stays on the interpreter).   */
+ * blocks until that has happened (or failed: the batch then stays on the interpreter).
+ * At most RAOTEH_JIT_MAX_JOBS (default 2) such threads run at a time in a process: a batch
+ * created while they are busy keeps the interpreter kernel (a search over topologies does
+ * not pile up compiles; set "jit" to 0 there to skip the source generation as well).     */
 /* "rescale" (0 default / 1): batches created while it is set rescale their messages on the
  * way up -- whenever the largest entry of a site's message falls below 2^-256 the message is
  * multiplied by the exact power of two that brings it back to [1, 2) and the exponent is kept

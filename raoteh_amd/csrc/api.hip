@@ -1137,13 +1137,38 @@ struct jit_override {
     bool pipe = false;        // ... from the pipelined generator (leaves as factors)
 };
 
+// At most this many background compiles at a time (RAOTEH_JIT_MAX_JOBS, default 2): a caller
+// that creates batches over ever new trees (a search over topologies with "jit" left on
+// automatic) would otherwise start a host thread inside hiprtc per tree.  A batch created
+// while the limit is reached stays on the interpreter kernel (same numbers).
+static bool jit_jobs_full()
+{
+    int limit = 2;
+    if (const char *v = getenv("RAOTEH_JIT_MAX_JOBS")) limit = std::max(0, atoi(v));
+    return rt_jit_jobs_pending() >= limit;
+}
+
 // Background compile for an MFMA-family batch: candidates the cache already knows as
 // rejected are skipped; if the first one left is usable the caller's synchronous path takes
-// it from the cache (fast), else a job compiles the remaining ones in order (-> true).
+// it from the cache (fast: -> false), else a job compiles the remaining ones in order, or
+// none may start now and the batch keeps the interpreter kernel (-> true: nothing more to do
+// in rt_sites_create).
 template <class MakeSource>
 static bool sites_jit_start_async(rt_sites *s, const std::vector<rt_sites::jit_cand> &cands,
                                   MakeSource make)
 {
+    if (jit_jobs_full()) {
+        // without generating every candidate's text: is the preferred usable form cached?
+        for (const auto &c : cands) {
+            const std::string src = make(c);
+            if (src.empty()) continue;
+            const int known = rt_jit_cached(s->model->ctx, src);
+            if (known < 0) continue;
+            if (known > 0) return false;
+            break;
+        }
+        return true;
+    }
     std::vector<rt_sites::jit_cand> todo;
     std::vector<std::string> srcs;
     for (const auto &c : cands) {
@@ -1496,7 +1521,10 @@ static int sites_jit(rt_sites *s, bool generic, int kind, const jit_override *ov
     // not in this context's cache yet: compile in the background; the batch is created in the
     // interpreter's layout, keeps the caller's observations on the device and is packed again
     // for the kernel when it arrives (rt_sites_jit_poll)
-    if (!forced && opt_jit_async(s->model->ctx) && rt_jit_cached(s->model->ctx, src) == 0) {
+    const bool background = !forced && opt_jit_async(s->model->ctx) &&
+                            rt_jit_cached(s->model->ctx, src) == 0;
+    if (background && jit_jobs_full()) return RT_OK;    // the interpreter kernel, no new thread
+    if (background) {
         s->jit_lane.S = S;
         s->jit_lane.WG = WG;
         s->jit_lane.D = D;

@@ -375,6 +375,7 @@ std::shared_ptr<rt_jit_job> rt_jit_start(rt_ctx *ctx, std::vector<std::string> s
 bool rt_jit_job_done(rt_jit_job *job, bool wait);
 void rt_jit_job_result(rt_jit_job *job, int *rc, int *chosen, double *seconds, std::string *error);
 void rt_jit_join_all(const rt_ctx *ctx);
+int rt_jit_jobs_pending();
 // (ctx, src): 1 compiled and usable, -1 compiled and rejected, 0 unknown (no reference taken)
 int rt_jit_cached(const rt_ctx *ctx, const std::string &src);
 // api.hip: swap the finished background kernel of a batch in (wait: join the job first)

@@ -2531,8 +2531,29 @@ std::shared_ptr<rt_jit_job> rt_jit_start(rt_ctx *ctx, std::vector<std::string> s
         j->done.store(1, std::memory_order_release);
     });
     std::lock_guard<std::mutex> lock(g_jobs_mutex);
+    // finished jobs nobody holds any more (their batches are gone): join and drop them, so
+    // that a long run over many trees does not keep every job's source texts
+    for (auto it = g_jobs.begin(); it != g_jobs.end();) {
+        if ((*it)->done.load(std::memory_order_acquire) && it->use_count() == 1) {
+            if ((*it)->worker.joinable()) (*it)->worker.join();
+            it = g_jobs.erase(it);
+        } else {
+            ++it;
+        }
+    }
     g_jobs.push_back(job);
     return job;
+}
+
+// background compiles still running (whatever their context): rt_sites_create starts no
+// further one beyond the limit of api.hip -- every job is a host thread inside hiprtc
+int rt_jit_jobs_pending()
+{
+    std::lock_guard<std::mutex> lock(g_jobs_mutex);
+    int pending = 0;
+    for (const auto &j : g_jobs)
+        if (!j->done.load(std::memory_order_acquire)) ++pending;
+    return pending;
 }
 
 // A compile thread must not be inside hiprtc when the process runs its exit handlers (the

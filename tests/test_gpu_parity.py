@@ -2204,6 +2204,79 @@ def test_objects_in_a_reference_cycle_are_finalised_in_a_safe_order(ra):
     assert not batch._h and not model._h and not ctx._h
 
 
+def test_background_compiles_are_bounded_over_many_trees(ra, tmp_path, monkeypatch):
+    """A caller that creates batches over ever new trees with "jit" on automatic (a search
+    over topologies) gets at most RAOTEH_JIT_MAX_JOBS (default 2) compile threads at a time:
+    the batches created meanwhile stay on the interpreter kernel -- same numbers -- and a
+    tree met again later gets its kernel then (from the cache if it was compiled before)."""
+    monkeypatch.setenv('RAOTEH_JIT_CACHE_DIR', str(tmp_path / 'jit'))
+    rng = np.random.RandomState(4242)
+    n, nsites = 61, 3000
+    ctx = ra.device.Context(0)
+    ctx.set_option('jit_async', 1)
+    made = []
+    for k in range(6):
+        T, root, obs_nodes, w = _random_case(ra, rng, n, 40 + k, nsites)
+        pre, idx, ptr, esd = orc.get_esd_transitions(T, root, n)
+        dense = rng.uniform(0.05, 1.0, size=(nsites, len(obs_nodes), n))
+        model = ra.device.TreeModel(T, root, n, ctx=ctx)
+        model.set_transitions(esd)
+        model.set_root_distn(w)
+        batch = model.upload_sites(obs_nodes, dense, kind='dense')
+        ll0, st0 = model.log_likelihoods(batch)
+        want, wst = orc.batch_log_likelihoods(idx, ptr, esd, [pre.index(v) for v in obs_nodes],
+                                              dense, w)
+        np.testing.assert_allclose(ll0, want, rtol=RTOL_LL)
+        made.append((model, batch, ll0, (T, root, obs_nodes, w, esd, dense)))
+    # six creates take milliseconds each, a 61-state compile a second or more: the first two
+    # trees got a job, not every later one did
+    kinds = []
+    for model, batch, ll0, _ in made:
+        batch.wait_for_kernel()
+        ll1, _ = model.log_likelihoods(batch)
+        np.testing.assert_array_equal(ll0, ll1)
+        assert batch.kernel_name.startswith(('prune_tree_jit', 'prune_mfma')), batch.kernel_name
+        kinds.append(batch.kernel_name.startswith('prune_tree_jit'))
+    assert kinds[0] and kinds[1], kinds
+    assert not all(kinds), kinds
+    # every job has finished: a tree that stayed on the interpreter gets its kernel on the
+    # next visit, the first tree's kernel comes from the cache
+    late = kinds.index(False)
+    for k in (late, 0):
+        T, root, obs_nodes, w, esd, dense = made[k][3]
+        model = ra.device.TreeModel(T, root, n, ctx=ctx)
+        model.set_transitions(esd)
+        model.set_root_distn(w)
+        batch = model.upload_sites(obs_nodes, dense, kind='dense')
+        batch.wait_for_kernel()
+        ll2, _ = model.log_likelihoods(batch)
+        assert batch.kernel_name.startswith('prune_tree_jit'), (k, batch.kernel_name)
+        np.testing.assert_array_equal(made[k][2], ll2)
+        batch.close()
+        model.close()
+    for model, batch, _, _ in made:
+        batch.close()
+        model.close()
+    # RAOTEH_JIT_MAX_JOBS=0: never compile in the background
+    monkeypatch.setenv('RAOTEH_JIT_MAX_JOBS', '0')
+    T, root, obs_nodes, w = _random_case(ra, rng, n, 33, nsites)
+    pre, idx, ptr, esd = orc.get_esd_transitions(T, root, n)
+    dense = rng.uniform(0.05, 1.0, size=(nsites, len(obs_nodes), n))
+    model = ra.device.TreeModel(T, root, n, ctx=ctx)
+    model.set_transitions(esd)
+    model.set_root_distn(w)
+    batch = model.upload_sites(obs_nodes, dense, kind='dense')
+    batch.wait_for_kernel()
+    ll, st = model.log_likelihoods(batch)
+    assert batch.kernel_name.startswith('prune_mfma'), batch.kernel_name
+    want, wst = orc.batch_log_likelihoods(idx, ptr, esd, [pre.index(v) for v in obs_nodes],
+                                          dense, w)
+    np.testing.assert_allclose(ll, want, rtol=RTOL_LL)
+    batch.close()
+    model.close()
+    ctx.close()
+
+
 def test_background_compile_and_persistent_code_object_cache(ra, tmp_path, monkeypatch):
     """jit_async: rt_sites_create returns without waiting for hiprtc, the batch (and a clone
     made meanwhile) runs the interpreter kernel and switches to the tree-specialised one when
