@@ -2224,17 +2224,17 @@ def test_background_compiles_are_bounded_over_many_trees(ra, tmp_path, monkeypat
         model.set_root_distn(w)
         batch = model.upload_sites(obs_nodes, dense, kind='dense')
         ll0, st0 = model.log_likelihoods(batch)
-        want, wst = orc.batch_log_likelihoods(idx, ptr, esd, [pre.index(v) for v in obs_nodes],
-                                              dense, w)
-        np.testing.assert_allclose(ll0, want, rtol=RTOL_LL)
-        made.append((model, batch, ll0, (T, root, obs_nodes, w, esd, dense)))
+        made.append((model, batch, ll0, (T, root, obs_nodes, w, esd, dense),
+                     (idx, ptr, [pre.index(v) for v in obs_nodes])))
     # six creates take milliseconds each, a 61-state compile a second or more: the first two
     # trees got a job, not every later one did
     kinds = []
-    for model, batch, ll0, _ in made:
+    for model, batch, ll0, case, (idx, ptr, oidx) in made:
         batch.wait_for_kernel()
         ll1, _ = model.log_likelihoods(batch)
         np.testing.assert_array_equal(ll0, ll1)
+        want, wst = orc.batch_log_likelihoods(idx, ptr, case[4], oidx, case[5], case[3])
+        np.testing.assert_allclose(ll0, want, rtol=RTOL_LL)
         assert batch.kernel_name.startswith(('prune_tree_jit', 'prune_mfma')), batch.kernel_name
         kinds.append(batch.kernel_name.startswith('prune_tree_jit'))
     assert kinds[0] and kinds[1], kinds
@@ -2254,7 +2254,7 @@ def test_background_compiles_are_bounded_over_many_trees(ra, tmp_path, monkeypat
         np.testing.assert_array_equal(made[k][2], ll2)
         batch.close()
         model.close()
-    for model, batch, _, _ in made:
+    for model, batch, _, _, _ in made:
         batch.close()
         model.close()
     # RAOTEH_JIT_MAX_JOBS=0: never compile in the background
