@@ -651,3 +651,95 @@ def test_tmjp_get_inhomogeneous_mjp_matches_the_reference_twin():
             np.array([1], dtype=np.int64), np.array([0, 1, 1], dtype=np.int64),
             np.array([0, 7], dtype=np.int64), np.array([0, 0], dtype=np.int64), np.zeros((2, 2)),
             1.0, 1.0, 0, np.ones((2, 2), dtype=np.int64), np.zeros((2, 3, 3)))
+
+
+def _hiprtc_compile(src, vgpr_form):
+    """hiprtc with the options rt_jit_get uses (csrc/jit.hip); returns the code object."""
+    import ctypes
+    rtc = ctypes.CDLL('libhiprtc.so')
+    prog = ctypes.c_void_p()
+    assert rtc.hiprtcCreateProgram(ctypes.byref(prog), src, b'rt_jit_prune.hip', 0, None,
+                                   None) == 0
+    opts = [b'--offload-arch=gfx950', b'-O3', b'-std=c++17']
+    if vgpr_form:
+        opts += [b'-mllvm', b'-amdgpu-mfma-vgpr-form=1']
+    arr = (ctypes.c_char_p * len(opts))(*opts)
+    rc = rtc.hiprtcCompileProgram(prog, len(opts), arr)
+    if rc != 0:
+        sz = ctypes.c_size_t()
+        rtc.hiprtcGetProgramLogSize(prog, ctypes.byref(sz))
+        log = ctypes.create_string_buffer(sz.value + 1)
+        rtc.hiprtcGetProgramLog(prog, log)
+        raise AssertionError('hiprtc: ' + log.value.decode()[:3000])
+    sz = ctypes.c_size_t()
+    rtc.hiprtcGetCodeSize(prog, ctypes.byref(sz))
+    code = ctypes.create_string_buffer(sz.value)
+    rtc.hiprtcGetCode(prog, code)
+    rtc.hiprtcDestroyProgram(ctypes.byref(prog))
+    return code.raw
+
+
+def test_every_generator_emits_source_that_compiles_for_gfx950(tmp_path, monkeypatch):
+    """The text of every tree-specialised family -- lane, one-wave MFMA (16x16x4 and 4x4x4
+    blocks), split-M serial / pipelined / root halves / folded combine, NT = 8 waves above 64
+    states, and the leaf-state / leaf-set forms of each -- goes through hiprtc for gfx950 with
+    the product's options, here, without a device: no compiler error, no scratch (the
+    rejection rule of rt_jit_get), the kernel symbols rt_sites_create looks up."""
+    import ctypes
+    import re
+    import subprocess
+    from raoteh_amd import _lib, synth
+    from raoteh_amd._tree import TreeArrays
+    p64 = ctypes.POINTER(ctypes.c_int64)
+    buf = ctypes.create_string_buffer(1 << 24)
+    readelf = '/opt/rocm/lib/llvm/bin/llvm-readelf'
+    knobs = ('RAOTEH_JIT_TILES', 'RAOTEH_JIT_QUAD', 'RAOTEH_JIT_HALVES', 'RAOTEH_JIT_FOLD',
+             'RAOTEH_JIT_SOURCE_SPARSE', 'RAOTEH_JIT_SOURCE_STATES')
+    cases = [
+        # (states, leaves of the balanced tree, prefetch, environment)
+        (3, 8, 3, {}),
+        (4, 8, 3, {'RAOTEH_JIT_SOURCE_STATES': '1'}),
+        (20, 8, 2, {'RAOTEH_JIT_TILES': '2'}),
+        (20, 8, 2, {'RAOTEH_JIT_TILES': '2', 'RAOTEH_JIT_SOURCE_SPARSE': '1'}),
+        (13, 8, 2, {'RAOTEH_JIT_TILES': '1', 'RAOTEH_JIT_SOURCE_SPARSE': '2'}),
+        (32, 8, 2, {'RAOTEH_JIT_TILES': '2', 'RAOTEH_JIT_QUAD': '0'}),
+        (61, 8, 2, {'RAOTEH_JIT_TILES': '2'}),
+        (61, 8, 2, {'RAOTEH_JIT_TILES': '3', 'RAOTEH_JIT_HALVES': '1'}),
+        (48, 8, 2, {'RAOTEH_JIT_TILES': '2', 'RAOTEH_JIT_HALVES': '1', 'RAOTEH_JIT_FOLD': '1'}),
+        (61, 8, 2, {'RAOTEH_JIT_TILES': '2', 'RAOTEH_JIT_SOURCE_SPARSE': '1'}),
+        (61, 8, 2, {'RAOTEH_JIT_TILES': '2', 'RAOTEH_JIT_HALVES': '1',
+                    'RAOTEH_JIT_SOURCE_SPARSE': 'pipe'}),
+        (33, 8, 2, {'RAOTEH_JIT_TILES': '1', 'RAOTEH_JIT_SOURCE_SPARSE': 'pipe2'}),
+        (122, 4, 2, {'RAOTEH_JIT_TILES': '1', 'RAOTEH_JIT_HALVES': '1'}),
+        (122, 4, 2, {'RAOTEH_JIT_TILES': '1', 'RAOTEH_JIT_HALVES': '1',
+                     'RAOTEH_JIT_SOURCE_SPARSE': 'pipe2'}),
+        (97, 4, 2, {'RAOTEH_JIT_TILES': '1', 'RAOTEH_JIT_SOURCE_SPARSE': '1'}),
+    ]
+    for k, (n, nleaves, prefetch, env) in enumerate(cases):
+        for name in knobs:
+            monkeypatch.delenv(name, raising=False)
+        for name, value in env.items():
+            monkeypatch.setenv(name, value)
+        T, root, leaves = synth.balanced_tree(nleaves, seed=k)
+        ta = TreeArrays(T, root)
+        obs = np.array(sorted(ta.node_to_index[v] for v in leaves), dtype=np.int64)
+        _lib.check(_lib.lib().rt_jit_source(
+            ta.nnodes, ta.indices.ctypes.data_as(p64), ta.indptr.ctypes.data_as(p64), n,
+            len(obs), obs.ctypes.data_as(p64), prefetch, buf, len(buf)))
+        src = buf.value
+        assert src, (n, env)
+        # the leaf-state forms read the leaves' state words and have fewer matrix steps
+        assert (b'leafw' in src) == ('RAOTEH_JIT_SOURCE_SPARSE' in env), (n, env)
+        code = _hiprtc_compile(src, vgpr_form=n > 4)
+        path = tmp_path / ('k%d.co' % k)
+        path.write_bytes(code)
+        notes = subprocess.run([readelf, '--notes', str(path)], stdout=subprocess.PIPE,
+                               check=True).stdout.decode()
+        names = re.findall(r'\.name:\s+(\S+)', notes)
+        assert 'rt_jit_prune' in names, (n, env, names)
+        assert ('rt_jit_combine' in names) == \
+            (env.get('RAOTEH_JIT_HALVES') == '1' and n > 32 and
+             env.get('RAOTEH_JIT_SOURCE_SPARSE') != '1'), (n, env, names)
+        scratch = [int(v) for v in re.findall(r'\.private_segment_fixed_size:\s+(\d+)', notes)]
+        spills = [int(v) for v in re.findall(r'\.vgpr_spill_count:\s+(\d+)', notes)]
+        assert scratch and max(scratch) == 0 and max(spills + [0]) == 0, (n, env, scratch, spills)
