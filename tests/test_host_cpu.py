@@ -743,3 +743,47 @@ def test_every_generator_emits_source_that_compiles_for_gfx950(tmp_path, monkeyp
         scratch = [int(v) for v in re.findall(r'\.private_segment_fixed_size:\s+(\d+)', notes)]
         spills = [int(v) for v in re.findall(r'\.vgpr_spill_count:\s+(\d+)', notes)]
         assert scratch and max(scratch) == 0 and max(spills + [0]) == 0, (n, env, scratch, spills)
+
+
+def test_library_kernels_have_no_scratch_beyond_the_known_few(tmp_path):
+    """Register pressure is what the hot kernels are tuned against: a kernel that starts to
+    spill to scratch is a performance regression no parity test sees.  The code objects inside
+    libraoteh_hip.so (llvm-objdump --offloading, no device needed): scratch only in the listed
+    kernels, within the listed bytes -- the order-above-64 exponentials at 7 and 8 row tiles,
+    the legacy global-scratch exponential they replaced, the weighted site sums."""
+    import re
+    import shutil
+    import subprocess
+    from raoteh_amd import _lib
+    objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    readelf = '/opt/rocm/lib/llvm/bin/llvm-readelf'
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip('llvm-objdump / llvm-readelf not found')
+    so = tmp_path / 'lib.so'
+    shutil.copy(_lib.LIB_PATH, so)
+    subprocess.run([objdump, '--offloading', str(so)], cwd=tmp_path, check=True,
+                   stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    objs = sorted(tmp_path.glob('lib.so.*gfx950'))
+    assert len(objs) >= 8, objs                      # one per translation unit with kernels
+    allowed = {                                      # mangled-name fragment -> bytes
+        'expm_taylor_kernelILi5ELb1': 1100, 'expm_taylor_kernelILi6ELb1': 1100,
+        'expm_taylor_kernelILi7ELb1': 1100, 'expm_taylor_kernelILi8ELb1': 1100,
+        'expm_taylor_wide_kernelILi8ELb1': 160, 'expm_taylor_wide_kernelILi7ELb0': 64,
+        'expm_taylor_wide_kernelILi8ELb0': 80, 'expect_wsum_kernelILi4ELb1': 16,
+    }
+    seen = 0
+    hot = 0
+    for obj in objs:
+        notes = subprocess.run([readelf, '--notes', str(obj)], stdout=subprocess.PIPE,
+                               check=True).stdout.decode()
+        for block in re.split(r'\n\s+- \.agpr_count:', notes)[1:]:
+            name = re.search(r'\.name:\s+(\S+)', block).group(1)
+            scratch = int(re.search(r'\.private_segment_fixed_size:\s+(\d+)', block).group(1))
+            seen += 1
+            limit = max([v for k, v in allowed.items() if k in name] + [0])
+            assert scratch <= limit, (name, scratch, limit)
+            if re.search(r'prune_mfma_kernel|expect_down_lds_kernel|expm_taylor_kernelILi\dELb0|'
+                         r'spectral_kernel|expect_wsum_kernelILi\dELb0', name):
+                hot += 1
+                assert scratch == 0, (name, scratch)
+    assert seen > 300 and hot >= 40, (seen, hot)
