@@ -759,6 +759,8 @@ def test_library_kernels_have_no_scratch_beyond_the_known_few(tmp_path):
     readelf = '/opt/rocm/lib/llvm/bin/llvm-readelf'
     if not (os.path.exists(objdump) and os.path.exists(readelf)):
         pytest.skip('llvm-objdump / llvm-readelf not found')
+    if 'debug' in os.path.basename(_lib.LIB_PATH):
+        pytest.skip('the sanitizer build (make debug-test) is not the tuned one')
     so = tmp_path / 'lib.so'
     shutil.copy(_lib.LIB_PATH, so)
     subprocess.run([objdump, '--offloading', str(so)], cwd=tmp_path, check=True,
